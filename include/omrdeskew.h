@@ -1,0 +1,220 @@
+/*
+ * omrdeskew.h -- C ABI of libomrdeskew.so, the MI355X-native OMR deskew engine.
+ *
+ * This is the drop-in boundary for the projection-std-dev angle sweep of
+ * ch1ny/omr-img-corrector (crate `oics`, packages/lib).  The reference has no FFI layer of its
+ * own (it calls OpenCV through the `opencv` crate); a Rust shim crate `oics` binds these entry
+ * points 1:1 in an `extern "C"` block (INTEGRATION.md shows it).  Every entry point cites the
+ * reference interface it replaces as file:line under /root/reference.
+ *
+ * Conventions
+ *   - images are 8-bit, row-major, `channels` interleaved, `step_bytes >= cols*channels`;
+ *     inputs are borrowed and never written; outputs are caller-allocated unless stated.
+ *   - return value: 0 on success, otherwise a negative OpenCV-style code
+ *     (-215 assertion / bad shape, -5 bad argument, -4 out of memory, -213 not implemented,
+ *      -217 GPU API error).  omr_last_error() gives the thread-local message.
+ *   - no exceptions and no aborts cross the ABI; all entry points are thread-safe and
+ *     re-entrant (the Tauri host runs several corrections at once: thread_pool.rs:41-88).
+ *   - there is NO CPU fallback: without a usable HIP device every compute entry point
+ *     fails with -217.
+ *   - `_device` entry points take device pointers (hipMalloc'ed, same device as the plan) and a
+ *     hipStream_t passed as void*; they enqueue work and return without synchronising.
+ */
+#ifndef OMRDESKEW_H
+#define OMRDESKEW_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OMR_OK 0
+#define OMR_ERR_ASSERT (-215)
+#define OMR_ERR_BADARG (-5)
+#define OMR_ERR_NOMEM (-4)
+#define OMR_ERR_NOTIMPL (-213)
+#define OMR_ERR_GPU (-217)
+
+/* Borrowed image view: stands for `&opencv::core::Mat` / `&TransformableMatrix`
+ * (packages/lib/src/transfer.rs:16-18). */
+typedef struct {
+    const uint8_t *data;
+    int32_t rows, cols, channels;
+    int64_t step_bytes;
+} omr_image;
+
+/* Owned image returned by the library (free with omr_image_free): stands for the fresh
+ * `TransformableMatrix` every reference helper returns (transfer.rs:55-59). */
+typedef struct {
+    uint8_t *data;
+    int32_t rows, cols, channels;
+    int64_t step_bytes;
+} omr_image_owned;
+
+/* types.rs:7-11 RotateClipStrategy */
+#define OMR_CLIP_DEFAULT 0
+#define OMR_CLIP_CONTAIN 1
+/* omr.rs:41-45 ResultStatus */
+#define OMR_STATUS_BELIEVED 0
+#define OMR_STATUS_NEED_CHECK 1
+#define OMR_STATUS_NOT_A_RESULT 2
+/* interpolation flags as the reference passes them (0 = INTER_NEAREST = WARP_POLAR_LINEAR's
+ * numeric value, transfer.rs / projection.rs:52; 1 = INTER_LINEAR, core/src/main.rs:76) */
+#define OMR_INTER_NEAREST 0
+#define OMR_INTER_LINEAR 1
+
+int omr_version(void);
+int omr_device_count(void);
+const char *omr_last_error(void);
+void omr_image_free(omr_image_owned *img);
+
+/* ---- geometry helpers ---------------------------------------------------------------- */
+
+/* imgproc::get_rotation_matrix_2d(center: Point2f, angle, scale) -> 2x3 f64;
+ * call sites transfer.rs:475,501; omr.rs:159-163,425-426. */
+int omr_get_rotation_matrix_2d(float cx, float cy, double angle_deg, double scale, double M[6]);
+
+/* `(max_angle as f64 / step) as u16` and the half-open candidate range -N..N
+ * (projection.rs:36-38, omr.rs:140-145).  Returns A = 2N (>= 0); *N_out = N. */
+int omr_candidate_count(uint16_t max_angle, double step, int32_t *N_out);
+
+/* The A forward matrices of a sweep over an image of rows x cols: centre
+ * (cols as f32 / 2, rows as f32 / 2), angle (i - N) * step, scale (transfer.rs:473-475;
+ * omr.rs:157-163 passes scale = projection_resize_scale).  M_out: A x 6 doubles. */
+int omr_sweep_matrices(int32_t rows, int32_t cols, uint16_t max_angle, double step, double scale,
+                       double *M_out, int32_t cap_A);
+
+/* ---- the hot path ---------------------------------------------------------------------- */
+
+/* One scan, A candidate matrices, host buffers.  For every candidate: nearest-neighbour
+ * warpAffine of the binarised image onto the same canvas with a white border, per-column and
+ * per-row count of pixels == 0, population std-dev of each projection.
+ * Replaces the body of projection.rs:47-65 / omr.rs:153-180:
+ *   rotate_mat DEFAULT (transfer.rs:459-486) -> get_projection_standard_deviations
+ *   (transfer.rs:527-536) or get_mat_projection_data (omr.rs:8-39) + calculate.rs:13-23.
+ * bin_u8c1: 1 channel; a pixel is black iff its value == 0.
+ * fwd_M: A x 6 row-major forward matrices as produced by getRotationMatrix2D.
+ * vproj (A x cols) and hproj (A x rows) may be NULL; v_sd / h_sd: A doubles each. */
+int omr_projection_sweep(const omr_image *bin_u8c1, const double *fwd_M, int32_t A,
+                         uint32_t *vproj, uint32_t *hproj, double *v_sd, double *h_sd);
+
+/* Resident form of the same path: device buffers and fixed-point tables are created once per
+ * (rows, cols, matrices) and reused for every scan of that shape. */
+typedef struct omr_sweep_plan omr_sweep_plan;
+
+int omr_sweep_plan_create(int32_t rows, int32_t cols, const double *fwd_M, int32_t A,
+                          int32_t device, omr_sweep_plan **plan_out);
+int omr_sweep_plan_create_angles(int32_t rows, int32_t cols, uint16_t max_angle, double step,
+                                 double scale, int32_t device, omr_sweep_plan **plan_out);
+void omr_sweep_plan_destroy(omr_sweep_plan *plan);
+int omr_sweep_plan_candidates(const omr_sweep_plan *plan); /* A */
+
+/* Enqueue one scan on `stream`.  d_img: device u8, 1 channel, rows x cols, row pitch
+ * step_bytes.  A pixel is black iff value <= black_max: pass 0 for an image binarised by
+ * transfer_gray_image_to_thresh_binary (transfer.rs:294-301), 127 to fuse that threshold
+ * (threshold(127,255,BINARY) then == 0  <=>  gray <= 127) into the load.
+ * Outputs are device pointers; any of d_vproj (A x cols u32), d_hproj (A x rows u32),
+ * d_best_idx (1 int32: projection.rs:125-190 arg-max, lowest index on exact ties) may be NULL.
+ * d_v_sd / d_h_sd: A doubles each. */
+int omr_sweep_plan_run_device(omr_sweep_plan *plan, const uint8_t *d_img, int64_t step_bytes,
+                              int32_t black_max, void *stream, uint32_t *d_vproj,
+                              uint32_t *d_hproj, double *d_v_sd, double *d_h_sd,
+                              int32_t *d_best_idx);
+
+/* Same, host image in / host results out (synchronous: H2D, sweep, D2H on `plan`'s stream). */
+int omr_sweep_plan_run(omr_sweep_plan *plan, const omr_image *img_u8c1, int32_t black_max,
+                       uint32_t *vproj, uint32_t *hproj, double *v_sd, double *h_sd,
+                       int32_t *best_idx);
+
+/* Duration in ms of the sweep kernel of the most recent omr_sweep_plan_run*(), measured with
+ * HIP events on the stream it was launched on (bench.py's roofline line). Synchronises. */
+int omr_sweep_plan_last_kernel_ms(omr_sweep_plan *plan, float *ms_out);
+/* Toggle event recording around the sweep kernel (off by default). */
+int omr_sweep_plan_set_timing(omr_sweep_plan *plan, int32_t enabled);
+/* Select the sweep kernel: 0 = automatic, 1 = generic global-memory kernel, 2 = LDS-staged
+ * kernel (fails with -5 when a candidate's source footprint does not fit). For tests. */
+int omr_sweep_plan_set_kernel(omr_sweep_plan *plan, int32_t which);
+/* Debug/parity hook: copy the fixed-point tables of candidate `a` to host
+ * (adelta, bdelta: cols ints; X0, Y0: rows ints) -- OpenCV hal::warpAffine's tables. */
+int omr_sweep_plan_tables(omr_sweep_plan *plan, int32_t a, int32_t *adelta, int32_t *bdelta,
+                          int32_t *X0, int32_t *Y0);
+
+/* Batch of n scans (all rows x cols, 1 channel) resident on the plan's device, scan i at
+ * d_scans + i * scan_stride_bytes.  Scans are independent (one correct_default per file,
+ * app/src-tauri/src/task.rs:19-38): they are issued round-robin on `n_streams` internal
+ * streams; no collective is involved.  Outputs are device pointers: d_best_idx (n int32),
+ * d_v_sd / d_h_sd (n x A doubles, may be NULL).  Returns after enqueueing; call
+ * omr_batch_sync() or synchronise the device before reading. */
+typedef struct omr_batch_ctx omr_batch_ctx;
+int omr_batch_create(int32_t rows, int32_t cols, uint16_t max_angle, double step, double scale,
+                     int32_t device, int32_t n_streams, omr_batch_ctx **ctx_out);
+void omr_batch_destroy(omr_batch_ctx *ctx);
+int omr_batch_run_device(omr_batch_ctx *ctx, const uint8_t *d_scans, int64_t scan_stride_bytes,
+                         int64_t step_bytes, int32_t n, int32_t black_max, int32_t *d_best_idx,
+                         double *d_v_sd, double *d_h_sd);
+int omr_batch_sync(omr_batch_ctx *ctx);
+/* Sum of the sweep-kernel durations (ms) and their count since the last call (timing must be
+ * enabled with omr_batch_set_timing). Synchronises. */
+int omr_batch_set_timing(omr_batch_ctx *ctx, int32_t enabled);
+int omr_batch_kernel_ms(omr_batch_ctx *ctx, double *sum_ms, int32_t *launches);
+
+/* Host-buffer batch over the visible devices (SURVEY.md 8b `omr_sweep_batch`): scans[i] goes
+ * to device i % n_devices; the only "collective" is the host-side gather of the results.
+ * best_angle[i] = (best_idx[i] - N) * step (projection.rs:189-190). */
+int omr_sweep_batch(const omr_image *scans, int32_t n, uint16_t max_angle, double step,
+                    int32_t n_devices, int32_t *best_idx, double *best_angle, double *v_sd_opt,
+                    double *h_sd_opt);
+
+/* ---- drivers with the reference's signatures ------------------------------------------ */
+
+/* oics::projection::get_angle_with_projections(&TransformableMatrix, u16, f64, f64, usize) -> f64
+ * (projection.rs:17-23).  src: 3 or 4 channels as the reference requires (cvtColor RGB2GRAY);
+ * 1 channel is accepted and skips the conversion.  threads_hint is ignored (the reference's
+ * multi-thread branch is buggy, projection.rs:94, and no caller uses it). */
+int omr_get_angle_with_projections(const omr_image *src, uint16_t max_angle, double step,
+                                   double resize_scale, size_t threads_hint, double *angle_out);
+
+/* find_target_angle(max_angle, step, thresh, threads) -> f64 on an already binarised image
+ * (app/src-tauri/src/test.rs:83-178, the in-app copy of the same driver). */
+int omr_find_target_angle(uint16_t max_angle, double step, const omr_image *thresh_u8c1,
+                          size_t threads_hint, double *angle_out);
+
+/* oics::omr::get_result_from_projection(&Mat, u16, f64, i32, i32) -> Result<OmrResult>
+ * (omr.rs:52-229).  candidates receives min(cand_len, cand_cap) angles. */
+int omr_get_result_from_projection(const omr_image *src, uint16_t max_angle, double step,
+                                   int32_t max_w, int32_t max_h, double *angle, int32_t *status,
+                                   double *candidates, int32_t cand_cap, int32_t *cand_len);
+
+/* projection.rs:125-190 on host arrays (also used by the drivers above). */
+int omr_argmax_projection(const double *v_sd, const double *h_sd, int32_t n, int32_t *index_out);
+/* omr.rs:147-221 on host arrays. */
+int omr_select_projection_result(const double *v_sd, const double *h_sd, int32_t n, int32_t N,
+                                 double step, double *angle, int32_t *status, double *candidates,
+                                 int32_t cand_cap, int32_t *cand_len);
+
+/* ---- per-image helpers of crate `oics` (GPU-backed) ------------------------------------- */
+
+/* transfer::transfer_gray_image_to_thresh_binary (transfer.rs:294-301): dst = src>127 ? 255 : 0 */
+int omr_threshold_binary(const omr_image *gray_u8c1, uint8_t *dst, int64_t dst_step_bytes);
+/* transfer::transfer_rgb_image_to_gray_image (transfer.rs:283-290): cvtColor RGB2GRAY on 3/4 ch */
+int omr_rgb_to_gray(const omr_image *src, uint8_t *dst, int64_t dst_step_bytes);
+/* transfer::rotate_mat (transfer.rs:459-523); border_value = Scalar(b, g, r, a) as u8. */
+int omr_rotate(const omr_image *src, double angle_deg, double scale, int32_t interp,
+               const uint8_t border_value[4], int32_t clip, omr_image_owned *dst);
+/* transfer::get_vertical_projection / get_horizontal_projection (transfer.rs:380-405, :305-333) */
+int omr_get_vertical_projection(const omr_image *bin_u8c1, double *out_cols);
+int omr_get_horizontal_projection(const omr_image *bin_u8c1, double *out_rows);
+/* omr::get_mat_projection_data (omr.rs:8-39): (horizontal[rows], vertical[cols]) */
+int omr_get_mat_projection_data(const omr_image *bin_u8c1, double *h_rows, double *v_cols);
+/* transfer::get_projection_standard_deviations (transfer.rs:527-536): (vertical, horizontal) */
+int omr_get_projection_standard_deviations(const omr_image *bin_u8c1, double *v_sd, double *h_sd);
+/* calculate::get_arithmetic_mean / get_standard_deviation (calculate.rs:2-10, :13-23) */
+int omr_get_arithmetic_mean(const double *v, size_t n, double *out);
+int omr_get_standard_deviation(const double *v, size_t n, double *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,525 @@
+// engine.cpp -- plans, scratch and the enqueue sequence behind the C ABI.
+// Built with hipcc -ffp-contract=off: the host-side matrix arithmetic below must round exactly
+// like OpenCV's (no FMA contraction).
+#include "engine.hpp"
+
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/omrdeskew.h"
+
+namespace omr {
+
+static thread_local std::string g_err;
+
+int fail(int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+int fail_gpu(const char *what, hipError_t e)
+{
+    return fail(OMR_ERR_GPU, "HIP error %d (%s) in %s", (int)e, hipGetErrorString(e), what);
+}
+
+const char *last_error() { return g_err.c_str(); }
+void clear_error() { g_err.clear(); }
+
+hipError_t DevBuf::alloc(size_t n)
+{
+    release();
+    if (n == 0) n = 16;
+    hipError_t e = hipMalloc(&p, n);
+    if (e == hipSuccess) bytes = n;
+    else p = nullptr;
+    return e;
+}
+
+void DevBuf::release()
+{
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    bytes = 0;
+}
+
+// ---- OpenCV 4.6.0 geometry on the host ------------------------------------------------------
+
+// getRotationMatrix2D_; call sites transfer.rs:475, omr.rs:159-163.
+void rotation_matrix_2d(float cx, float cy, double angle_deg, double scale, double M[6])
+{
+    const double CV_PI_ = 3.1415926535897932384626433832795;
+    double angle = angle_deg * (CV_PI_ / 180);
+    double alpha = cos(angle) * scale;
+    double beta = sin(angle) * scale;
+    M[0] = alpha;
+    M[1] = beta;
+    M[2] = (1 - alpha) * (double)cx - beta * (double)cy;
+    M[3] = -beta;
+    M[4] = alpha;
+    M[5] = beta * (double)cx + (1 - alpha) * (double)cy;
+}
+
+// cv::warpAffine's in-place inversion, same operation order.
+void invert_affine(const double Min[6], double M[6])
+{
+    memcpy(M, Min, 6 * sizeof(double));
+    double D = M[0] * M[4] - M[1] * M[3];
+    D = D != 0 ? 1. / D : 0;
+    double A11 = M[4] * D, A22 = M[0] * D;
+    M[0] = A11;
+    M[1] *= -D;
+    M[3] *= -D;
+    M[4] = A22;
+    double b1 = -M[0] * M[2] - M[1] * M[5];
+    double b2 = -M[3] * M[2] - M[4] * M[5];
+    M[2] = b1;
+    M[5] = b2;
+}
+
+// `(max_angle as f64 / step) as u16` (projection.rs:36): truncating, saturating, NaN -> 0.
+int candidate_count(uint16_t max_angle, double step, int *N_out)
+{
+    double q = (double)max_angle / step;
+    int N;
+    if (!(q == q) || q <= 0) N = 0;
+    else if (q >= 65535.0) N = 65535;
+    else N = (int)q;
+    if (N_out) *N_out = N;
+    return 2 * N;
+}
+
+// transfer.rs:473-475 per candidate `deg as f64 * step` for deg in -N..N (projection.rs:38,50).
+void sweep_matrices(int rows, int cols, int N, double step, double scale, double *M_out)
+{
+    const float cx = (float)cols / 2.0f, cy = (float)rows / 2.0f;
+    for (int i = 0; i < 2 * N; i++) rotation_matrix_2d(cx, cy, (double)(i - N) * step, scale, M_out + 6 * (size_t)i);
+}
+
+// ---- tables ---------------------------------------------------------------------------------
+
+static const int kSlabWords = 1024;  // must match LDS_SLAB_WORDS in kernels.hip
+static const int kMaxWinWords = 32;
+
+// Largest destination-row count per staged window whose source bounding box fits the wave's
+// LDS slab.  The fixed-point map deviates from the real affine map by < 1 px per axis (two
+// roundings of <= 0.5/1024 px plus the floor), which the +2 margins cover; the kernel re-checks
+// with the exact integer corners and gathers from global memory if a window were ever larger.
+static LdsTile size_tile(const double Mi[6])
+{
+    static const int cand[] = {256, 192, 128, 96, 64, 48, 32, 24, 16, 12, 8, 6, 4, 3, 2, 1};
+    LdsTile t{0, 0, 0};
+    for (int R : cand) {
+        double xspan = 63.0 * fabs(Mi[0]) + (double)(R - 1) * fabs(Mi[1]);
+        double yspan = 63.0 * fabs(Mi[3]) + (double)(R - 1) * fabs(Mi[4]);
+        if (!(xspan < 1e6) || !(yspan < 1e6)) continue;
+        int words = (int)((xspan + 2.0) / 32.0) + 2;
+        int rows = (int)(yspan + 2.0) + 2;
+        if (words <= kMaxWinWords && (long long)rows * (words | 1) <= kSlabWords) {
+            t.rows_per_tile = R;
+            t.win_words = words;
+            t.win_rows = rows;
+            return t;
+        }
+    }
+    return t;
+}
+
+int SweepTables::create(int rows, int cols, const double *fwd_M, int A, int dev)
+{
+    // OpenCV's remap asserts every dimension < SHRT_MAX
+    if (rows <= 0 || cols <= 0 || rows >= 32767 || cols >= 32767)
+        return fail(OMR_ERR_ASSERT, "bad image size %dx%d (need 0 < dim < 32767)", cols, rows);
+    if (A <= 0 || !fwd_M) return fail(OMR_ERR_BADARG, "need at least one candidate matrix");
+    int ndev = 0;
+    OMR_HIP(hipGetDeviceCount(&ndev));
+    if (dev < 0 || dev >= ndev) return fail(OMR_ERR_BADARG, "device %d out of range (%d visible)", dev, ndev);
+    OMR_HIP(hipSetDevice(dev));
+    device = dev;
+    dims.rows = rows;
+    dims.cols = cols;
+    dims.A = A;
+    dims.wpr = (cols + 31) / 32;
+
+    host_minv.resize((size_t)A * 6);
+    std::vector<LdsTile> ht((size_t)A);
+    lds_ok = true;
+    max_rows_per_tile = 0;
+    for (int a = 0; a < A; a++) {
+        for (int k = 0; k < 6; k++)
+            if (!isfinite(fwd_M[6 * (size_t)a + k])) return fail(OMR_ERR_BADARG, "matrix %d is not finite", a);
+        invert_affine(fwd_M + 6 * (size_t)a, &host_minv[6 * (size_t)a]);
+        ht[a] = size_tile(&host_minv[6 * (size_t)a]);
+        if (ht[a].rows_per_tile == 0) lds_ok = false;
+        if (ht[a].rows_per_tile > max_rows_per_tile) max_rows_per_tile = ht[a].rows_per_tile;
+    }
+    OMR_HIP(minv.alloc(sizeof(double) * 6 * (size_t)A));
+    OMR_HIP(adelta.alloc(sizeof(int32_t) * (size_t)A * cols));
+    OMR_HIP(bdelta.alloc(sizeof(int32_t) * (size_t)A * cols));
+    OMR_HIP(xy0.alloc(sizeof(int2_t) * (size_t)A * rows));
+    OMR_HIP(tiles.alloc(sizeof(LdsTile) * (size_t)A));
+    DevBuf ovf;
+    OMR_HIP(ovf.alloc(sizeof(int32_t)));
+    OMR_HIP(hipMemcpy(minv.p, host_minv.data(), sizeof(double) * 6 * (size_t)A, hipMemcpyHostToDevice));
+    OMR_HIP(hipMemcpy(tiles.p, ht.data(), sizeof(LdsTile) * (size_t)A, hipMemcpyHostToDevice));
+    OMR_HIP(hipMemset(ovf.p, 0, sizeof(int32_t)));
+    OMR_HIP(launch_tables(minv.as<double>(), dims, 512, adelta.as<int32_t>(), bdelta.as<int32_t>(), xy0.as<int2_t>(),
+                          ovf.as<int32_t>(), nullptr));
+    int32_t h_ovf = 0;
+    OMR_HIP(hipMemcpy(&h_ovf, ovf.p, sizeof h_ovf, hipMemcpyDeviceToHost));
+    if (h_ovf) return fail(OMR_ERR_BADARG, "affine map leaves the 32-bit fixed-point range of warpAffine");
+    return OMR_OK;
+}
+
+int SweepScratch::create(const SweepDims &d)
+{
+    OMR_HIP(bits.alloc(sizeof(uint32_t) * (size_t)d.rows * d.wpr));
+    OMR_HIP(vproj.alloc(sizeof(uint32_t) * (size_t)d.A * d.cols));
+    OMR_HIP(hproj.alloc(sizeof(uint32_t) * (size_t)d.A * d.rows));
+    OMR_HIP(vsd.alloc(sizeof(double) * (size_t)d.A));
+    OMR_HIP(hsd.alloc(sizeof(double) * (size_t)d.A));
+    OMR_HIP(best.alloc(sizeof(int32_t)));
+    return OMR_OK;
+}
+
+int enqueue_sweep(const SweepTables &t, SweepScratch &s, int kernel_sel, const uint8_t *d_img, int64_t step,
+                  int black_max, hipStream_t stream, uint32_t *d_vproj, uint32_t *d_hproj, double *d_v_sd,
+                  double *d_h_sd, int32_t *d_best, hipEvent_t ev0, hipEvent_t ev1)
+{
+    const SweepDims &d = t.dims;
+    if (!d_img) return fail(OMR_ERR_BADARG, "null image");
+    if (step < d.cols) return fail(OMR_ERR_BADARG, "step_bytes %lld < cols %d", (long long)step, d.cols);
+    bool use_lds;
+    if (kernel_sel == KERNEL_GENERIC) use_lds = false;
+    else if (kernel_sel == KERNEL_LDS) {
+        if (!t.lds_ok) return fail(OMR_ERR_BADARG, "a candidate's source window does not fit the LDS slab");
+        use_lds = true;
+    } else use_lds = t.lds_ok;
+
+    // integer projections accumulate with atomics: the caller's buffers double as accumulators
+    uint32_t *vp = d_vproj ? d_vproj : s.vproj.as<uint32_t>();
+    uint32_t *hp = d_hproj ? d_hproj : s.hproj.as<uint32_t>();
+    double *vs = d_v_sd ? d_v_sd : s.vsd.as<double>();
+    double *hs = d_h_sd ? d_h_sd : s.hsd.as<double>();
+    OMR_HIP(hipMemsetAsync(vp, 0, sizeof(uint32_t) * (size_t)d.A * d.cols, stream));
+    OMR_HIP(hipMemsetAsync(hp, 0, sizeof(uint32_t) * (size_t)d.A * d.rows, stream));
+    OMR_HIP(launch_pack_bits(d_img, step, d.rows, d.cols, black_max, s.bits.as<uint32_t>(), d.wpr, stream));
+    if (ev0) OMR_HIP(hipEventRecord(ev0, stream));
+    if (use_lds)
+        OMR_HIP(launch_sweep_lds(s.bits.as<uint32_t>(), d, t.adelta.as<int32_t>(), t.bdelta.as<int32_t>(),
+                                 t.xy0.as<int2_t>(), t.tiles.as<LdsTile>(), t.max_rows_per_tile, vp, hp, stream));
+    else
+        OMR_HIP(launch_sweep_generic(s.bits.as<uint32_t>(), d, t.adelta.as<int32_t>(), t.bdelta.as<int32_t>(),
+                                     t.xy0.as<int2_t>(), vp, hp, stream));
+    if (ev1) OMR_HIP(hipEventRecord(ev1, stream));
+    OMR_HIP(launch_stddev(vp, hp, d, vs, hs, stream));
+    if (d_best) OMR_HIP(launch_argmax_path1(vs, hs, d.A, d_best, stream));
+    return OMR_OK;
+}
+
+}  // namespace omr
+
+using namespace omr;
+
+omr_sweep_plan::~omr_sweep_plan()
+{
+    (void)hipSetDevice(tables.device);
+    if (ev0) (void)hipEventDestroy(ev0);
+    if (ev1) (void)hipEventDestroy(ev1);
+    if (stream) (void)hipStreamDestroy(stream);
+}
+
+omr_batch_ctx::~omr_batch_ctx()
+{
+    (void)hipSetDevice(tables.device);
+    for (auto &e : events) {
+        (void)hipEventDestroy(e.first);
+        (void)hipEventDestroy(e.second);
+    }
+    for (auto e : joins) (void)hipEventDestroy(e);
+    for (auto s : streams) (void)hipStreamDestroy(s);
+}
+
+extern "C" {
+
+int omr_version(void) { return 100; }
+
+int omr_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+const char *omr_last_error(void) { return last_error(); }
+
+int omr_get_rotation_matrix_2d(float cx, float cy, double angle_deg, double scale, double M[6])
+{
+    if (!M) return fail(OMR_ERR_BADARG, "null output");
+    rotation_matrix_2d(cx, cy, angle_deg, scale, M);
+    return OMR_OK;
+}
+
+int omr_candidate_count(uint16_t max_angle, double step, int32_t *N_out)
+{
+    int N;
+    int A = candidate_count(max_angle, step, &N);
+    if (N_out) *N_out = N;
+    return A;
+}
+
+int omr_sweep_matrices(int32_t rows, int32_t cols, uint16_t max_angle, double step, double scale, double *M_out,
+                       int32_t cap_A)
+{
+    int N, A = candidate_count(max_angle, step, &N);
+    if (!M_out || cap_A < A) return fail(OMR_ERR_BADARG, "matrix buffer too small (%d < %d)", cap_A, A);
+    sweep_matrices(rows, cols, N, step, scale, M_out);
+    return OMR_OK;
+}
+
+int omr_sweep_plan_create(int32_t rows, int32_t cols, const double *fwd_M, int32_t A, int32_t device,
+                          omr_sweep_plan **plan_out)
+{
+    if (!plan_out) return fail(OMR_ERR_BADARG, "null plan_out");
+    *plan_out = nullptr;
+    std::unique_ptr<omr_sweep_plan> p(new omr_sweep_plan);
+    int rc = p->tables.create(rows, cols, fwd_M, A, device);
+    if (rc) return rc;
+    rc = p->scratch.create(p->tables.dims);
+    if (rc) return rc;
+    OMR_HIP(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
+    OMR_HIP(hipEventCreate(&p->ev0));
+    OMR_HIP(hipEventCreate(&p->ev1));
+    *plan_out = p.release();
+    return OMR_OK;
+}
+
+int omr_sweep_plan_create_angles(int32_t rows, int32_t cols, uint16_t max_angle, double step, double scale,
+                                 int32_t device, omr_sweep_plan **plan_out)
+{
+    int N, A = candidate_count(max_angle, step, &N);
+    if (A <= 0) return fail(OMR_ERR_BADARG, "empty candidate range (max_angle %u, step %g)", (unsigned)max_angle, step);
+    std::vector<double> M((size_t)A * 6);
+    sweep_matrices(rows, cols, N, step, scale, M.data());
+    return omr_sweep_plan_create(rows, cols, M.data(), A, device, plan_out);
+}
+
+void omr_sweep_plan_destroy(omr_sweep_plan *plan) { delete plan; }
+
+int omr_sweep_plan_candidates(const omr_sweep_plan *plan) { return plan ? plan->tables.dims.A : 0; }
+
+int omr_sweep_plan_run_device(omr_sweep_plan *plan, const uint8_t *d_img, int64_t step_bytes, int32_t black_max,
+                              void *stream, uint32_t *d_vproj, uint32_t *d_hproj, double *d_v_sd, double *d_h_sd,
+                              int32_t *d_best_idx)
+{
+    if (!plan) return fail(OMR_ERR_BADARG, "null plan");
+    std::lock_guard<std::mutex> lk(plan->mu);
+    OMR_HIP(hipSetDevice(plan->tables.device));
+    plan->timed = plan->timing;
+    return enqueue_sweep(plan->tables, plan->scratch, plan->kernel_sel, d_img, step_bytes, black_max,
+                         (hipStream_t)stream, d_vproj, d_hproj, d_v_sd, d_h_sd, d_best_idx,
+                         plan->timing ? plan->ev0 : nullptr, plan->timing ? plan->ev1 : nullptr);
+}
+
+int omr_sweep_plan_run(omr_sweep_plan *plan, const omr_image *img, int32_t black_max, uint32_t *vproj,
+                       uint32_t *hproj, double *v_sd, double *h_sd, int32_t *best_idx)
+{
+    if (!plan || !img || !img->data) return fail(OMR_ERR_BADARG, "null plan or image");
+    const SweepDims &d = plan->tables.dims;
+    if (img->channels != 1) return fail(OMR_ERR_ASSERT, "sweep needs a 1-channel image (got %d)", img->channels);
+    if (img->rows != d.rows || img->cols != d.cols)
+        return fail(OMR_ERR_ASSERT, "image %dx%d does not match the plan %dx%d", img->cols, img->rows, d.cols, d.rows);
+    if (img->step_bytes < img->cols) return fail(OMR_ERR_BADARG, "step_bytes < cols");
+    std::lock_guard<std::mutex> lk(plan->mu);
+    OMR_HIP(hipSetDevice(plan->tables.device));
+    const size_t need = (size_t)d.rows * d.cols;
+    if (plan->img.bytes < need) OMR_HIP(plan->img.alloc(need));
+    hipStream_t s = plan->stream;
+    OMR_HIP(hipMemcpy2DAsync(plan->img.p, (size_t)d.cols, img->data, (size_t)img->step_bytes, (size_t)d.cols,
+                             (size_t)d.rows, hipMemcpyHostToDevice, s));
+    plan->timed = plan->timing;
+    int rc = enqueue_sweep(plan->tables, plan->scratch, plan->kernel_sel, plan->img.as<uint8_t>(), d.cols, black_max, s,
+                           nullptr, nullptr, nullptr, nullptr, plan->scratch.best.as<int32_t>(),
+                           plan->timing ? plan->ev0 : nullptr, plan->timing ? plan->ev1 : nullptr);
+    if (rc) return rc;
+    if (vproj)
+        OMR_HIP(hipMemcpyAsync(vproj, plan->scratch.vproj.p, sizeof(uint32_t) * (size_t)d.A * d.cols,
+                               hipMemcpyDeviceToHost, s));
+    if (hproj)
+        OMR_HIP(hipMemcpyAsync(hproj, plan->scratch.hproj.p, sizeof(uint32_t) * (size_t)d.A * d.rows,
+                               hipMemcpyDeviceToHost, s));
+    if (v_sd) OMR_HIP(hipMemcpyAsync(v_sd, plan->scratch.vsd.p, sizeof(double) * (size_t)d.A, hipMemcpyDeviceToHost, s));
+    if (h_sd) OMR_HIP(hipMemcpyAsync(h_sd, plan->scratch.hsd.p, sizeof(double) * (size_t)d.A, hipMemcpyDeviceToHost, s));
+    if (best_idx) OMR_HIP(hipMemcpyAsync(best_idx, plan->scratch.best.p, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    OMR_HIP(hipStreamSynchronize(s));
+    return OMR_OK;
+}
+
+int omr_sweep_plan_set_timing(omr_sweep_plan *plan, int32_t enabled)
+{
+    if (!plan) return fail(OMR_ERR_BADARG, "null plan");
+    plan->timing = enabled != 0;
+    return OMR_OK;
+}
+
+int omr_sweep_plan_last_kernel_ms(omr_sweep_plan *plan, float *ms_out)
+{
+    if (!plan || !ms_out) return fail(OMR_ERR_BADARG, "null argument");
+    if (!plan->timed) return fail(OMR_ERR_BADARG, "timing was not enabled for the last run");
+    OMR_HIP(hipSetDevice(plan->tables.device));
+    OMR_HIP(hipEventSynchronize(plan->ev1));
+    OMR_HIP(hipEventElapsedTime(ms_out, plan->ev0, plan->ev1));
+    return OMR_OK;
+}
+
+int omr_sweep_plan_set_kernel(omr_sweep_plan *plan, int32_t which)
+{
+    if (!plan || which < 0 || which > 2) return fail(OMR_ERR_BADARG, "bad kernel selector");
+    if (which == KERNEL_LDS && !plan->tables.lds_ok)
+        return fail(OMR_ERR_BADARG, "a candidate's source window does not fit the LDS slab");
+    plan->kernel_sel = which;
+    return OMR_OK;
+}
+
+int omr_sweep_plan_tables(omr_sweep_plan *plan, int32_t a, int32_t *adelta, int32_t *bdelta, int32_t *X0, int32_t *Y0)
+{
+    if (!plan) return fail(OMR_ERR_BADARG, "null plan");
+    const SweepDims &d = plan->tables.dims;
+    if (a < 0 || a >= d.A) return fail(OMR_ERR_BADARG, "candidate %d out of range", a);
+    OMR_HIP(hipSetDevice(plan->tables.device));
+    if (adelta)
+        OMR_HIP(hipMemcpy(adelta, plan->tables.adelta.as<int32_t>() + (size_t)a * d.cols, sizeof(int32_t) * d.cols,
+                          hipMemcpyDeviceToHost));
+    if (bdelta)
+        OMR_HIP(hipMemcpy(bdelta, plan->tables.bdelta.as<int32_t>() + (size_t)a * d.cols, sizeof(int32_t) * d.cols,
+                          hipMemcpyDeviceToHost));
+    if (X0 || Y0) {
+        std::vector<int2_t> t((size_t)d.rows);
+        OMR_HIP(hipMemcpy(t.data(), plan->tables.xy0.as<int2_t>() + (size_t)a * d.rows, sizeof(int2_t) * d.rows,
+                          hipMemcpyDeviceToHost));
+        for (int y = 0; y < d.rows; y++) {
+            if (X0) X0[y] = t[y].x;
+            if (Y0) Y0[y] = t[y].y;
+        }
+    }
+    return OMR_OK;
+}
+
+int omr_projection_sweep(const omr_image *bin, const double *fwd_M, int32_t A, uint32_t *vproj, uint32_t *hproj,
+                         double *v_sd, double *h_sd)
+{
+    if (!bin || !bin->data) return fail(OMR_ERR_BADARG, "null image");
+    if (A == 0) return OMR_OK;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return fail(OMR_ERR_GPU, "no usable HIP device (there is no CPU fallback)");
+    omr_sweep_plan *plan = nullptr;
+    int rc = omr_sweep_plan_create(bin->rows, bin->cols, fwd_M, A, dev, &plan);
+    if (rc) return rc;
+    rc = omr_sweep_plan_run(plan, bin, 0, vproj, hproj, v_sd, h_sd, nullptr);
+    omr_sweep_plan_destroy(plan);
+    return rc;
+}
+
+// ---- batch ----------------------------------------------------------------------------------
+
+int omr_batch_create(int32_t rows, int32_t cols, uint16_t max_angle, double step, double scale, int32_t device,
+                     int32_t n_streams, omr_batch_ctx **ctx_out)
+{
+    if (!ctx_out) return fail(OMR_ERR_BADARG, "null ctx_out");
+    *ctx_out = nullptr;
+    if (n_streams < 1 || n_streams > 16) return fail(OMR_ERR_BADARG, "n_streams must be in 1..16");
+    int N, A = candidate_count(max_angle, step, &N);
+    if (A <= 0) return fail(OMR_ERR_BADARG, "empty candidate range");
+    std::vector<double> M((size_t)A * 6);
+    sweep_matrices(rows, cols, N, step, scale, M.data());
+    std::unique_ptr<omr_batch_ctx> c(new omr_batch_ctx);
+    c->N = N;
+    c->step = step;
+    int rc = c->tables.create(rows, cols, M.data(), A, device);
+    if (rc) return rc;
+    for (int i = 0; i < n_streams; i++) {
+        c->scratch.emplace_back(new SweepScratch);
+        rc = c->scratch.back()->create(c->tables.dims);
+        if (rc) return rc;
+        hipStream_t s;
+        OMR_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+        c->streams.push_back(s);
+    }
+    *ctx_out = c.release();
+    return OMR_OK;
+}
+
+void omr_batch_destroy(omr_batch_ctx *ctx) { delete ctx; }
+
+int omr_batch_set_timing(omr_batch_ctx *ctx, int32_t enabled)
+{
+    if (!ctx) return fail(OMR_ERR_BADARG, "null ctx");
+    ctx->timing = enabled != 0;
+    return OMR_OK;
+}
+
+int omr_batch_run_device(omr_batch_ctx *ctx, const uint8_t *d_scans, int64_t scan_stride, int64_t step_bytes,
+                         int32_t n, int32_t black_max, int32_t *d_best_idx, double *d_v_sd, double *d_h_sd)
+{
+    if (!ctx || !d_scans || n < 0) return fail(OMR_ERR_BADARG, "bad batch arguments");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    OMR_HIP(hipSetDevice(ctx->tables.device));
+    const int S = (int)ctx->streams.size();
+    const int A = ctx->tables.dims.A;
+    for (int i = 0; i < n; i++) {
+        const int k = i % S;
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (ctx->timing) {
+            if (ctx->events_used == ctx->events.size()) {
+                hipEvent_t a, b;
+                OMR_HIP(hipEventCreate(&a));
+                OMR_HIP(hipEventCreate(&b));
+                ctx->events.emplace_back(a, b);
+            }
+            e0 = ctx->events[ctx->events_used].first;
+            e1 = ctx->events[ctx->events_used].second;
+            ctx->events_used++;
+        }
+        int rc = enqueue_sweep(ctx->tables, *ctx->scratch[k], KERNEL_AUTO, d_scans + (size_t)i * scan_stride,
+                               step_bytes, black_max, ctx->streams[k], nullptr, nullptr,
+                               d_v_sd ? d_v_sd + (size_t)i * A : nullptr, d_h_sd ? d_h_sd + (size_t)i * A : nullptr,
+                               d_best_idx ? d_best_idx + i : nullptr, e0, e1);
+        if (rc) return rc;
+    }
+    return OMR_OK;
+}
+
+int omr_batch_sync(omr_batch_ctx *ctx)
+{
+    if (!ctx) return fail(OMR_ERR_BADARG, "null ctx");
+    OMR_HIP(hipSetDevice(ctx->tables.device));
+    for (auto s : ctx->streams) OMR_HIP(hipStreamSynchronize(s));
+    return OMR_OK;
+}
+
+int omr_batch_kernel_ms(omr_batch_ctx *ctx, double *sum_ms, int32_t *launches)
+{
+    if (!ctx || !sum_ms || !launches) return fail(OMR_ERR_BADARG, "null argument");
+    int rc = omr_batch_sync(ctx);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    double sum = 0;
+    for (size_t i = 0; i < ctx->events_used; i++) {
+        float ms = 0;
+        OMR_HIP(hipEventElapsedTime(&ms, ctx->events[i].first, ctx->events[i].second));
+        sum += ms;
+    }
+    *sum_ms = sum;
+    *launches = (int32_t)ctx->events_used;
+    ctx->events_used = 0;
+    return OMR_OK;
+}
+
+}  // extern "C"

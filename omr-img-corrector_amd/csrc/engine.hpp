@@ -1,0 +1,98 @@
+// engine.hpp -- device-side engine objects behind the C ABI (include/omrdeskew.h).
+#pragma once
+#include <hip/hip_runtime_api.h>
+#include <stdint.h>
+
+#include <memory>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "kernels.hpp"
+
+namespace omr {
+
+// thread-local error channel (omr_last_error)
+int fail(int code, const char *fmt, ...);
+int fail_gpu(const char *what, hipError_t e);
+const char *last_error();
+void clear_error();
+
+#define OMR_HIP(expr)                                          \
+    do {                                                       \
+        hipError_t e__ = (expr);                               \
+        if (e__ != hipSuccess) return ::omr::fail_gpu(#expr, e__); \
+    } while (0)
+
+// RAII device allocation
+struct DevBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    ~DevBuf() { release(); }
+    hipError_t alloc(size_t n);
+    void release();
+    template <class T>
+    T *as() const { return static_cast<T *>(p); }
+};
+
+// getRotationMatrix2D / warpAffine inversion on the host (fp64, built -ffp-contract=off, same
+// libm as the caller's process) -- OpenCV 4.6.0 semantics, SURVEY.md A.1 / A.2 step 1.
+void rotation_matrix_2d(float cx, float cy, double angle_deg, double scale, double M[6]);
+void invert_affine(const double M[6], double Minv[6]);
+int candidate_count(uint16_t max_angle, double step, int *N_out);  // projection.rs:36-38
+void sweep_matrices(int rows, int cols, int N, double step, double scale, double *M_out);
+
+// Immutable per-(shape, matrices) state: inverse matrices, fixed-point tables, LDS tiling.
+struct SweepTables {
+    int device = 0;
+    SweepDims dims{};
+    DevBuf minv, adelta, bdelta, xy0, tiles;
+    bool lds_ok = false;
+    int max_rows_per_tile = 0;
+    std::vector<double> host_minv;
+    int create(int rows, int cols, const double *fwd_M, int A, int device);
+};
+
+// Mutable per-stream scratch: bit image, integer projections, scores.
+struct SweepScratch {
+    DevBuf bits, vproj, hproj, vsd, hsd, best;
+    int create(const SweepDims &d);
+};
+
+enum KernelSel { KERNEL_AUTO = 0, KERNEL_GENERIC = 1, KERNEL_LDS = 2 };
+
+// Enqueue pack -> sweep -> std-dev -> arg-max for one device-resident scan.
+int enqueue_sweep(const SweepTables &t, SweepScratch &s, int kernel_sel, const uint8_t *d_img, int64_t step,
+                  int black_max, hipStream_t stream, uint32_t *d_vproj, uint32_t *d_hproj, double *d_v_sd,
+                  double *d_h_sd, int32_t *d_best, hipEvent_t ev0, hipEvent_t ev1);
+
+}  // namespace omr
+
+struct omr_sweep_plan {
+    omr::SweepTables tables;
+    omr::SweepScratch scratch;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool timing = false, timed = false;
+    int kernel_sel = omr::KERNEL_AUTO;
+    omr::DevBuf img;  // staging for the host-image entry point
+    std::mutex mu;
+    ~omr_sweep_plan();
+};
+
+struct omr_batch_ctx {
+    omr::SweepTables tables;
+    int N = 0;
+    double step = 0;
+    std::vector<std::unique_ptr<omr::SweepScratch>> scratch;
+    std::vector<hipStream_t> streams;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+    std::vector<hipEvent_t> joins;
+    size_t events_used = 0;
+    bool timing = false;
+    std::mutex mu;
+    ~omr_batch_ctx();
+};

@@ -1,0 +1,82 @@
+// kernels.hpp -- launch wrappers of the gfx950 kernels (kernels.hip). Host-callable, no torch types.
+#pragma once
+#include <hip/hip_runtime_api.h>
+#include <stdint.h>
+
+namespace omr {
+
+struct int2_t {
+    int32_t x, y;
+};
+
+// Sweep geometry shared by host and device.
+struct SweepDims {
+    int32_t rows, cols;  // image (and destination canvas) size
+    int32_t A;           // candidate count
+    int32_t wpr;         // 32-bit words per row of the bit image
+};
+
+// Per-candidate tiling parameters of the LDS-staged kernel, computed on the host from the
+// inverse matrix (plan creation).
+struct LdsTile {
+    int32_t rows_per_tile;  // destination rows a wave covers per staged window (0: does not fit)
+    int32_t win_words;      // window row pitch in 32-bit words
+    int32_t win_rows;       // window height
+};
+
+// u8 image -> bit image: bit (x & 31) of word [y][x >> 5] is 1 iff px <= black_max.
+hipError_t launch_pack_bits(const uint8_t *d_img, int64_t step, int rows, int cols, int black_max,
+                            uint32_t *d_bits, int wpr, hipStream_t s);
+
+// OpenCV hal::warpAffine fixed-point tables for A inverse matrices.
+// adelta/bdelta: [A][cols]; xy0: [A][rows] (X0, Y0 incl. round_delta). *d_overflow != 0 when a
+// table entry left the int32-safe range.
+hipError_t launch_tables(const double *d_Minv, SweepDims d, int round_delta, int32_t *d_adelta,
+                         int32_t *d_bdelta, int2_t *d_xy0, int32_t *d_overflow, hipStream_t s);
+
+// Generic sweep: every (candidate, dst pixel) gathers its source bit from global memory.
+// vproj [A][cols], hproj [A][rows] must be zero on entry (integer atomics).
+hipError_t launch_sweep_generic(const uint32_t *d_bits, SweepDims d, const int32_t *d_adelta,
+                                const int32_t *d_bdelta, const int2_t *d_xy0, uint32_t *d_vproj,
+                                uint32_t *d_hproj, hipStream_t s);
+
+// LDS-staged sweep (rotation-like matrices whose per-wave source window fits the LDS budget).
+hipError_t launch_sweep_lds(const uint32_t *d_bits, SweepDims d, const int32_t *d_adelta,
+                            const int32_t *d_bdelta, const int2_t *d_xy0, const LdsTile *d_tiles,
+                            int max_rows_per_tile, uint32_t *d_vproj, uint32_t *d_hproj,
+                            hipStream_t s);
+
+// calculate.rs:13-23 on the integer projections: one block per (candidate, axis).
+hipError_t launch_stddev(const uint32_t *d_vproj, const uint32_t *d_hproj, SweepDims d,
+                         double *d_v_sd, double *d_h_sd, hipStream_t s);
+
+// projection.rs:125-190 arg-max (lowest index on exact ties).
+hipError_t launch_argmax_path1(const double *d_v_sd, const double *d_h_sd, int A, int32_t *d_best,
+                               hipStream_t s);
+
+// ---- per-image helpers -------------------------------------------------------------------
+hipError_t launch_threshold(const uint8_t *d_src, int64_t sstep, int rows, int cols, uint8_t *d_dst,
+                            int64_t dstep, int thresh, int maxval, hipStream_t s);
+hipError_t launch_rgb2gray(const uint8_t *d_src, int64_t sstep, int rows, int cols, int cn,
+                           uint8_t *d_dst, int64_t dstep, hipStream_t s);
+hipError_t launch_erode_cross3(const uint8_t *d_src, int64_t sstep, int rows, int cols,
+                               uint8_t *d_dst, int64_t dstep, hipStream_t s);
+hipError_t launch_resize_area_int(const uint8_t *d_src, int64_t sstep, int srows, int scols, int cn,
+                                  uint8_t *d_dst, int64_t dstep, int drows, int dcols, int kx, int ky,
+                                  hipStream_t s);
+struct AreaTap {
+    int32_t si, di;
+    float alpha;
+};
+hipError_t launch_resize_area_general(const uint8_t *d_src, int64_t sstep, int cn, uint8_t *d_dst,
+                                      int64_t dstep, int drows, int dcols, const AreaTap *d_xtab,
+                                      const int32_t *d_xofs, const AreaTap *d_ytab,
+                                      const int32_t *d_yofs, hipStream_t s);
+hipError_t launch_warp_nn(const uint8_t *d_src, int64_t sstep, int srows, int scols, int cn,
+                          uint8_t *d_dst, int64_t dstep, int drows, int dcols, const double *d_Minv,
+                          uint32_t border_rgba, hipStream_t s);
+hipError_t launch_warp_linear(const uint8_t *d_src, int64_t sstep, int srows, int scols, int cn,
+                              uint8_t *d_dst, int64_t dstep, int drows, int dcols,
+                              const double *d_Minv, uint32_t border_rgba, hipStream_t s);
+
+}  // namespace omr

@@ -1,0 +1,670 @@
+// oics_host.cpp -- host side of crate `oics` above the device engine: the drivers and helpers
+// with the reference's names, argument meaning and error behaviour, exported through the C ABI.
+// (The reference's host language is Rust; there is no rustc in this image, so the host layer is
+// C++ -- INTEGRATION.md shows the Rust `extern "C"` shim that binds it.)
+//
+//   oics::projection::get_angle_with_projections   packages/lib/src/projection.rs:17-194
+//   find_target_angle                              packages/app/src-tauri/src/test.rs:83-178
+//   oics::omr::get_result_from_projection          packages/lib/src/omr.rs:52-229
+//   oics::transfer::*  / oics::calculate::*        packages/lib/src/transfer.rs, calculate.rs
+//
+// Every image operation runs on the GPU; the host only sequences launches, builds the 2x3
+// matrices / resize tap tables (a few hundred doubles) and applies the arg-max policy to the A
+// scores.  No CPU fallback exists: without a HIP device every entry point returns -217.
+#include <float.h>
+#include <math.h>
+#include <string.h>
+
+#include <list>
+#include <memory>
+#include <thread>
+#include <tuple>
+#include <vector>
+
+#include "../../include/omrdeskew.h"
+#include "engine.hpp"
+
+using namespace omr;
+
+namespace {
+
+int current_device(int *dev)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+        return fail(OMR_ERR_GPU, "no usable HIP device (there is no CPU fallback)");
+    OMR_HIP(hipGetDevice(dev));
+    return OMR_OK;
+}
+
+int check_image(const omr_image *im, bool need_c1)
+{
+    if (!im || !im->data) return fail(OMR_ERR_BADARG, "null image");
+    if (im->rows <= 0 || im->cols <= 0) return fail(OMR_ERR_ASSERT, "empty image");
+    if (im->rows >= 32767 || im->cols >= 32767) return fail(OMR_ERR_ASSERT, "image dimension >= SHRT_MAX");
+    if (im->channels < 1 || im->channels > 4) return fail(OMR_ERR_ASSERT, "unsupported channel count %d", im->channels);
+    if (need_c1 && im->channels != 1) return fail(OMR_ERR_ASSERT, "expected a 1-channel image, got %d", im->channels);
+    if (im->step_bytes < (int64_t)im->cols * im->channels) return fail(OMR_ERR_BADARG, "step_bytes too small");
+    return OMR_OK;
+}
+
+// device image (tightly packed rows)
+struct DevImage {
+    DevBuf buf;
+    int rows = 0, cols = 0, cn = 1;
+    int64_t step() const { return (int64_t)cols * cn; }
+    uint8_t *ptr() const { return buf.as<uint8_t>(); }
+    int alloc(int r, int c, int ch)
+    {
+        rows = r;
+        cols = c;
+        cn = ch;
+        OMR_HIP(buf.alloc((size_t)r * c * ch));
+        return OMR_OK;
+    }
+    int upload(const omr_image *im, hipStream_t s)
+    {
+        int rc = alloc(im->rows, im->cols, im->channels);
+        if (rc) return rc;
+        OMR_HIP(hipMemcpy2DAsync(buf.p, (size_t)step(), im->data, (size_t)im->step_bytes, (size_t)step(),
+                                 (size_t)rows, hipMemcpyHostToDevice, s));
+        return OMR_OK;
+    }
+    int download(uint8_t *dst, int64_t dstep, hipStream_t s) const
+    {
+        OMR_HIP(hipMemcpy2DAsync(dst, (size_t)dstep, buf.p, (size_t)step(), (size_t)step(), (size_t)rows,
+                                 hipMemcpyDeviceToHost, s));
+        OMR_HIP(hipStreamSynchronize(s));
+        return OMR_OK;
+    }
+};
+
+struct Stream {
+    hipStream_t s = nullptr;
+    ~Stream()
+    {
+        if (s) (void)hipStreamDestroy(s);
+    }
+    int create()
+    {
+        OMR_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+        return OMR_OK;
+    }
+};
+
+// ---- plan cache: the app calls the drivers over and over with one parameter set --------------
+struct PlanKey {
+    int device, rows, cols;
+    uint16_t max_angle;
+    double step, scale;
+    bool operator==(const PlanKey &o) const
+    {
+        return device == o.device && rows == o.rows && cols == o.cols && max_angle == o.max_angle && step == o.step &&
+               scale == o.scale;
+    }
+};
+std::mutex g_cache_mu;
+std::list<std::pair<PlanKey, std::shared_ptr<omr_sweep_plan>>> g_cache;
+
+int get_plan(const PlanKey &k, std::shared_ptr<omr_sweep_plan> *out)
+{
+    {
+        std::lock_guard<std::mutex> lk(g_cache_mu);
+        for (auto it = g_cache.begin(); it != g_cache.end(); ++it)
+            if (it->first == k) {
+                *out = it->second;
+                g_cache.splice(g_cache.begin(), g_cache, it);
+                return OMR_OK;
+            }
+    }
+    omr_sweep_plan *raw = nullptr;
+    int rc = omr_sweep_plan_create_angles(k.rows, k.cols, k.max_angle, k.step, k.scale, k.device, &raw);
+    if (rc) return rc;
+    std::shared_ptr<omr_sweep_plan> sp(raw);
+    std::lock_guard<std::mutex> lk(g_cache_mu);
+    g_cache.emplace_front(k, sp);
+    while (g_cache.size() > 8) g_cache.pop_back();
+    *out = sp;
+    return OMR_OK;
+}
+
+// Sweep a device-resident 1-channel image and fetch the A scores.
+int sweep_scores(const DevImage &img, int black_max, uint16_t max_angle, double step, double scale, int device,
+                 hipStream_t s, std::vector<double> *v_sd, std::vector<double> *h_sd, int *N_out)
+{
+    int N, A = candidate_count(max_angle, step, &N);
+    if (N_out) *N_out = N;
+    v_sd->assign((size_t)(A > 0 ? A : 0), 0.0);
+    h_sd->assign((size_t)(A > 0 ? A : 0), 0.0);
+    if (A <= 0) return OMR_OK;
+    std::shared_ptr<omr_sweep_plan> plan;
+    int rc = get_plan(PlanKey{device, img.rows, img.cols, max_angle, step, scale}, &plan);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lk(plan->mu);
+    rc = enqueue_sweep(plan->tables, plan->scratch, plan->kernel_sel, img.ptr(), img.step(), black_max, s, nullptr,
+                       nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+    if (rc) return rc;
+    OMR_HIP(hipMemcpyAsync(v_sd->data(), plan->scratch.vsd.p, sizeof(double) * (size_t)A, hipMemcpyDeviceToHost, s));
+    OMR_HIP(hipMemcpyAsync(h_sd->data(), plan->scratch.hsd.p, sizeof(double) * (size_t)A, hipMemcpyDeviceToHost, s));
+    OMR_HIP(hipStreamSynchronize(s));
+    return OMR_OK;
+}
+
+inline int cv_floor(double v)
+{
+    int i = (int)v;
+    return i - (i > v);
+}
+inline int cv_ceil(double v)
+{
+    int i = (int)v;
+    return i + (i < v);
+}
+
+// OpenCV computeResizeAreaTab (resize.cpp), grouped per destination index (CSR offsets).
+void area_tab(int ssize, int dsize, int cn, double scale, std::vector<AreaTap> *tab, std::vector<int32_t> *ofs)
+{
+    tab->clear();
+    ofs->assign((size_t)dsize + 1, 0);
+    for (int dx = 0; dx < dsize; dx++) {
+        (*ofs)[dx] = (int32_t)tab->size();
+        double fsx1 = dx * scale;
+        double fsx2 = fsx1 + scale;
+        double cellWidth = scale < ssize - fsx1 ? scale : ssize - fsx1;
+        int sx1 = cv_ceil(fsx1), sx2 = cv_floor(fsx2);
+        sx2 = sx2 < ssize - 1 ? sx2 : ssize - 1;
+        sx1 = sx1 < sx2 ? sx1 : sx2;
+        if (sx1 - fsx1 > 1e-3) tab->push_back(AreaTap{(sx1 - 1) * cn, dx * cn, (float)((sx1 - fsx1) / cellWidth)});
+        for (int sx = sx1; sx < sx2; sx++) tab->push_back(AreaTap{sx * cn, dx * cn, (float)(1.0 / cellWidth)});
+        if (fsx2 - sx2 > 1e-3) {
+            double m = fsx2 - sx2 < 1. ? fsx2 - sx2 : 1.;
+            m = m < cellWidth ? m : cellWidth;
+            tab->push_back(AreaTap{sx2 * cn, dx * cn, (float)(m / cellWidth)});
+        }
+    }
+    (*ofs)[dsize] = (int32_t)tab->size();
+}
+
+// resize(src, dsize, INTER_AREA) on the device: transfer.rs:66-91 (scale_self) and omr.rs:114-126.
+int resize_area(const DevImage &src, int drows, int dcols, DevImage *dst, hipStream_t s)
+{
+    if (drows <= 0 || dcols <= 0) return fail(OMR_ERR_ASSERT, "resize to an empty size");
+    int rc = dst->alloc(drows, dcols, src.cn);
+    if (rc) return rc;
+    if (drows == src.rows && dcols == src.cols) {
+        OMR_HIP(hipMemcpyAsync(dst->buf.p, src.buf.p, (size_t)src.rows * src.step(), hipMemcpyDeviceToDevice, s));
+        return OMR_OK;
+    }
+    double inv_scale_x = (double)dcols / src.cols, inv_scale_y = (double)drows / src.rows;
+    double scale_x = 1. / inv_scale_x, scale_y = 1. / inv_scale_y;
+    if (!(scale_x >= 1 && scale_y >= 1))
+        return fail(OMR_ERR_NOTIMPL, "INTER_AREA up-scaling (OpenCV's linear branch, quirk B7) is not implemented");
+    int iscale_x = (int)lrint(scale_x), iscale_y = (int)lrint(scale_y);
+    bool is_area_fast = fabs(scale_x - iscale_x) < DBL_EPSILON && fabs(scale_y - iscale_y) < DBL_EPSILON;
+    if (is_area_fast) {
+        OMR_HIP(launch_resize_area_int(src.ptr(), src.step(), src.rows, src.cols, src.cn, dst->ptr(), dst->step(),
+                                       drows, dcols, iscale_x, iscale_y, s));
+        return OMR_OK;
+    }
+    std::vector<AreaTap> xt, yt;
+    std::vector<int32_t> xo, yo;
+    area_tab(src.cols, dcols, src.cn, scale_x, &xt, &xo);
+    area_tab(src.rows, drows, 1, scale_y, &yt, &yo);
+    DevBuf dxt, dxo, dyt, dyo;
+    OMR_HIP(dxt.alloc(sizeof(AreaTap) * xt.size()));
+    OMR_HIP(dxo.alloc(sizeof(int32_t) * xo.size()));
+    OMR_HIP(dyt.alloc(sizeof(AreaTap) * yt.size()));
+    OMR_HIP(dyo.alloc(sizeof(int32_t) * yo.size()));
+    OMR_HIP(hipMemcpyAsync(dxt.p, xt.data(), sizeof(AreaTap) * xt.size(), hipMemcpyHostToDevice, s));
+    OMR_HIP(hipMemcpyAsync(dxo.p, xo.data(), sizeof(int32_t) * xo.size(), hipMemcpyHostToDevice, s));
+    OMR_HIP(hipMemcpyAsync(dyt.p, yt.data(), sizeof(AreaTap) * yt.size(), hipMemcpyHostToDevice, s));
+    OMR_HIP(hipMemcpyAsync(dyo.p, yo.data(), sizeof(int32_t) * yo.size(), hipMemcpyHostToDevice, s));
+    OMR_HIP(launch_resize_area_general(src.ptr(), src.step(), src.cn, dst->ptr(), dst->step(), drows, dcols,
+                                       dxt.as<AreaTap>(), dxo.as<int32_t>(), dyt.as<AreaTap>(), dyo.as<int32_t>(), s));
+    OMR_HIP(hipStreamSynchronize(s));  // the tap tables are freed on return
+    return OMR_OK;
+}
+
+int to_gray(const DevImage &src, DevImage *gray, hipStream_t s)
+{
+    int rc = gray->alloc(src.rows, src.cols, 1);
+    if (rc) return rc;
+    if (src.cn == 1) {
+        // the reference's cvtColor would raise on a 1-channel Mat; accepted here as a convenience
+        OMR_HIP(hipMemcpyAsync(gray->buf.p, src.buf.p, (size_t)src.rows * src.cols, hipMemcpyDeviceToDevice, s));
+        return OMR_OK;
+    }
+    if (src.cn != 3 && src.cn != 4) return fail(OMR_ERR_ASSERT, "RGB2GRAY needs 3 or 4 channels, got %d", src.cn);
+    OMR_HIP(launch_rgb2gray(src.ptr(), src.step(), src.rows, src.cols, src.cn, gray->ptr(), gray->step(), s));
+    return OMR_OK;
+}
+
+// projection.rs:125-190 on the host copy of the scores (lowest index on exact ties, quirk B5).
+int argmax_path1(const double *v, const double *h, int n)
+{
+    double vmax = v[0], hmax = h[0];
+    int vcount = 1, hcount = 1, vfirst = 0, hfirst = 0;
+    for (int i = 0; i < n; i++) {
+        if (v[i] > vmax) vmax = v[i], vcount = 1, vfirst = i;
+        else if (v[i] == vmax) vcount++;
+        if (h[i] > hmax) hmax = h[i], hcount = 1, hfirst = i;
+        else if (h[i] == hmax) hcount++;
+    }
+    if (vcount == 1 && hcount == 1 && vfirst == hfirst) return vfirst;
+    double sdp = 0.0;
+    int result = -1;
+    for (int i = 0; i < n; i++)
+        if (v[i] == vmax || h[i] == hmax) {
+            double cur = v[i] * v[i] + h[i] * h[i];
+            if (sdp < cur) sdp = cur, result = i;
+        }
+    return result < 0 ? n / 2 : result;
+}
+
+}  // namespace
+
+extern "C" {
+
+void omr_image_free(omr_image_owned *img)
+{
+    if (img && img->data) {
+        free(img->data);
+        img->data = nullptr;
+    }
+}
+
+int omr_argmax_projection(const double *v_sd, const double *h_sd, int32_t n, int32_t *index_out)
+{
+    if (!v_sd || !h_sd || !index_out || n <= 0) return fail(OMR_ERR_BADARG, "bad arguments");
+    *index_out = argmax_path1(v_sd, h_sd, n);
+    return OMR_OK;
+}
+
+// omr.rs:147-221
+int omr_select_projection_result(const double *v_sd, const double *h_sd, int32_t n, int32_t N, double step,
+                                 double *angle, int32_t *status, double *candidates, int32_t cand_cap,
+                                 int32_t *cand_len)
+{
+    if (!v_sd || !h_sd || !angle || !status || n < 0) return fail(OMR_ERR_BADARG, "bad arguments");
+    double max_h = 0.0, max_v = 0.0;
+    unsigned hc = 1, vc = 1;
+    std::vector<double> cand;
+    for (int i = 0; i < n; i++) {
+        double ang = (double)(i - N) * step;
+        double hs = h_sd[i];
+        if (max_h < hs) {
+            max_h = hs;
+            max_v = v_sd[i];
+            hc = 1;
+            vc = 1;
+            cand.assign(1, ang);
+        } else if (max_h == hs) {
+            hc += 1;
+            double vs = v_sd[i];
+            if (max_v < vs) {
+                vc = 1;
+                max_v = vs;
+                cand.assign(1, ang);
+            } else if (max_v == vs) {
+                vc += 1;
+                cand.push_back(ang);
+            }
+        }
+    }
+    if (cand_len) *cand_len = (int32_t)cand.size();
+    if (candidates)
+        for (size_t i = 0; i < cand.size() && (int32_t)i < cand_cap; i++) candidates[i] = cand[i];
+    if (cand.empty()) {  // omr.rs:211 would panic on [0] (quirk B6)
+        *status = OMR_STATUS_NOT_A_RESULT;
+        *angle = 0.0;
+    } else if (hc == 1 && vc == 1) {
+        *status = OMR_STATUS_BELIEVED;
+        *angle = cand[0];
+    } else if (cand.size() == 1) {
+        *status = OMR_STATUS_NEED_CHECK;
+        *angle = cand[0];
+    } else {
+        *status = OMR_STATUS_NOT_A_RESULT;
+        *angle = 0.0;
+    }
+    return OMR_OK;
+}
+
+// projection.rs:17-194
+int omr_get_angle_with_projections(const omr_image *src, uint16_t max_angle, double step, double resize_scale,
+                                   size_t threads_hint, double *angle_out)
+{
+    (void)threads_hint;  // projection.rs:69-122 is buggy (:94) and unused by every caller
+    int rc = check_image(src, false);
+    if (rc) return rc;
+    if (!angle_out) return fail(OMR_ERR_BADARG, "null angle_out");
+    if (src->channels == 2) return fail(OMR_ERR_ASSERT, "RGB2GRAY needs 3 or 4 channels");
+    int N, A = candidate_count(max_angle, step, &N);
+    if (A <= 0) return fail(OMR_ERR_BADARG, "empty candidate range (the reference indexes [0] and panics)");
+    int dev;
+    if ((rc = current_device(&dev))) return rc;
+    Stream st;
+    if ((rc = st.create())) return rc;
+    DevImage in, scaled, gray;
+    if ((rc = in.upload(src, st.s))) return rc;
+    const DevImage *cur = &in;
+    if (resize_scale != 1.0) {  // :24-27 scale_self (transfer.rs:66-91)
+        if (resize_scale > 1.0)
+            return fail(OMR_ERR_NOTIMPL, "scale_self with scale > 1 (INTER_LINEAR enlargement) is not implemented");
+        int dc = (int)((double)src->cols * resize_scale), dr = (int)((double)src->rows * resize_scale);
+        if ((rc = resize_area(in, dr, dc, &scaled, st.s))) return rc;
+        cur = &scaled;
+    }
+    if ((rc = to_gray(*cur, &gray, st.s))) return rc;  // :30
+    std::vector<double> vs, hs;
+    // :31 threshold(127,255,BINARY) is fused into the bit-pack (black iff gray <= 127)
+    if ((rc = sweep_scores(gray, 127, max_angle, step, 1.0, dev, st.s, &vs, &hs, nullptr))) return rc;
+    int idx = argmax_path1(vs.data(), hs.data(), A);
+    *angle_out = ((double)idx - (double)N) * step;  // :189-190
+    return OMR_OK;
+}
+
+// app/src-tauri/src/test.rs:83-178 (same driver on an already binarised image)
+int omr_find_target_angle(uint16_t max_angle, double step, const omr_image *thresh, size_t threads_hint,
+                          double *angle_out)
+{
+    (void)threads_hint;
+    int rc = check_image(thresh, true);
+    if (rc) return rc;
+    if (!angle_out) return fail(OMR_ERR_BADARG, "null angle_out");
+    int N, A = candidate_count(max_angle, step, &N);
+    if (A <= 0) return fail(OMR_ERR_BADARG, "empty candidate range");
+    int dev;
+    if ((rc = current_device(&dev))) return rc;
+    Stream st;
+    if ((rc = st.create())) return rc;
+    DevImage in;
+    if ((rc = in.upload(thresh, st.s))) return rc;
+    std::vector<double> vs, hs;
+    if ((rc = sweep_scores(in, 0, max_angle, step, 1.0, dev, st.s, &vs, &hs, nullptr))) return rc;
+    int idx = argmax_path1(vs.data(), hs.data(), A);
+    *angle_out = ((double)idx - (double)N) * step;
+    return OMR_OK;
+}
+
+// omr.rs:52-229
+int omr_get_result_from_projection(const omr_image *src, uint16_t max_angle, double step, int32_t max_w,
+                                   int32_t max_h, double *angle, int32_t *status, double *candidates,
+                                   int32_t cand_cap, int32_t *cand_len)
+{
+    int rc = check_image(src, false);
+    if (rc) return rc;
+    if (!angle || !status) return fail(OMR_ERR_BADARG, "null output");
+    if (src->channels == 2) return fail(OMR_ERR_ASSERT, "RGB2GRAY needs 3 or 4 channels");
+    // :60-82
+    double width_scale = max_w <= 0 ? 1.0 : (double)max_w / (double)src->cols;
+    double height_scale = max_h <= 0 ? 1.0 : (double)max_h / (double)src->rows;
+    double scale = width_scale < height_scale ? width_scale : height_scale;
+    int dev;
+    if ((rc = current_device(&dev))) return rc;
+    Stream st;
+    if ((rc = st.create())) return rc;
+    DevImage in, gray, e1, e2, scaled;
+    if ((rc = in.upload(src, st.s))) return rc;
+    if ((rc = to_gray(in, &gray, st.s))) return rc;  // :88-92
+    // :98-112 erode(3x3 cross, iterations = 3)
+    if ((rc = e1.alloc(gray.rows, gray.cols, 1))) return rc;
+    if ((rc = e2.alloc(gray.rows, gray.cols, 1))) return rc;
+    OMR_HIP(launch_erode_cross3(gray.ptr(), gray.step(), gray.rows, gray.cols, e1.ptr(), e1.step(), st.s));
+    OMR_HIP(launch_erode_cross3(e1.ptr(), e1.step(), gray.rows, gray.cols, e2.ptr(), e2.step(), st.s));
+    OMR_HIP(launch_erode_cross3(e2.ptr(), e2.step(), gray.rows, gray.cols, e1.ptr(), e1.step(), st.s));
+    // :114-126
+    int dc = (int)((double)src->cols * scale), dr = (int)((double)src->rows * scale);
+    if ((rc = resize_area(e1, dr, dc, &scaled, st.s))) return rc;
+    // :129-139 threshold fused into the pack; :153-208 sweep with matrix scale = resize scale (quirk B4)
+    std::vector<double> vs, hs;
+    int N = 0;
+    if ((rc = sweep_scores(scaled, 127, max_angle, step, scale, dev, st.s, &vs, &hs, &N))) return rc;
+    return omr_select_projection_result(vs.data(), hs.data(), (int32_t)vs.size(), N, step, angle, status, candidates,
+                                        cand_cap, cand_len);
+}
+
+// ---- per-image helpers ------------------------------------------------------------------------
+
+int omr_threshold_binary(const omr_image *gray, uint8_t *dst, int64_t dst_step)
+{
+    int rc = check_image(gray, true);
+    if (rc) return rc;
+    if (!dst || dst_step < gray->cols) return fail(OMR_ERR_BADARG, "bad destination");
+    int dev;
+    if ((rc = current_device(&dev))) return rc;
+    Stream st;
+    if ((rc = st.create())) return rc;
+    DevImage in, out;
+    if ((rc = in.upload(gray, st.s))) return rc;
+    if ((rc = out.alloc(in.rows, in.cols, 1))) return rc;
+    OMR_HIP(launch_threshold(in.ptr(), in.step(), in.rows, in.cols, out.ptr(), out.step(), 127, 255, st.s));
+    return out.download(dst, dst_step, st.s);
+}
+
+int omr_rgb_to_gray(const omr_image *src, uint8_t *dst, int64_t dst_step)
+{
+    int rc = check_image(src, false);
+    if (rc) return rc;
+    if (src->channels != 3 && src->channels != 4) return fail(OMR_ERR_ASSERT, "RGB2GRAY needs 3 or 4 channels");
+    if (!dst || dst_step < src->cols) return fail(OMR_ERR_BADARG, "bad destination");
+    int dev;
+    if ((rc = current_device(&dev))) return rc;
+    Stream st;
+    if ((rc = st.create())) return rc;
+    DevImage in, out;
+    if ((rc = in.upload(src, st.s))) return rc;
+    if ((rc = to_gray(in, &out, st.s))) return rc;
+    return out.download(dst, dst_step, st.s);
+}
+
+// transfer.rs:459-523
+int omr_rotate(const omr_image *src, double angle_deg, double scale, int32_t interp, const uint8_t border_value[4],
+               int32_t clip, omr_image_owned *dst)
+{
+    int rc = check_image(src, false);
+    if (rc) return rc;
+    if (!dst || !border_value) return fail(OMR_ERR_BADARG, "null output");
+    if (interp != OMR_INTER_NEAREST && interp != OMR_INTER_LINEAR)
+        return fail(OMR_ERR_NOTIMPL, "interpolation flag %d is not implemented", interp);
+    double M[6], Minv[6];
+    int drows, dcols;
+    if (clip == OMR_CLIP_DEFAULT) {  // :472-486
+        drows = src->rows;
+        dcols = src->cols;
+        rotation_matrix_2d((float)src->cols / 2.0f, (float)src->rows / 2.0f, angle_deg, scale, M);
+    } else if (clip == OMR_CLIP_CONTAIN) {  // :487-519
+        const double CV_PI_ = 3.1415926535897932384626433832795;
+        double sn = fabs(sin(angle_deg * CV_PI_ / 180.0)), cs = fabs(cos(angle_deg * CV_PI_ / 180.0));
+        double rotated_width = ceil((double)src->rows * sn + (double)src->cols * cs);
+        double rotated_height = ceil((double)src->cols * sn + (double)src->rows * cs);
+        dcols = (int)rotated_width;
+        drows = (int)rotated_height;
+        rotation_matrix_2d((float)ceil(rotated_width / 2.0), (float)ceil(rotated_height / 2.0), angle_deg, scale, M);
+        M[2] += ceil((rotated_width - (double)src->cols) / 2.0);
+        M[5] += ceil((rotated_height - (double)src->rows) / 2.0);
+    } else {
+        return fail(OMR_ERR_BADARG, "unknown clip strategy %d", clip);
+    }
+    if (drows <= 0 || dcols <= 0 || drows >= 32767 || dcols >= 32767) return fail(OMR_ERR_ASSERT, "bad canvas size");
+    invert_affine(M, Minv);
+    int dev;
+    if ((rc = current_device(&dev))) return rc;
+    Stream st;
+    if ((rc = st.create())) return rc;
+    DevImage in, out;
+    DevBuf dM;
+    if ((rc = in.upload(src, st.s))) return rc;
+    if ((rc = out.alloc(drows, dcols, src->channels))) return rc;
+    OMR_HIP(dM.alloc(sizeof Minv));
+    OMR_HIP(hipMemcpyAsync(dM.p, Minv, sizeof Minv, hipMemcpyHostToDevice, st.s));
+    uint32_t border = (uint32_t)border_value[0] | ((uint32_t)border_value[1] << 8) | ((uint32_t)border_value[2] << 16) |
+                      ((uint32_t)border_value[3] << 24);
+    if (interp == OMR_INTER_NEAREST)
+        OMR_HIP(launch_warp_nn(in.ptr(), in.step(), in.rows, in.cols, in.cn, out.ptr(), out.step(), drows, dcols,
+                               dM.as<double>(), border, st.s));
+    else
+        OMR_HIP(launch_warp_linear(in.ptr(), in.step(), in.rows, in.cols, in.cn, out.ptr(), out.step(), drows, dcols,
+                                   dM.as<double>(), border, st.s));
+    dst->rows = drows;
+    dst->cols = dcols;
+    dst->channels = src->channels;
+    dst->step_bytes = (int64_t)dcols * src->channels;
+    dst->data = (uint8_t *)malloc((size_t)drows * dst->step_bytes);
+    if (!dst->data) return fail(OMR_ERR_NOMEM, "out of host memory");
+    rc = out.download(dst->data, dst->step_bytes, st.s);
+    if (rc) omr_image_free(dst);
+    return rc;
+}
+
+// Identity "sweep" = plain projections of the image itself: X = (x*1024 + 512) >> 10 = x.
+static int identity_projections(const omr_image *bin, std::vector<uint32_t> *vp, std::vector<uint32_t> *hp, double *v_sd,
+                                double *h_sd)
+{
+    int rc = check_image(bin, true);
+    if (rc) return rc;
+    const double I[6] = {1, 0, 0, 0, 1, 0};
+    vp->assign((size_t)bin->cols, 0);
+    hp->assign((size_t)bin->rows, 0);
+    double vs, hs;
+    rc = omr_projection_sweep(bin, I, 1, vp->data(), hp->data(), &vs, &hs);
+    if (v_sd) *v_sd = vs;
+    if (h_sd) *h_sd = hs;
+    return rc;
+}
+
+int omr_get_vertical_projection(const omr_image *bin, double *out_cols)
+{
+    if (!out_cols) return fail(OMR_ERR_BADARG, "null output");
+    std::vector<uint32_t> vp, hp;
+    int rc = identity_projections(bin, &vp, &hp, nullptr, nullptr);
+    if (rc) return rc;
+    for (size_t i = 0; i < vp.size(); i++) out_cols[i] = (double)vp[i];
+    return OMR_OK;
+}
+
+int omr_get_horizontal_projection(const omr_image *bin, double *out_rows)
+{
+    if (!out_rows) return fail(OMR_ERR_BADARG, "null output");
+    std::vector<uint32_t> vp, hp;
+    int rc = identity_projections(bin, &vp, &hp, nullptr, nullptr);
+    if (rc) return rc;
+    for (size_t i = 0; i < hp.size(); i++) out_rows[i] = (double)hp[i];
+    return OMR_OK;
+}
+
+int omr_get_mat_projection_data(const omr_image *bin, double *h_rows, double *v_cols)
+{
+    if (!h_rows || !v_cols) return fail(OMR_ERR_BADARG, "null output");
+    std::vector<uint32_t> vp, hp;
+    int rc = identity_projections(bin, &vp, &hp, nullptr, nullptr);
+    if (rc) return rc;
+    for (size_t i = 0; i < hp.size(); i++) h_rows[i] = (double)hp[i];
+    for (size_t i = 0; i < vp.size(); i++) v_cols[i] = (double)vp[i];
+    return OMR_OK;
+}
+
+int omr_get_projection_standard_deviations(const omr_image *bin, double *v_sd, double *h_sd)
+{
+    if (!v_sd || !h_sd) return fail(OMR_ERR_BADARG, "null output");
+    std::vector<uint32_t> vp, hp;
+    return identity_projections(bin, &vp, &hp, v_sd, h_sd);
+}
+
+// calculate.rs:2-10 -- a sequential f64 chain over a host vector: nothing to parallelise.
+int omr_get_arithmetic_mean(const double *v, size_t n, double *out)
+{
+    if (!v || !out || n == 0) return fail(OMR_ERR_BADARG, "empty vector (the reference indexes [0] and panics)");
+    double sum = v[0];
+    for (size_t i = 1; i < n; i++) sum = sum + v[i];
+    *out = sum / (double)n;
+    return OMR_OK;
+}
+
+// calculate.rs:13-23
+int omr_get_standard_deviation(const double *v, size_t n, double *out)
+{
+    double mean;
+    int rc = omr_get_arithmetic_mean(v, n, &mean);
+    if (rc) return rc;
+    double d = v[0] - mean;
+    double sum = d * d;
+    for (size_t i = 1; i < n; i++) {
+        d = v[i] - mean;
+        sum = sum + d * d;
+    }
+    *out = sqrt(sum / (double)n);
+    return OMR_OK;
+}
+
+// Host-buffer batch over the visible devices: scan i -> device i % n_devices, one host worker
+// per device, two streams per device; results are gathered on the host (no collective).
+int omr_sweep_batch(const omr_image *scans, int32_t n, uint16_t max_angle, double step, int32_t n_devices,
+                    int32_t *best_idx, double *best_angle, double *v_sd_opt, double *h_sd_opt)
+{
+    if (!scans || n < 0 || !best_idx) return fail(OMR_ERR_BADARG, "bad batch arguments");
+    if (n == 0) return OMR_OK;
+    int ndev = omr_device_count();
+    if (ndev <= 0) return fail(OMR_ERR_GPU, "no usable HIP device (there is no CPU fallback)");
+    if (n_devices <= 0 || n_devices > ndev) n_devices = ndev;
+    int N, A = candidate_count(max_angle, step, &N);
+    if (A <= 0) return fail(OMR_ERR_BADARG, "empty candidate range");
+    const int rows = scans[0].rows, cols = scans[0].cols;
+    for (int i = 0; i < n; i++) {
+        int rc = check_image(&scans[i], true);
+        if (rc) return rc;
+        if (scans[i].rows != rows || scans[i].cols != cols)
+            return fail(OMR_ERR_ASSERT, "all scans of a batch must share one size");
+    }
+    std::vector<int> rcs((size_t)n_devices, OMR_OK);
+    std::vector<std::string> errs((size_t)n_devices);
+    auto worker = [&](int dv) {
+        auto run = [&]() -> int {
+            OMR_HIP(hipSetDevice(dv));
+            omr_batch_ctx *raw = nullptr;
+            int rc = omr_batch_create(rows, cols, max_angle, step, 1.0, dv, 2, &raw);
+            if (rc) return rc;
+            std::unique_ptr<omr_batch_ctx> ctx(raw);
+            const size_t img_bytes = (size_t)rows * cols;
+            DevBuf dimg[2], dbest, dvs, dhs;
+            OMR_HIP(dimg[0].alloc(img_bytes));
+            OMR_HIP(dimg[1].alloc(img_bytes));
+            int mine = 0;
+            for (int i = dv; i < n; i += n_devices) mine++;
+            OMR_HIP(dbest.alloc(sizeof(int32_t) * (size_t)mine));
+            OMR_HIP(dvs.alloc(sizeof(double) * (size_t)mine * A));
+            OMR_HIP(dhs.alloc(sizeof(double) * (size_t)mine * A));
+            int j = 0;
+            for (int i = dv; i < n; i += n_devices, j++) {
+                const int k = j & 1;
+                hipStream_t s = ctx->streams[k];
+                OMR_HIP(hipMemcpy2DAsync(dimg[k].p, (size_t)cols, scans[i].data, (size_t)scans[i].step_bytes,
+                                         (size_t)cols, (size_t)rows, hipMemcpyHostToDevice, s));
+                rc = enqueue_sweep(ctx->tables, *ctx->scratch[k], KERNEL_AUTO, dimg[k].as<uint8_t>(), cols, 0, s,
+                                   nullptr, nullptr, dvs.as<double>() + (size_t)j * A, dhs.as<double>() + (size_t)j * A,
+                                   dbest.as<int32_t>() + j, nullptr, nullptr);
+                if (rc) return rc;
+                OMR_HIP(hipMemcpyAsync(&best_idx[i], dbest.as<int32_t>() + j, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+                if (v_sd_opt)
+                    OMR_HIP(hipMemcpyAsync(v_sd_opt + (size_t)i * A, dvs.as<double>() + (size_t)j * A,
+                                           sizeof(double) * (size_t)A, hipMemcpyDeviceToHost, s));
+                if (h_sd_opt)
+                    OMR_HIP(hipMemcpyAsync(h_sd_opt + (size_t)i * A, dhs.as<double>() + (size_t)j * A,
+                                           sizeof(double) * (size_t)A, hipMemcpyDeviceToHost, s));
+            }
+            return omr_batch_sync(ctx.get());
+        };
+        rcs[dv] = run();
+        if (rcs[dv]) errs[dv] = last_error();
+    };
+    std::vector<std::thread> th;
+    for (int dv = 0; dv < n_devices; dv++) th.emplace_back(worker, dv);
+    for (auto &t : th) t.join();
+    for (int dv = 0; dv < n_devices; dv++)
+        if (rcs[dv]) return fail(rcs[dv], "device %d: %s", dv, errs[dv].c_str());
+    if (best_angle)
+        for (int i = 0; i < n; i++) best_angle[i] = ((double)best_idx[i] - (double)N) * step;  // projection.rs:189-190
+    return OMR_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,109 @@
+"""ctypes loader of libomrdeskew.so (the C ABI of include/omrdeskew.h).
+
+The product path: every compute call goes through this shared library and from there to the
+hand-written HIP kernels.  There is no Python/numpy fallback -- a missing library or a missing
+GPU raises.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libomrdeskew.so")
+
+u8p = C.POINTER(C.c_uint8)
+i32p = C.POINTER(C.c_int32)
+u32p = C.POINTER(C.c_uint32)
+f64p = C.POINTER(C.c_double)
+
+
+class OmrImage(C.Structure):
+    _fields_ = [("data", C.c_void_p), ("rows", C.c_int32), ("cols", C.c_int32), ("channels", C.c_int32),
+                ("step_bytes", C.c_int64)]
+
+
+class OmrImageOwned(C.Structure):
+    _fields_ = [("data", C.c_void_p), ("rows", C.c_int32), ("cols", C.c_int32), ("channels", C.c_int32),
+                ("step_bytes", C.c_int64)]
+
+
+class OmrError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__("omrdeskew error %d: %s" % (code, message))
+        self.code = code
+        self.message = message
+
+
+# name -> (restype, argtypes): every symbol include/omrdeskew.h declares
+SYMBOLS = {
+    "omr_version": (C.c_int, []),
+    "omr_device_count": (C.c_int, []),
+    "omr_last_error": (C.c_char_p, []),
+    "omr_image_free": (None, [C.POINTER(OmrImageOwned)]),
+    "omr_get_rotation_matrix_2d": (C.c_int, [C.c_float, C.c_float, C.c_double, C.c_double, f64p]),
+    "omr_candidate_count": (C.c_int, [C.c_uint16, C.c_double, i32p]),
+    "omr_sweep_matrices": (C.c_int, [C.c_int32, C.c_int32, C.c_uint16, C.c_double, C.c_double, f64p, C.c_int32]),
+    "omr_projection_sweep": (C.c_int, [C.POINTER(OmrImage), f64p, C.c_int32, u32p, u32p, f64p, f64p]),
+    "omr_sweep_plan_create": (C.c_int, [C.c_int32, C.c_int32, f64p, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]),
+    "omr_sweep_plan_create_angles": (C.c_int, [C.c_int32, C.c_int32, C.c_uint16, C.c_double, C.c_double, C.c_int32,
+                                               C.POINTER(C.c_void_p)]),
+    "omr_sweep_plan_destroy": (None, [C.c_void_p]),
+    "omr_sweep_plan_candidates": (C.c_int, [C.c_void_p]),
+    "omr_sweep_plan_run_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p,
+                                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "omr_sweep_plan_run": (C.c_int, [C.c_void_p, C.POINTER(OmrImage), C.c_int32, u32p, u32p, f64p, f64p, i32p]),
+    "omr_sweep_plan_last_kernel_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
+    "omr_sweep_plan_set_timing": (C.c_int, [C.c_void_p, C.c_int32]),
+    "omr_sweep_plan_set_kernel": (C.c_int, [C.c_void_p, C.c_int32]),
+    "omr_sweep_plan_tables": (C.c_int, [C.c_void_p, C.c_int32, i32p, i32p, i32p, i32p]),
+    "omr_batch_create": (C.c_int, [C.c_int32, C.c_int32, C.c_uint16, C.c_double, C.c_double, C.c_int32, C.c_int32,
+                                   C.POINTER(C.c_void_p)]),
+    "omr_batch_destroy": (None, [C.c_void_p]),
+    "omr_batch_run_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_void_p,
+                                       C.c_void_p, C.c_void_p]),
+    "omr_batch_sync": (C.c_int, [C.c_void_p]),
+    "omr_batch_set_timing": (C.c_int, [C.c_void_p, C.c_int32]),
+    "omr_batch_kernel_ms": (C.c_int, [C.c_void_p, f64p, i32p]),
+    "omr_sweep_batch": (C.c_int, [C.POINTER(OmrImage), C.c_int32, C.c_uint16, C.c_double, C.c_int32, i32p, f64p, f64p,
+                                  f64p]),
+    "omr_get_angle_with_projections": (C.c_int, [C.POINTER(OmrImage), C.c_uint16, C.c_double, C.c_double, C.c_size_t,
+                                                 f64p]),
+    "omr_find_target_angle": (C.c_int, [C.c_uint16, C.c_double, C.POINTER(OmrImage), C.c_size_t, f64p]),
+    "omr_get_result_from_projection": (C.c_int, [C.POINTER(OmrImage), C.c_uint16, C.c_double, C.c_int32, C.c_int32, f64p,
+                                                 i32p, f64p, C.c_int32, i32p]),
+    "omr_argmax_projection": (C.c_int, [f64p, f64p, C.c_int32, i32p]),
+    "omr_select_projection_result": (C.c_int, [f64p, f64p, C.c_int32, C.c_int32, C.c_double, f64p, i32p, f64p,
+                                               C.c_int32, i32p]),
+    "omr_threshold_binary": (C.c_int, [C.POINTER(OmrImage), u8p, C.c_int64]),
+    "omr_rgb_to_gray": (C.c_int, [C.POINTER(OmrImage), u8p, C.c_int64]),
+    "omr_rotate": (C.c_int, [C.POINTER(OmrImage), C.c_double, C.c_double, C.c_int32, u8p, C.c_int32,
+                             C.POINTER(OmrImageOwned)]),
+    "omr_get_vertical_projection": (C.c_int, [C.POINTER(OmrImage), f64p]),
+    "omr_get_horizontal_projection": (C.c_int, [C.POINTER(OmrImage), f64p]),
+    "omr_get_mat_projection_data": (C.c_int, [C.POINTER(OmrImage), f64p, f64p]),
+    "omr_get_projection_standard_deviations": (C.c_int, [C.POINTER(OmrImage), f64p, f64p]),
+    "omr_get_arithmetic_mean": (C.c_int, [f64p, C.c_size_t, f64p]),
+    "omr_get_standard_deviation": (C.c_int, [f64p, C.c_size_t, f64p]),
+}
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError("libomrdeskew.so is not built (%s); run __graft_entry__.build() -- there is no "
+                              "fallback path" % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            f = getattr(L, name)
+            f.restype = res
+            f.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise OmrError(rc, lib().omr_last_error().decode("utf-8", "replace"))
+    return rc

@@ -1,0 +1,170 @@
+"""oics::projection (packages/lib/src/projection.rs) through the C ABI."""
+import ctypes as C
+
+import numpy as np
+
+from ._lib import check, f64p, i32p, lib, u32p
+from .transfer import _mat, as_image
+
+
+def get_angle_with_projections(src_img, max_angle, step, resize_scale, threads):
+    """projection.rs:17-23: (&TransformableMatrix, u16, f64, f64, usize) -> f64"""
+    a, im = as_image(_mat(src_img))
+    out = C.c_double()
+    check(lib().omr_get_angle_with_projections(C.byref(im), int(max_angle), float(step), float(resize_scale),
+                                               int(threads), C.byref(out)))
+    return out.value
+
+
+def find_target_angle(max_angle, step, thresh, threads):
+    """app/src-tauri/src/test.rs:83-178"""
+    a, im = as_image(_mat(thresh))
+    out = C.c_double()
+    check(lib().omr_find_target_angle(int(max_angle), float(step), C.byref(im), int(threads), C.byref(out)))
+    return out.value
+
+
+def candidate_count(max_angle, step):
+    n = C.c_int32()
+    A = lib().omr_candidate_count(int(max_angle), float(step), C.byref(n))
+    return n.value, A
+
+
+def sweep_matrices(rows, cols, max_angle, step, scale=1.0):
+    _, A = candidate_count(max_angle, step)
+    M = np.zeros((max(A, 1), 6), np.float64)
+    check(lib().omr_sweep_matrices(rows, cols, int(max_angle), float(step), float(scale), M.ctypes.data_as(f64p), A))
+    return M[:A]
+
+
+def projection_sweep(bin_img, fwd_M, want_proj=True):
+    """The hot loop (projection.rs:47-65 / omr.rs:153-180) for explicit matrices, host buffers."""
+    a, im = as_image(_mat(bin_img))
+    M = np.ascontiguousarray(fwd_M, np.float64).reshape(-1, 6)
+    A = M.shape[0]
+    vp = np.zeros((A, im.cols), np.uint32) if want_proj else None
+    hp = np.zeros((A, im.rows), np.uint32) if want_proj else None
+    vs, hs = np.zeros(A), np.zeros(A)
+    check(lib().omr_projection_sweep(C.byref(im), M.ctypes.data_as(f64p), A,
+                                     vp.ctypes.data_as(u32p) if want_proj else None,
+                                     hp.ctypes.data_as(u32p) if want_proj else None,
+                                     vs.ctypes.data_as(f64p), hs.ctypes.data_as(f64p)))
+    return vp, hp, vs, hs
+
+
+def argmax_projection(v_sd, h_sd):
+    v = np.ascontiguousarray(v_sd, np.float64)
+    h = np.ascontiguousarray(h_sd, np.float64)
+    idx = C.c_int32()
+    check(lib().omr_argmax_projection(v.ctypes.data_as(f64p), h.ctypes.data_as(f64p), v.size, C.byref(idx)))
+    return idx.value
+
+
+class SweepPlan:
+    """Resident form (omr_sweep_plan_*): tables and scratch live on the device across scans."""
+
+    def __init__(self, rows, cols, max_angle=None, step=None, scale=1.0, matrices=None, device=0):
+        self.handle = C.c_void_p()
+        self.rows, self.cols = rows, cols
+        if matrices is not None:
+            M = np.ascontiguousarray(matrices, np.float64).reshape(-1, 6)
+            check(lib().omr_sweep_plan_create(rows, cols, M.ctypes.data_as(f64p), M.shape[0], device,
+                                              C.byref(self.handle)))
+        else:
+            check(lib().omr_sweep_plan_create_angles(rows, cols, int(max_angle), float(step), float(scale), device,
+                                                     C.byref(self.handle)))
+        self.A = lib().omr_sweep_plan_candidates(self.handle)
+
+    def close(self):
+        if self.handle:
+            lib().omr_sweep_plan_destroy(self.handle)
+            self.handle = C.c_void_p()
+
+    __del__ = close
+
+    def set_kernel(self, which):
+        check(lib().omr_sweep_plan_set_kernel(self.handle, which))
+
+    def set_timing(self, on):
+        check(lib().omr_sweep_plan_set_timing(self.handle, 1 if on else 0))
+
+    def last_kernel_ms(self):
+        ms = C.c_float()
+        check(lib().omr_sweep_plan_last_kernel_ms(self.handle, C.byref(ms)))
+        return ms.value
+
+    def tables(self, a):
+        ad, bd = np.zeros(self.cols, np.int32), np.zeros(self.cols, np.int32)
+        X0, Y0 = np.zeros(self.rows, np.int32), np.zeros(self.rows, np.int32)
+        check(lib().omr_sweep_plan_tables(self.handle, a, ad.ctypes.data_as(i32p), bd.ctypes.data_as(i32p),
+                                          X0.ctypes.data_as(i32p), Y0.ctypes.data_as(i32p)))
+        return ad, bd, X0, Y0
+
+    def run(self, img, black_max=0, want_proj=True):
+        a, im = as_image(_mat(img))
+        vp = np.zeros((self.A, self.cols), np.uint32) if want_proj else None
+        hp = np.zeros((self.A, self.rows), np.uint32) if want_proj else None
+        vs, hs = np.zeros(self.A), np.zeros(self.A)
+        best = C.c_int32()
+        check(lib().omr_sweep_plan_run(self.handle, C.byref(im), black_max,
+                                       vp.ctypes.data_as(u32p) if want_proj else None,
+                                       hp.ctypes.data_as(u32p) if want_proj else None,
+                                       vs.ctypes.data_as(f64p), hs.ctypes.data_as(f64p), C.byref(best)))
+        return vp, hp, vs, hs, best.value
+
+    def run_device(self, d_img_ptr, step_bytes, black_max, stream, d_vproj, d_hproj, d_v_sd, d_h_sd, d_best):
+        check(lib().omr_sweep_plan_run_device(self.handle, d_img_ptr, step_bytes, black_max, stream, d_vproj, d_hproj,
+                                              d_v_sd, d_h_sd, d_best))
+
+
+class Batch:
+    """omr_batch_*: n device-resident scans of one shape, round-robin over internal streams."""
+
+    def __init__(self, rows, cols, max_angle, step, scale=1.0, device=0, n_streams=2):
+        self.handle = C.c_void_p()
+        check(lib().omr_batch_create(rows, cols, int(max_angle), float(step), float(scale), device, n_streams,
+                                     C.byref(self.handle)))
+        self.N, self.A = candidate_count(max_angle, step)
+        self.step = step
+
+    def close(self):
+        if self.handle:
+            lib().omr_batch_destroy(self.handle)
+            self.handle = C.c_void_p()
+
+    __del__ = close
+
+    def run_device(self, d_scans, scan_stride, step_bytes, n, black_max, d_best, d_v_sd=None, d_h_sd=None):
+        check(lib().omr_batch_run_device(self.handle, d_scans, scan_stride, step_bytes, n, black_max, d_best, d_v_sd,
+                                         d_h_sd))
+
+    def sync(self):
+        check(lib().omr_batch_sync(self.handle))
+
+    def set_timing(self, on):
+        check(lib().omr_batch_set_timing(self.handle, 1 if on else 0))
+
+    def kernel_ms(self):
+        s, n = C.c_double(), C.c_int32()
+        check(lib().omr_batch_kernel_ms(self.handle, C.byref(s), C.byref(n)))
+        return s.value, n.value
+
+
+def sweep_batch(scans, max_angle, step, n_devices=0, want_sd=False):
+    """omr_sweep_batch: host images, scan i -> device i % n_devices, host-side gather."""
+    from ._lib import OmrImage
+    keep, arr = [], (OmrImage * len(scans))()
+    for i, s in enumerate(scans):
+        a, im = as_image(_mat(s))
+        keep.append(a)
+        arr[i] = im
+    n = len(scans)
+    _, A = candidate_count(max_angle, step)
+    best = np.zeros(n, np.int32)
+    ang = np.zeros(n, np.float64)
+    vs = np.zeros((n, A)) if want_sd else None
+    hs = np.zeros((n, A)) if want_sd else None
+    check(lib().omr_sweep_batch(arr, n, int(max_angle), float(step), n_devices, best.ctypes.data_as(i32p),
+                                ang.ctypes.data_as(f64p), vs.ctypes.data_as(f64p) if want_sd else None,
+                                hs.ctypes.data_as(f64p) if want_sd else None))
+    return best, ang, vs, hs

@@ -1,0 +1,145 @@
+/*
+ * oracle.h -- CPU restatement of the reference's projection-std-dev deskew hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is part of the product: only
+ * tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it, and
+ * only as the checker / the reported CPU baseline.  The shipped library
+ * (omr-img-corrector_amd/csrc -> libomrdeskew.so) never links or calls this code.
+ *
+ * PARITY STATUS: "parity unpinned".  The reference (ch1ny/omr-img-corrector) holds no
+ * golden vectors or known-answer tests for this path, it cannot
+ * be built here (no rustc, no OpenCV 4.6.0), and the arithmetic of the warp lives in the
+ * un-vendored third-party dependency OpenCV 4.6.0 (crate opencv = "0.77.0",
+ * packages/lib/Cargo.toml:9).  The oracle therefore restates (a) the in-tree Rust code
+ * line by line and (b) the published OpenCV 4.6.0 algorithms (imgwarp.cpp warpAffine /
+ * remapNearest, thresh.cpp, color_rgb, morph, resize.cpp) and is pinned only by
+ * hand-computed micro cases (tests/test_oracle_micro.py), by an independently written
+ * numpy restatement (oracle/oracle_np.py) and by the reference's accuracy criterion
+ * (|detected - injected| < 0.5 deg, packages/lib/src/lib.rs:103-113).
+ *
+ * All file:line citations are relative to /root/reference.
+ */
+#ifndef ORC_ORACLE_H
+#define ORC_ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- OpenCV 4.6.0 restatements (third-party, published algorithm) ------------------ */
+
+/* getRotationMatrix2D(Point2f center, double angle_deg, double scale) -> 2x3 f64.
+ * Call sites: packages/lib/src/transfer.rs:475,501; packages/lib/src/omr.rs:159-163,425-426. */
+void orc_get_rotation_matrix_2d(float cx, float cy, double angle_deg, double scale, double M[6]);
+
+/* warpAffine step 1 (no WARP_INVERSE_MAP): invert the forward matrix, exact op order. */
+void orc_invert_affine(const double M[6], double Minv[6]);
+
+/* warpAffine fixed-point tables.  adelta/bdelta: dcols ints, X0/Y0: drows ints
+ * (X0/Y0 already include round_delta: 512 for NEAREST, 16 for LINEAR). */
+void orc_warp_tables(const double Minv[6], int dcols, int drows, int round_delta,
+                     int32_t *adelta, int32_t *bdelta, int32_t *X0, int32_t *Y0);
+
+/* warpAffine(src, dst, M, dsize, INTER_NEAREST, BORDER_CONSTANT, border) for 8-bit images with
+ * `cn` interleaved channels.  Call sites: transfer.rs:477-485,510-518; omr.rs:165-173,435-443
+ * (flags = WARP_POLAR_LINEAR whose numeric value is 0 = INTER_NEAREST).
+ * Returns 0, or -215 on a bad shape (OpenCV assertion: every dim < SHRT_MAX). */
+int orc_warp_affine_nn(const uint8_t *src, int srows, int scols, int cn, int64_t sstep,
+                       uint8_t *dst, int drows, int dcols, int64_t dstep,
+                       const double M[6], const uint8_t border[4]);
+
+/* warpAffine(..., INTER_LINEAR, BORDER_CONSTANT, border): the final deskew of
+ * packages/core/src/main.rs:72-81 and app/src-tauri/src/test.rs:322-331. */
+int orc_warp_affine_linear(const uint8_t *src, int srows, int scols, int cn, int64_t sstep,
+                           uint8_t *dst, int drows, int dcols, int64_t dstep,
+                           const double M[6], const uint8_t border[4]);
+
+/* threshold(src, dst, 127, 255, THRESH_BINARY) on 8U: transfer.rs:294-301, omr.rs:129-139. */
+void orc_threshold_binary(const uint8_t *src, int rows, int cols, int64_t sstep,
+                          uint8_t *dst, int64_t dstep, int thresh, int maxval);
+
+/* cvtColor(COLOR_RGB2GRAY) 8U, cn = 3 or 4: transfer.rs:283-290, omr.rs:88-92. */
+void orc_rgb2gray(const uint8_t *src, int rows, int cols, int cn, int64_t sstep,
+                  uint8_t *dst, int64_t dstep);
+
+/* erode(3x3 MORPH_ELLIPSE (= cross), iterations, BORDER_CONSTANT, default border): omr.rs:98-112. */
+void orc_erode_cross3(const uint8_t *src, int rows, int cols, int64_t sstep,
+                      uint8_t *dst, int64_t dstep, int iterations);
+
+/* resize(..., dsize, INTER_AREA) 8U, cn channels: transfer.rs:66-91, omr.rs:114-126.
+ * Returns 0 or -215. */
+int orc_resize_area(const uint8_t *src, int srows, int scols, int cn, int64_t sstep,
+                    uint8_t *dst, int drows, int dcols, int64_t dstep);
+
+/* ---- in-tree Rust restatements ----------------------------------------------------- */
+
+/* calculate.rs:2-10 and :13-23 (population sd, strictly sequential f64). */
+double orc_arithmetic_mean(const double *v, size_t n);
+double orc_standard_deviation(const double *v, size_t n);
+
+/* transfer.rs:380-405 (per-column count of px==0) and :305-333 (per-row count). */
+void orc_vertical_projection(const uint8_t *img, int rows, int cols, int64_t step, double *out_cols);
+void orc_horizontal_projection(const uint8_t *img, int rows, int cols, int64_t step, double *out_rows);
+/* omr.rs:8-39: fused single pass, returns (horizontal[rows], vertical[cols]). */
+void orc_mat_projection_data(const uint8_t *img, int rows, int cols, int64_t step,
+                             double *h_rows, double *v_cols);
+/* transfer.rs:527-536: (vertical sd, horizontal sd). */
+void orc_projection_standard_deviations(const uint8_t *img, int rows, int cols, int64_t step,
+                                        double *v_sd, double *h_sd);
+
+/* transfer.rs:459-523 rotate_mat.  clip: 0 = DEFAULT (same canvas), 1 = CONTAIN.
+ * interp: 0 nearest, 1 linear.  For CONTAIN call orc_rotate_mat_size first. */
+void orc_rotate_mat_size(int rows, int cols, double angle_deg, int clip, int *drows, int *dcols);
+int orc_rotate_mat(const uint8_t *src, int rows, int cols, int cn, int64_t sstep,
+                   double angle_deg, double scale, int interp, const uint8_t border[4], int clip,
+                   uint8_t *dst, int drows, int dcols, int64_t dstep);
+
+/* Number of half-open candidates: N = (max_angle as f64 / step) as u16, A = 2N
+ * (projection.rs:36-38, omr.rs:140-145). */
+int orc_candidate_count(uint16_t max_angle, double step, int *N_out);
+
+/* The hot loop of projection.rs:47-65 on an already binarised image, faithful to the
+ * reference's materialisation: per candidate warp -> clone (transfer.rs:522) -> two
+ * projection passes -> two std-devs.  `matrix_scale` is the scale handed to
+ * getRotationMatrix2D (1.0 for path 1; projection_resize_scale for omr.rs:159-163).
+ * vproj (A x cols) / hproj (A x rows) may be NULL.  threads <= 1: sequential; > 1:
+ * angle-parallel OpenMP (the intent of projection.rs:69-122 with the index*step bug fixed). */
+int orc_sweep(const uint8_t *bin, int rows, int cols, int64_t step,
+              uint16_t max_angle, double angle_step, double matrix_scale, int threads,
+              uint32_t *vproj, uint32_t *hproj, double *v_sd, double *h_sd);
+
+/* Same loop for an explicit list of A forward 2x3 matrices (row-major, A x 6). */
+int orc_sweep_matrices(const uint8_t *bin, int rows, int cols, int64_t step,
+                       const double *fwd_M, int A, int threads,
+                       uint32_t *vproj, uint32_t *hproj, double *v_sd, double *h_sd);
+
+/* projection.rs:125-190 argmax + tie policy.  Returns the lowest acceptable index; if
+ * `accept` (n bytes) is non-NULL it is set to 1 for every index the reference could return
+ * (its HashMap iteration order is random on exact ties). */
+size_t orc_argmax_path1(const double *v_sd, const double *h_sd, size_t n, uint8_t *accept);
+
+/* omr.rs:147-221 selection + status.  status: 0 Believed, 1 NeedCheck, 2 NotAResult.
+ * candidates (cap >= n) receives the candidate angles; returns angle. */
+double orc_select_path2(const double *v_sd, const double *h_sd, size_t n, int N, double angle_step,
+                        int *status, double *candidates, int *cand_len);
+
+/* projection.rs:17-194 (threads = 1 semantics) on an 8-bit image with cn = 3/4 channels
+ * (cn = 1 is accepted as a convenience: the reference would panic in cvtColor).
+ * Returns 0 / negative error; *angle_out receives the angle in degrees. */
+int orc_get_angle_with_projections(const uint8_t *src, int rows, int cols, int cn, int64_t step,
+                                   uint16_t max_angle, double angle_step, double resize_scale,
+                                   double *angle_out, size_t *index_out);
+
+/* omr.rs:52-229 get_result_from_projection. */
+int orc_get_result_from_projection(const uint8_t *src, int rows, int cols, int cn, int64_t step,
+                                   uint16_t max_angle, double angle_step, int max_w, int max_h,
+                                   double *angle, int *status, double *candidates, int cand_cap,
+                                   int *cand_len);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

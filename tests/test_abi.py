@@ -1,0 +1,95 @@
+"""CPU-side checks of the drop-in boundary: the library loads, exports every symbol that
+include/omrdeskew.h declares, fails loudly without a GPU, and its host-only entry points
+(geometry, candidate range, arg-max policies, calculate.rs) agree with the oracle."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import oics
+from oics import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_symbols():
+    txt = open(os.path.join(ROOT, "include", "omrdeskew.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(omr_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol():
+    L = C.CDLL(_lib.LIB_PATH)
+    names = header_symbols()
+    assert len(names) >= 35
+    for n in names:
+        assert hasattr(L, n), "libomrdeskew.so does not export %s" % n
+    assert sorted(_lib.SYMBOLS) == names, "ctypes table and header disagree"
+
+
+def test_version_and_error_channel():
+    L = oics.lib()
+    assert L.omr_version() >= 100
+    assert L.omr_candidate_count(10, 0.05, None) == 400
+    with pytest.raises(oics.OmrError) as e:
+        oics.projection.argmax_projection([], [])
+    assert e.value.code == -5
+
+
+def test_no_cpu_fallback_without_gpu():
+    if oics.lib().omr_device_count() > 0:
+        pytest.skip("a GPU is present")
+    b = np.zeros((16, 16), np.uint8)
+    with pytest.raises(oics.OmrError) as e:
+        oics.projection.find_target_angle(5, 0.5, b, 1)
+    assert e.value.code == -217
+    with pytest.raises(oics.OmrError) as e:
+        oics.transfer.get_projection_standard_deviations(b)
+    assert e.value.code == -217
+
+
+def test_geometry_matches_oracle(oracle):
+    for (rows, cols, ma, st, sc) in ((3508, 2480, 10, 0.05, 1.0), (230, 248, 45, 0.2, 0.2), (511, 333, 5, 0.5, 1.0)):
+        assert oics.projection.candidate_count(ma, st) == oracle.candidate_count(ma, st)
+        M = oics.projection.sweep_matrices(rows, cols, ma, st, sc)
+        Mo = oracle.rotation_matrices(rows, cols, ma, st, sc)
+        assert M.shape == Mo.shape and (M.view(np.uint64) == Mo.view(np.uint64)).all()
+    assert oics.projection.candidate_count(1, 0.3) == (3, 6)
+    assert oics.projection.candidate_count(1, 2.0) == (0, 0)
+
+
+def test_argmax_policies_match_oracle(oracle):
+    rng = np.random.Generator(np.random.PCG64(5))
+    for trial in range(300):
+        n = int(rng.integers(1, 12))
+        # small integer scores force plenty of exact ties
+        v = rng.integers(0, 4, n).astype(np.float64)
+        h = rng.integers(0, 4, n).astype(np.float64)
+        idx = oics.projection.argmax_projection(v, h)
+        lowest, accept = oracle.argmax_path1(v, h)
+        assert idx == lowest and idx in accept.tolist()
+        N = n // 2
+        r = oics.omr.select_projection_result(v, h, N, 0.25)
+        ang, st, cand = oracle.select_path2(v, h, N, 0.25)
+        assert (r.angle, int(r.status), r.candidates.tolist()) == (ang, st, cand.tolist())
+
+
+def test_calculate_matches_oracle(oracle):
+    rng = np.random.Generator(np.random.PCG64(6))
+    for n in (1, 2, 7, 2480, 3508):
+        v = rng.integers(0, 3000, n).astype(np.float64) + rng.random(n)
+        assert oics.calculate.get_arithmetic_mean(v) == oracle.arithmetic_mean(v)
+        assert oics.calculate.get_standard_deviation(v) == oracle.standard_deviation(v)
+    with pytest.raises(oics.OmrError):
+        oics.calculate.get_standard_deviation([])
+
+
+def test_bad_arguments_are_errors_not_crashes():
+    with pytest.raises(oics.OmrError):
+        oics.projection.SweepPlan(0, 10, 5, 0.5)
+    with pytest.raises(oics.OmrError):
+        oics.projection.SweepPlan(40000, 10, 5, 0.5)
+    with pytest.raises(oics.OmrError):
+        oics.projection.SweepPlan(10, 10, 1, 2.0)  # empty candidate range

