@@ -51,8 +51,9 @@ def cpu_baseline(gray, gpu_vs, gpu_hs, sample_angles):
     b = orc.threshold_binary(gray)
     Ms = orc.rotation_matrices(ROWS, COLS, MAX_ANGLE, STEP)
     A = Ms.shape[0]
+    cores = min(os.cpu_count() or 1, 64)
+    sample_angles = min(A, max(sample_angles, 2 * cores))
     pick = np.linspace(0, A - 1, sample_angles).astype(int)
-    cores = os.cpu_count() or 1
     orc.sweep_matrices(b, Ms[pick[:2]], threads=1, want_proj=False, fast=True)  # warm-up
     t0 = time.perf_counter()
     _, _, vs1, hs1 = orc.sweep_matrices(b, Ms[pick[: max(4, sample_angles // 8)]], threads=1, want_proj=False, fast=True)
@@ -84,7 +85,9 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--scans", type=int, default=4, help="scans per GPU per step")
-    ap.add_argument("--streams", type=int, default=2)
+    ap.add_argument("--streams", type=int, default=1,
+                    help="HIP streams per GPU; the sweep kernel fills the chip by itself, so 1 keeps the "
+                         "per-kernel HIP-event / rocprof durations free of cross-stream overlap")
     ap.add_argument("--cpu-sample-angles", type=int, default=48)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()

@@ -189,6 +189,9 @@ int omr_get_result_from_projection(const omr_image *src, uint16_t max_angle, dou
 
 /* projection.rs:125-190 on host arrays (also used by the drivers above). */
 int omr_argmax_projection(const double *v_sd, const double *h_sd, int32_t n, int32_t *index_out);
+/* Same policy for scores that live on the device (enqueue only; d_index_out: 1 int32). */
+int omr_argmax_projection_device(const double *d_v_sd, const double *d_h_sd, int32_t n,
+                                 int32_t *d_index_out, void *stream);
 /* omr.rs:147-221 on host arrays. */
 int omr_select_projection_result(const double *v_sd, const double *h_sd, int32_t n, int32_t N,
                                  double step, double *angle, int32_t *status, double *candidates,

@@ -427,6 +427,14 @@ int omr_projection_sweep(const omr_image *bin, const double *fwd_M, int32_t A, u
     return rc;
 }
 
+int omr_argmax_projection_device(const double *d_v_sd, const double *d_h_sd, int32_t n, int32_t *d_index_out,
+                                 void *stream)
+{
+    if (!d_v_sd || !d_h_sd || !d_index_out || n <= 0) return fail(OMR_ERR_BADARG, "bad arguments");
+    OMR_HIP(launch_argmax_path1(d_v_sd, d_h_sd, n, d_index_out, (hipStream_t)stream));
+    return OMR_OK;
+}
+
 // ---- batch ----------------------------------------------------------------------------------
 
 int omr_batch_create(int32_t rows, int32_t cols, uint16_t max_angle, double step, double scale, int32_t device,

@@ -197,6 +197,8 @@ __global__ __launch_bounds__(LDS_WAVES *OMR_WAVE) void sweep_lds_kernel(
     const LdsTile tile = tiles[a];
     const int R = tile.rows_per_tile;
     const int pitch = tile.win_words | 1;
+    const int pitch4 = pitch * 4;
+    const int slab_byte = wave * LDS_SLAB_WORDS * 4;
     const unsigned long long active_mask = __ballot(active);
 
     for (int i = threadIdx.x; i < LDS_BAND; i += LDS_WAVES * OMR_WAVE) hacc[i] = 0;
@@ -243,12 +245,8 @@ __global__ __launch_bounds__(LDS_WAVES *OMR_WAVE) void sweep_lds_kernel(
                 }
             }
             // wave-private slab: the LDS operations of one wave execute in order, no barrier needed
-            auto tally = [&](uint32_t bit, int y) {
-                vacc += bit;
-                const unsigned long long m = __ballot(bit != 0) & active_mask;
-                const int k = y - hbase;
-                hrow = write_lane(hrow, __popcll(m), k);
-                if (k == OMR_WAVE - 1) {
+            auto flush_rows = [&](int y_last) {
+                if (y_last - hbase == OMR_WAVE - 1) {
                     if (hrow) atomicAdd(&hacc[hbase - y0 + lane], (uint32_t)hrow);
                     hrow = 0;
                     hbase += OMR_WAVE;
@@ -258,23 +256,57 @@ __global__ __launch_bounds__(LDS_WAVES *OMR_WAVE) void sweep_lds_kernel(
                 const int xoff = wx0 << 15;  // (wx0 * 32) << 10
                 const int yoff = ya << 10;
                 const int adl = ad - xoff, bdl = bd - yoff;  // window-local lane constants
-#pragma unroll 4
-                for (int r = 0; r < tr; r++) {
-                    const int2_t s0 = s0p[ty + r];
-                    const int sx = s0.x + adl;  // >= 0 inside the window
-                    const int sy = s0.y + bdl;
-                    const uint32_t w = slab[__mul24(sy >> 10, pitch) + (sx >> 15)];
-                    tally((w >> ((sx >> 10) & 31)) & 1u, ty + r);
+                int r = 0;
+                // y0, R and 64 are multiples of 4: a group of four rows never straddles a 64-row
+                // flush boundary, so four gathers are in flight before the first is consumed
+                for (; r + 4 <= tr; r += 4) {
+                    const int y = ty + r;
+                    int2_t s4[4];
+                    uint32_t w[4];
+                    int sh[4];
+#pragma unroll
+                    for (int j = 0; j < 4; j++) s4[j] = s0p[y + j];
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        const int sx = s4[j].x + adl;  // >= 0 inside the window
+                        const int sy = s4[j].y + bdl;
+                        // byte address = Y * pitch4 + 4 * (X >> 5) + slab base (and_or + mad24)
+                        const int off = __mul24(sy >> 10, pitch4) + (((sx >> 13) & 0xFFC) | slab_byte);
+                        w[j] = *(const uint32_t *)((const char *)slab_all + off);
+                        sh[j] = sx >> 10;
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        const uint32_t bit = __builtin_amdgcn_ubfe(w[j], (uint32_t)sh[j], 1u);
+                        vacc += bit;
+                        const unsigned long long m = __ballot(bit != 0) & active_mask;
+                        hrow = write_lane(hrow, __popcll(m), y + j - hbase);
+                    }
+                    flush_rows(y + 3);
+                }
+                for (; r < tr; r++) {
+                    const int y = ty + r;
+                    const int2_t s0 = s0p[y];
+                    const int sx = s0.x + adl, sy = s0.y + bdl;
+                    const uint32_t bit = __builtin_amdgcn_ubfe(slab[__mul24(sy >> 10, pitch) + (sx >> 15)], (uint32_t)(sx >> 10), 1u);
+                    vacc += bit;
+                    const unsigned long long m = __ballot(bit != 0) & active_mask;
+                    hrow = write_lane(hrow, __popcll(m), y - hbase);
+                    flush_rows(y);
                 }
             } else {
                 for (int r = 0; r < tr; r++) {
-                    const int2_t s0 = s0p[ty + r];
+                    const int y = ty + r;
+                    const int2_t s0 = s0p[y];
                     const int X = (s0.x + ad) >> 10;
                     const int Y = (s0.y + bd) >> 10;
                     uint32_t bit = 0;
                     if ((unsigned)X < (unsigned)d.cols && (unsigned)Y < (unsigned)d.rows)
                         bit = (bits[(int64_t)Y * d.wpr + (X >> 5)] >> (X & 31)) & 1u;
-                    tally(bit, ty + r);
+                    vacc += bit;
+                    const unsigned long long m = __ballot(bit != 0) & active_mask;
+                    hrow = write_lane(hrow, __popcll(m), y - hbase);
+                    flush_rows(y);
                 }
             }
         }
@@ -345,7 +377,17 @@ __global__ __launch_bounds__(SD_THREADS) void stddev_kernel(const uint32_t *__re
         }
         __syncthreads();
         if (threadIdx.x == 0) {
-            for (int i = 0; i < m; i++) acc = acc + sq[i];
+            // the adds form one dependent chain (that order IS the specification); keep 16 LDS
+            // reads in flight ahead of it so the chain runs at f64-add latency, not LDS latency
+            int i = 0;
+            for (; i + 16 <= m; i += 16) {
+                double t[16];
+#pragma unroll
+                for (int j = 0; j < 16; j++) t[j] = sq[i + j];
+#pragma unroll
+                for (int j = 0; j < 16; j++) acc = acc + t[j];
+            }
+            for (; i < m; i++) acc = acc + sq[i];
         }
         __syncthreads();
     }
@@ -370,52 +412,105 @@ hipError_t launch_stddev(const uint32_t *d_vproj, const uint32_t *d_hproj, Sweep
 // matters for the len()==1 test); unique-and-equal -> that index; otherwise the candidate of
 // the union with the largest v^2+h^2 (strict < from 0.0); the reference iterates a HashMap, we
 // take the lowest index among exact ties (quirk B5); nothing positive -> n/2.
-__global__ void argmax_path1_kernel(const double *__restrict__ v, const double *__restrict__ h, int n,
-                                    int32_t *__restrict__ best)
+#define AM_THREADS 256
+
+// 64-bit key helpers: (value, index) packed so that max() prefers the larger value and, on
+// equal values, the LOWER index.  The scores are finite and >= 0, so their IEEE bit patterns
+// order like the values.
+__device__ __forceinline__ unsigned long long am_block_max(unsigned long long v, unsigned long long *sh)
 {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    double vmax = v[0], hmax = h[0];
-    int vcount = 1, hcount = 1, vfirst = 0, hfirst = 0;
-    for (int i = 0; i < n; i++) {
-        if (v[i] > vmax) {
-            vmax = v[i];
-            vcount = 1;
-            vfirst = i;
-        } else if (v[i] == vmax) {
-            vcount++;
-        }
-        if (h[i] > hmax) {
-            hmax = h[i];
-            hcount = 1;
-            hfirst = i;
-        } else if (h[i] == hmax) {
-            hcount++;
-        }
+    for (int off = 32; off > 0; off >>= 1) {
+        const unsigned long long o = __shfl_down(v, off);
+        v = o > v ? o : v;
     }
-    int result;
-    if (vcount == 1 && hcount == 1 && vfirst == hfirst) {
-        result = vfirst;
-    } else {
-        double sdp = 0.0;
-        result = -1;
-        for (int i = 0; i < n; i++) {
-            if (v[i] == vmax || h[i] == hmax) {
-                const double cur = v[i] * v[i] + h[i] * h[i];
-                if (sdp < cur) {
-                    sdp = cur;
-                    result = i;
-                }
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    unsigned long long r = sh[0];
+    for (int w = 1; w < AM_THREADS / OMR_WAVE; w++) r = sh[w] > r ? sh[w] : r;
+    return r;
+}
+
+__device__ __forceinline__ unsigned am_block_sum(unsigned v, unsigned *sh)
+{
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    unsigned r = 0;
+    for (int w = 0; w < AM_THREADS / OMR_WAVE; w++) r += sh[w];
+    return r;
+}
+
+__global__ __launch_bounds__(AM_THREADS) void argmax_path1_kernel(const double *__restrict__ v,
+                                                                  const double *__restrict__ h, int n,
+                                                                  int32_t *__restrict__ best)
+{
+    __shared__ unsigned long long shm[AM_THREADS / OMR_WAVE];
+    __shared__ unsigned shc[AM_THREADS / OMR_WAVE];
+    // pass 1: maxima of both score vectors
+    double lv = 0.0, lh = 0.0;  // scores are >= 0
+    for (int i = threadIdx.x; i < n; i += AM_THREADS) {
+        lv = fmax(lv, v[i]);
+        lh = fmax(lh, h[i]);
+    }
+    const double vmax = __longlong_as_double((long long)am_block_max((unsigned long long)__double_as_longlong(lv), shm));
+    const double hmax = __longlong_as_double((long long)am_block_max((unsigned long long)__double_as_longlong(lh), shm));
+    // pass 2: sizes of the two "possibles" lists, their first members, and the best candidate
+    unsigned vc = 0, hc = 0;
+    unsigned vfirst = 0xffffffffu, hfirst = 0xffffffffu;
+    unsigned long long key = 0;  // (v^2+h^2 bits, ~index): 0 = "nothing beats 0.0"
+    for (int i = threadIdx.x; i < n; i += AM_THREADS) {
+        const double vi = v[i], hi = h[i];
+        const bool ve = vi == vmax, he = hi == hmax;
+        if (ve) {
+            vc++;
+            vfirst = min(vfirst, (unsigned)i);
+        }
+        if (he) {
+            hc++;
+            hfirst = min(hfirst, (unsigned)i);
+        }
+        if (ve || he) {
+            const double cur = vi * vi + hi * hi;
+            if (cur > 0.0) {
+                // cur <= 2^53-ish: its top bits fit 40 bits?  No -- keep the full pattern and break
+                // ties with a second reduction instead (see below)
+                const unsigned long long k = (unsigned long long)__double_as_longlong(cur);
+                key = k > key ? k : key;
             }
         }
-        if (result < 0) result = n / 2;
     }
-    *best = result;
+    const unsigned vcount = am_block_sum(vc, shc) + (v[0] == vmax ? 1u : 0u);  // index 0 is listed twice
+    const unsigned hcount = am_block_sum(hc, shc) + (h[0] == hmax ? 1u : 0u);
+    const unsigned vf = 0xffffffffu - (unsigned)am_block_max(0xffffffffu - vfirst, shm);
+    const unsigned hf = 0xffffffffu - (unsigned)am_block_max(0xffffffffu - hfirst, shm);
+    const unsigned long long kbest = am_block_max(key, shm);
+    // pass 3: lowest index among the candidates that reach the best v^2+h^2
+    unsigned cand = 0xffffffffu;
+    if (kbest != 0) {
+        for (int i = threadIdx.x; i < n; i += AM_THREADS) {
+            const double vi = v[i], hi = h[i];
+            if (vi == vmax || hi == hmax) {
+                const double cur = vi * vi + hi * hi;
+                if ((unsigned long long)__double_as_longlong(cur) == kbest) cand = min(cand, (unsigned)i);
+            }
+        }
+    }
+    const unsigned cf = 0xffffffffu - (unsigned)am_block_max(0xffffffffu - cand, shm);
+    if (threadIdx.x == 0) {
+        int result;
+        if (vcount == 1 && hcount == 1 && vf == hf) result = (int)vf;
+        else if (kbest != 0) result = (int)cf;
+        else result = n / 2;
+        *best = result;
+    }
 }
 
 hipError_t launch_argmax_path1(const double *d_v_sd, const double *d_h_sd, int A, int32_t *d_best, hipStream_t s)
 {
     if (A <= 0) return hipSuccess;
-    hipLaunchKernelGGL(argmax_path1_kernel, dim3(1), dim3(64), 0, s, d_v_sd, d_h_sd, A, d_best);
+    hipLaunchKernelGGL(argmax_path1_kernel, dim3(1), dim3(AM_THREADS), 0, s, d_v_sd, d_h_sd, A, d_best);
     return hipGetLastError();
 }
 

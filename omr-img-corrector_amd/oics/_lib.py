@@ -71,6 +71,7 @@ SYMBOLS = {
     "omr_get_result_from_projection": (C.c_int, [C.POINTER(OmrImage), C.c_uint16, C.c_double, C.c_int32, C.c_int32, f64p,
                                                  i32p, f64p, C.c_int32, i32p]),
     "omr_argmax_projection": (C.c_int, [f64p, f64p, C.c_int32, i32p]),
+    "omr_argmax_projection_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     "omr_select_projection_result": (C.c_int, [f64p, f64p, C.c_int32, C.c_int32, C.c_double, f64p, i32p, f64p,
                                                C.c_int32, i32p]),
     "omr_threshold_binary": (C.c_int, [C.POINTER(OmrImage), u8p, C.c_int64]),

@@ -294,3 +294,20 @@ def test_plan_is_reusable_and_thread_safe(oracle):
     [t.join() for t in ts]
     plan.close()
     assert not errs, errs
+
+
+def test_device_argmax_tie_policy(oracle):
+    import torch
+    rng = np.random.Generator(np.random.PCG64(17))
+    dev = torch.device("cuda:0")
+    out = torch.zeros(1, dtype=torch.int32, device=dev)
+    for trial in range(200):
+        n = int(rng.integers(1, 700))
+        levels = int(rng.integers(1, 5))  # few distinct values -> many exact ties
+        v = rng.integers(0, levels, n).astype(np.float64) * 1.5
+        h = rng.integers(0, levels, n).astype(np.float64) * 0.5
+        dv, dh = torch.from_numpy(v).to(dev), torch.from_numpy(h).to(dev)
+        oics._lib.check(oics.lib().omr_argmax_projection_device(dv.data_ptr(), dh.data_ptr(), n, out.data_ptr(), None))
+        torch.cuda.synchronize()
+        lowest, accept = oracle.argmax_path1(v, h)
+        assert int(out.item()) == lowest, (trial, n)

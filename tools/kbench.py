@@ -1,0 +1,50 @@
+"""Kernel micro-benchmark (development aid): sweep-kernel time at the headline size, one scan at a
+time on one stream, HIP events around the sweep kernel only.  Usage: python tools/kbench.py [reps]"""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "omr-img-corrector_amd"))
+import numpy as np
+import torch
+
+from oics import projection, synth
+
+reps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+ROWS, COLS = 3508, 2480
+g, th = synth.make_card(ROWS, COLS, 2)
+dev = torch.device("cuda:0")
+d = torch.from_numpy(g).to(dev)
+A = 400
+vs = torch.zeros(A, dtype=torch.float64, device=dev)
+hs = torch.zeros(A, dtype=torch.float64, device=dev)
+best = torch.zeros(1, dtype=torch.int32, device=dev)
+s = torch.cuda.Stream()
+ref = None
+for name, sel in (("generic", 1), ("lds", 2)):
+    plan = projection.SweepPlan(ROWS, COLS, 10, 0.05)
+    plan.set_kernel(sel)
+    plan.set_timing(True)
+    ts = []
+    for i in range(reps + 3):
+        plan.run_device(d.data_ptr(), COLS, 127, s.cuda_stream, None, None, vs.data_ptr(), hs.data_ptr(), best.data_ptr())
+        ms = plan.last_kernel_ms()
+        if i >= 3:
+            ts.append(ms)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(reps):
+        plan.run_device(d.data_ptr(), COLS, 127, s.cuda_stream, None, None, vs.data_ptr(), hs.data_ptr(), best.data_ptr())
+    s.synchronize()
+    wall = (time.perf_counter() - t0) / reps * 1e3
+    r = (vs.cpu().numpy().copy(), hs.cpu().numpy().copy(), int(best.item()))
+    if ref is None:
+        ref = r
+    same = bool((r[0].view(np.uint64) == ref[0].view(np.uint64)).all() and (r[1].view(np.uint64) == ref[1].view(np.uint64)).all() and r[2] == ref[2])
+    ts = np.array(ts)
+    gbps = A * ROWS * COLS / (np.median(ts) * 1e-3) / 1e9
+    print("%-8s sweep kernel median %.3f ms (min %.3f)  -> %.0f GB/s algorithmic (%.3f of 8 TB/s); whole scan wall %.3f ms; best %d angle %.2f (inj %.2f) same=%s"
+          % (name, np.median(ts), ts.min(), gbps, gbps / 8000, wall, r[2], (r[2] - 200) * 0.05, th, same))
+    plan.close()
