@@ -133,9 +133,14 @@ int omr_sweep_plan_run(omr_sweep_plan *plan, const omr_image *img_u8c1, int32_t 
 int omr_sweep_plan_last_kernel_ms(omr_sweep_plan *plan, float *ms_out);
 /* Toggle event recording around the sweep kernel (off by default). */
 int omr_sweep_plan_set_timing(omr_sweep_plan *plan, int32_t enabled);
-/* Select the sweep kernel: 0 = automatic, 1 = generic global-memory kernel, 2 = LDS-staged
- * kernel (fails with -5 when a candidate's source footprint does not fit). For tests. */
+/* Select the sweep kernel: 0 = automatic (run-merging kernel for every candidate that qualifies,
+ * LDS-staged or generic gather kernel for the rest), 1 = generic gather kernel for all, 2 = LDS-staged
+ * gather kernel for all (fails with -5 when a candidate's source footprint does not fit), 3 = as 0 but
+ * fails with -5 when no candidate qualifies for the run-merging kernel.  For tests and profiling. */
 int omr_sweep_plan_set_kernel(omr_sweep_plan *plan, int32_t which);
+/* How the plan splits its candidates: *n_runs are swept by the run-merging kernel (small-angle
+ * rotations), *n_gather by the per-sample gather kernels.  Either pointer may be NULL. */
+int omr_sweep_plan_info(const omr_sweep_plan *plan, int32_t *n_runs, int32_t *n_gather);
 /* Debug/parity hook: copy the fixed-point tables of candidate `a` to host
  * (adelta, bdelta: cols ints; X0, Y0: rows ints) -- OpenCV hal::warpAffine's tables. */
 int omr_sweep_plan_tables(omr_sweep_plan *plan, int32_t a, int32_t *adelta, int32_t *bdelta,

@@ -6,6 +6,7 @@
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "../../include/omrdeskew.h"
@@ -146,7 +147,7 @@ int SweepTables::create(int rows, int cols, const double *fwd_M, int A, int dev)
     dims.rows = rows;
     dims.cols = cols;
     dims.A = A;
-    dims.wpr = (cols + 31) / 32;
+    dims.wpr = ((cols + 31) / 32 + 3) & ~3;  // rows are 16-byte multiples (aligned 4-word loads)
 
     host_minv.resize((size_t)A * 6);
     std::vector<LdsTile> ht((size_t)A);
@@ -175,11 +176,109 @@ int SweepTables::create(int rows, int cols, const double *fwd_M, int A, int dev)
     int32_t h_ovf = 0;
     OMR_HIP(hipMemcpy(&h_ovf, ovf.p, sizeof h_ovf, hipMemcpyDeviceToHost));
     if (h_ovf) return fail(OMR_ERR_BADARG, "affine map leaves the 32-bit fixed-point range of warpAffine");
+    return build_runs();
+}
+
+// Run tables for both passes, then a dry run of the pass kernels on an all-white scan: window
+// geometry does not depend on the pixels, so a candidate whose windows fit once always fits.
+int SweepTables::build_runs()
+{
+    const int rows = dims.rows, cols = dims.cols, A = dims.A;
+    runs_built = false;
+    n_runs = 0;
+    n_gather = A;
+    host_mode.assign((size_t)A, 0);
+    NWh = (cols + 31) / 32;
+    NWv = (rows + 31) / 32;
+    Gh = (NWh + 7) / 8;
+    Gv = (NWv + 7) / 8;
+    wprT = (NWv + 3) & ~3;
+    const size_t tab_bytes = (size_t)A * (size_t)(NWh + NWv) * sizeof(RunTab);
+    const char *off = getenv("OMR_DISABLE_RUNS");
+    if ((off && off[0] == '1') || tab_bytes > ((size_t)3 << 30)) return OMR_OK;  // gather kernels only
+    OMR_HIP(rtv.alloc(sizeof(int2_t) * (size_t)A * cols));
+    OMR_HIP(cav.alloc(sizeof(int32_t) * (size_t)A * rows));
+    OMR_HIP(cbv.alloc(sizeof(int32_t) * (size_t)A * rows));
+    OMR_HIP(tabsH.alloc(sizeof(RunTab) * (size_t)A * NWh));
+    OMR_HIP(tabsV.alloc(sizeof(RunTab) * (size_t)A * NWv));
+    OMR_HIP(metaH.alloc(sizeof(RunMeta) * (size_t)A * NWh));
+    OMR_HIP(metaV.alloc(sizeof(RunMeta) * (size_t)A * NWv));
+    OMR_HIP(mode.alloc(sizeof(int32_t) * (size_t)A));
+    OMR_HIP(list_runs.alloc(sizeof(int32_t) * (size_t)A));
+    OMR_HIP(list_gather.alloc(sizeof(int32_t) * (size_t)A));
+    OMR_HIP(hipMemset(tabsH.p, 0, tabsH.bytes));
+    OMR_HIP(hipMemset(tabsV.p, 0, tabsV.bytes));
+    OMR_HIP(launch_vtables(dims, adelta.as<int32_t>(), bdelta.as<int32_t>(), xy0.as<int2_t>(), rtv.as<int2_t>(),
+                           cav.as<int32_t>(), cbv.as<int32_t>(), nullptr));
+    OMR_HIP(launch_runtab(adelta.as<int32_t>(), bdelta.as<int32_t>(), A, cols, NWh, tabsH.as<RunTab>(),
+                          metaH.as<RunMeta>(), nullptr));
+    OMR_HIP(launch_runtab(cav.as<int32_t>(), cbv.as<int32_t>(), A, rows, NWv, tabsV.as<RunTab>(), metaV.as<RunMeta>(),
+                          nullptr));
+    // dry run
+    DevBuf z0, z1, hp, vp, gd, all;
+    OMR_HIP(z0.alloc(sizeof(uint32_t) * (size_t)rows * dims.wpr));
+    OMR_HIP(z1.alloc(sizeof(uint32_t) * (size_t)cols * wprT));
+    OMR_HIP(hp.alloc(sizeof(uint16_t) * (size_t)A * Gh * rows));
+    OMR_HIP(vp.alloc(sizeof(uint16_t) * (size_t)A * Gv * cols));
+    OMR_HIP(gd.alloc(sizeof(int32_t) * (size_t)A));
+    OMR_HIP(all.alloc(sizeof(int32_t) * (size_t)A));
+    OMR_HIP(hipMemset(z0.p, 0, z0.bytes));
+    OMR_HIP(hipMemset(z1.p, 0, z1.bytes));
+    OMR_HIP(hipMemset(gd.p, 0, gd.bytes));
+    std::vector<int32_t> idx((size_t)A);
+    for (int a = 0; a < A; a++) idx[a] = a;
+    OMR_HIP(hipMemcpy(all.p, idx.data(), sizeof(int32_t) * (size_t)A, hipMemcpyHostToDevice));
+    RunPass ph{z0.as<uint32_t>(), rows, dims.wpr, xy0.as<int2_t>(), adelta.as<int32_t>(), bdelta.as<int32_t>(),
+               rows, cols, NWh, tabsH.as<RunTab>(), metaH.as<RunMeta>(), hp.as<uint16_t>(), Gh, 0};
+    RunPass pv{z1.as<uint32_t>(), cols, wprT, rtv.as<int2_t>(), cav.as<int32_t>(), cbv.as<int32_t>(),
+               cols, rows, NWv, tabsV.as<RunTab>(), metaV.as<RunMeta>(), vp.as<uint16_t>(), Gv, 0};
+    OMR_HIP(launch_runs(ph, all.as<int32_t>(), A, gd.as<int32_t>(), nullptr));
+    OMR_HIP(launch_runs(pv, all.as<int32_t>(), A, gd.as<int32_t>(), nullptr));
+    std::vector<int32_t> g((size_t)A);
+    std::vector<RunMeta> mh((size_t)A * NWh), mv((size_t)A * NWv);
+    OMR_HIP(hipMemcpy(g.data(), gd.p, sizeof(int32_t) * (size_t)A, hipMemcpyDeviceToHost));
+    OMR_HIP(hipMemcpy(mh.data(), metaH.p, sizeof(RunMeta) * mh.size(), hipMemcpyDeviceToHost));
+    OMR_HIP(hipMemcpy(mv.data(), metaV.p, sizeof(RunMeta) * mv.size(), hipMemcpyDeviceToHost));
+    if (getenv("OMR_DEBUG")) {
+        int ng = 0, nh = 0, nv = 0;
+        for (int a = 0; a < A; a++) {
+            ng += g[a] != 0;
+            bool bh = false, bv = false;
+            for (int w = 0; w < NWh; w++) bh |= mh[(size_t)a * NWh + w].ok == 0;
+            for (int w = 0; w < NWv; w++) bv |= mv[(size_t)a * NWv + w].ok == 0;
+            nh += bh;
+            nv += bv;
+        }
+        const RunMeta &m0 = mh[0], &m1 = mv[0];
+        fprintf(stderr, "[omr] runs: A=%d guard-fail=%d metaH-bad=%d metaV-bad=%d | H[0,0]: nlev=%d smax=%d ok=%d cb0=%d ca0=%d | V[0,0]: nlev=%d smax=%d ok=%d\n",
+                A, ng, nh, nv, m0.nlev, m0.smax, m0.ok, m0.cb0, m0.ca0, m1.nlev, m1.smax, m1.ok);
+    }
+    std::vector<int32_t> lr, lg;
+    for (int a = 0; a < A; a++) {
+        bool ok = g[a] == 0;
+        for (int w = 0; ok && w < NWh; w++) ok = mh[(size_t)a * NWh + w].ok != 0;
+        for (int w = 0; ok && w < NWv; w++) ok = mv[(size_t)a * NWv + w].ok != 0;
+        host_mode[a] = ok ? 1 : 0;
+        (ok ? lr : lg).push_back(a);
+    }
+    n_runs = (int)lr.size();
+    n_gather = (int)lg.size();
+    OMR_HIP(hipMemcpy(mode.p, host_mode.data(), sizeof(int32_t) * (size_t)A, hipMemcpyHostToDevice));
+    if (n_runs) OMR_HIP(hipMemcpy(list_runs.p, lr.data(), sizeof(int32_t) * lr.size(), hipMemcpyHostToDevice));
+    if (n_gather) OMR_HIP(hipMemcpy(list_gather.p, lg.data(), sizeof(int32_t) * lg.size(), hipMemcpyHostToDevice));
+    runs_built = true;
     return OMR_OK;
 }
 
-int SweepScratch::create(const SweepDims &d)
+int SweepScratch::create(const SweepTables &t)
 {
+    const SweepDims &d = t.dims;
+    if (t.runs_built && t.n_runs > 0) {
+        OMR_HIP(bitsT.alloc(sizeof(uint32_t) * (size_t)d.cols * t.wprT));
+        OMR_HIP(hpart.alloc(sizeof(uint16_t) * (size_t)d.A * t.Gh * d.rows));
+        OMR_HIP(vpart.alloc(sizeof(uint16_t) * (size_t)d.A * t.Gv * d.cols));
+        OMR_HIP(guard.alloc(sizeof(int32_t) * (size_t)d.A));
+    }
     OMR_HIP(bits.alloc(sizeof(uint32_t) * (size_t)d.rows * d.wpr));
     OMR_HIP(vproj.alloc(sizeof(uint32_t) * (size_t)d.A * d.cols));
     OMR_HIP(hproj.alloc(sizeof(uint32_t) * (size_t)d.A * d.rows));
@@ -191,35 +290,68 @@ int SweepScratch::create(const SweepDims &d)
 
 int enqueue_sweep(const SweepTables &t, SweepScratch &s, int kernel_sel, const uint8_t *d_img, int64_t step,
                   int black_max, hipStream_t stream, uint32_t *d_vproj, uint32_t *d_hproj, double *d_v_sd,
-                  double *d_h_sd, int32_t *d_best, hipEvent_t ev0, hipEvent_t ev1)
+                  double *d_h_sd, int32_t *d_best, hipEvent_t ev0, hipEvent_t ev1, bool want_proj)
 {
     const SweepDims &d = t.dims;
     if (!d_img) return fail(OMR_ERR_BADARG, "null image");
     if (step < d.cols) return fail(OMR_ERR_BADARG, "step_bytes %lld < cols %d", (long long)step, d.cols);
-    bool use_lds;
-    if (kernel_sel == KERNEL_GENERIC) use_lds = false;
+    // which kernels sweep which candidates
+    bool use_runs = false, gather_lds = t.lds_ok;
+    const int32_t *glist = nullptr;  // nullptr = every candidate
+    int n_g = d.A;
+    if (kernel_sel == KERNEL_GENERIC) gather_lds = false;
     else if (kernel_sel == KERNEL_LDS) {
         if (!t.lds_ok) return fail(OMR_ERR_BADARG, "a candidate's source window does not fit the LDS slab");
-        use_lds = true;
-    } else use_lds = t.lds_ok;
+    } else {
+        use_runs = t.runs_built && t.n_runs > 0 && s.bitsT.p != nullptr;
+        if (kernel_sel == KERNEL_RUNS && !use_runs)
+            return fail(OMR_ERR_BADARG, "no candidate of this plan qualifies for the run-merging kernel");
+        if (use_runs) {
+            glist = t.list_gather.as<int32_t>();
+            n_g = t.n_gather;
+        }
+    }
+    want_proj = want_proj || d_vproj || d_hproj;
 
     // integer projections accumulate with atomics: the caller's buffers double as accumulators
     uint32_t *vp = d_vproj ? d_vproj : s.vproj.as<uint32_t>();
     uint32_t *hp = d_hproj ? d_hproj : s.hproj.as<uint32_t>();
     double *vs = d_v_sd ? d_v_sd : s.vsd.as<double>();
     double *hs = d_h_sd ? d_h_sd : s.hsd.as<double>();
-    OMR_HIP(hipMemsetAsync(vp, 0, sizeof(uint32_t) * (size_t)d.A * d.cols, stream));
-    OMR_HIP(hipMemsetAsync(hp, 0, sizeof(uint32_t) * (size_t)d.A * d.rows, stream));
+    if (n_g > 0 || want_proj) {
+        OMR_HIP(hipMemsetAsync(vp, 0, sizeof(uint32_t) * (size_t)d.A * d.cols, stream));
+        OMR_HIP(hipMemsetAsync(hp, 0, sizeof(uint32_t) * (size_t)d.A * d.rows, stream));
+    }
     OMR_HIP(launch_pack_bits(d_img, step, d.rows, d.cols, black_max, s.bits.as<uint32_t>(), d.wpr, stream));
+    if (use_runs)
+        OMR_HIP(launch_transpose_bits(s.bits.as<uint32_t>(), d.rows, d.cols, d.wpr, s.bitsT.as<uint32_t>(), t.wprT,
+                                      stream));
     if (ev0) OMR_HIP(hipEventRecord(ev0, stream));
-    if (use_lds)
-        OMR_HIP(launch_sweep_lds(s.bits.as<uint32_t>(), d, t.adelta.as<int32_t>(), t.bdelta.as<int32_t>(),
-                                 t.xy0.as<int2_t>(), t.tiles.as<LdsTile>(), t.max_rows_per_tile, vp, hp, stream));
-    else
-        OMR_HIP(launch_sweep_generic(s.bits.as<uint32_t>(), d, t.adelta.as<int32_t>(), t.bdelta.as<int32_t>(),
-                                     t.xy0.as<int2_t>(), vp, hp, stream));
+    if (use_runs) {
+        RunPass ph{s.bits.as<uint32_t>(), d.rows, d.wpr, t.xy0.as<int2_t>(), t.adelta.as<int32_t>(),
+                   t.bdelta.as<int32_t>(), d.rows, d.cols, t.NWh, t.tabsH.as<RunTab>(), t.metaH.as<RunMeta>(),
+                   s.hpart.as<uint16_t>(), t.Gh, 0};
+        RunPass pv{s.bitsT.as<uint32_t>(), d.cols, t.wprT, t.rtv.as<int2_t>(), t.cav.as<int32_t>(),
+                   t.cbv.as<int32_t>(), d.cols, d.rows, t.NWv, t.tabsV.as<RunTab>(), t.metaV.as<RunMeta>(),
+                   s.vpart.as<uint16_t>(), t.Gv, 0};
+        OMR_HIP(launch_runs(ph, t.list_runs.as<int32_t>(), t.n_runs, s.guard.as<int32_t>(), stream));
+        OMR_HIP(launch_runs(pv, t.list_runs.as<int32_t>(), t.n_runs, s.guard.as<int32_t>(), stream));
+    }
+    if (n_g > 0) {
+        if (gather_lds)
+            OMR_HIP(launch_sweep_lds(s.bits.as<uint32_t>(), d, t.adelta.as<int32_t>(), t.bdelta.as<int32_t>(),
+                                     t.xy0.as<int2_t>(), t.tiles.as<LdsTile>(), glist, n_g, vp, hp, stream));
+        else
+            OMR_HIP(launch_sweep_generic(s.bits.as<uint32_t>(), d, t.adelta.as<int32_t>(), t.bdelta.as<int32_t>(),
+                                         t.xy0.as<int2_t>(), glist, n_g, vp, hp, stream));
+    }
     if (ev1) OMR_HIP(hipEventRecord(ev1, stream));
-    OMR_HIP(launch_stddev(vp, hp, d, vs, hs, stream));
+    if (use_runs && want_proj) {
+        OMR_HIP(launch_fold_parts(s.hpart.as<uint16_t>(), t.Gh, d.rows, t.list_runs.as<int32_t>(), t.n_runs, hp, stream));
+        OMR_HIP(launch_fold_parts(s.vpart.as<uint16_t>(), t.Gv, d.cols, t.list_runs.as<int32_t>(), t.n_runs, vp, stream));
+    }
+    OMR_HIP(launch_stddev(vp, hp, d, use_runs ? t.mode.as<int32_t>() : nullptr, s.vpart.as<uint16_t>(), t.Gv,
+                          s.hpart.as<uint16_t>(), t.Gh, vs, hs, stream));
     if (d_best) OMR_HIP(launch_argmax_path1(vs, hs, d.A, d_best, stream));
     return OMR_OK;
 }
@@ -292,7 +424,7 @@ int omr_sweep_plan_create(int32_t rows, int32_t cols, const double *fwd_M, int32
     std::unique_ptr<omr_sweep_plan> p(new omr_sweep_plan);
     int rc = p->tables.create(rows, cols, fwd_M, A, device);
     if (rc) return rc;
-    rc = p->scratch.create(p->tables.dims);
+    rc = p->scratch.create(p->tables);
     if (rc) return rc;
     OMR_HIP(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
     OMR_HIP(hipEventCreate(&p->ev0));
@@ -347,7 +479,8 @@ int omr_sweep_plan_run(omr_sweep_plan *plan, const omr_image *img, int32_t black
     plan->timed = plan->timing;
     int rc = enqueue_sweep(plan->tables, plan->scratch, plan->kernel_sel, plan->img.as<uint8_t>(), d.cols, black_max, s,
                            nullptr, nullptr, nullptr, nullptr, plan->scratch.best.as<int32_t>(),
-                           plan->timing ? plan->ev0 : nullptr, plan->timing ? plan->ev1 : nullptr);
+                           plan->timing ? plan->ev0 : nullptr, plan->timing ? plan->ev1 : nullptr,
+                           vproj != nullptr || hproj != nullptr);
     if (rc) return rc;
     if (vproj)
         OMR_HIP(hipMemcpyAsync(vproj, plan->scratch.vproj.p, sizeof(uint32_t) * (size_t)d.A * d.cols,
@@ -381,10 +514,21 @@ int omr_sweep_plan_last_kernel_ms(omr_sweep_plan *plan, float *ms_out)
 
 int omr_sweep_plan_set_kernel(omr_sweep_plan *plan, int32_t which)
 {
-    if (!plan || which < 0 || which > 2) return fail(OMR_ERR_BADARG, "bad kernel selector");
+    if (!plan || which < 0 || which > 3) return fail(OMR_ERR_BADARG, "bad kernel selector");
+    if (which == KERNEL_RUNS && !(plan->tables.runs_built && plan->tables.n_runs > 0))
+        return fail(OMR_ERR_BADARG, "no candidate of this plan qualifies for the run-merging kernel");
     if (which == KERNEL_LDS && !plan->tables.lds_ok)
         return fail(OMR_ERR_BADARG, "a candidate's source window does not fit the LDS slab");
     plan->kernel_sel = which;
+    return OMR_OK;
+}
+
+int omr_sweep_plan_info(const omr_sweep_plan *plan, int32_t *n_runs, int32_t *n_gather)
+{
+    if (!plan) return fail(OMR_ERR_BADARG, "null plan");
+    const bool runs = plan->tables.runs_built && plan->tables.n_runs > 0;
+    if (n_runs) *n_runs = runs ? plan->tables.n_runs : 0;
+    if (n_gather) *n_gather = runs ? plan->tables.n_gather : plan->tables.dims.A;
     return OMR_OK;
 }
 
@@ -454,7 +598,7 @@ int omr_batch_create(int32_t rows, int32_t cols, uint16_t max_angle, double step
     if (rc) return rc;
     for (int i = 0; i < n_streams; i++) {
         c->scratch.emplace_back(new SweepScratch);
-        rc = c->scratch.back()->create(c->tables.dims);
+        rc = c->scratch.back()->create(c->tables);
         if (rc) return rc;
         hipStream_t s;
         OMR_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));

@@ -53,21 +53,30 @@ struct SweepTables {
     bool lds_ok = false;
     int max_rows_per_tile = 0;
     std::vector<double> host_minv;
+    // run-merging ("S") kernels: transposed-pass tables, per-(candidate, word) run tables, and the
+    // split of the candidates into run-merged ones and ones left to the gather kernels
+    bool runs_built = false;
+    int wprT = 0, NWh = 0, NWv = 0, Gh = 0, Gv = 0;
+    DevBuf rtv, cav, cbv, tabsH, metaH, tabsV, metaV, list_runs, list_gather, mode;
+    int n_runs = 0, n_gather = 0;
+    std::vector<int32_t> host_mode;
     int create(int rows, int cols, const double *fwd_M, int A, int device);
+    int build_runs();
 };
 
 // Mutable per-stream scratch: bit image, integer projections, scores.
 struct SweepScratch {
     DevBuf bits, vproj, hproj, vsd, hsd, best;
-    int create(const SweepDims &d);
+    DevBuf bitsT, hpart, vpart, guard;  // run-merging scratch
+    int create(const SweepTables &t);
 };
 
-enum KernelSel { KERNEL_AUTO = 0, KERNEL_GENERIC = 1, KERNEL_LDS = 2 };
+enum KernelSel { KERNEL_AUTO = 0, KERNEL_GENERIC = 1, KERNEL_LDS = 2, KERNEL_RUNS = 3 };
 
 // Enqueue pack -> sweep -> std-dev -> arg-max for one device-resident scan.
 int enqueue_sweep(const SweepTables &t, SweepScratch &s, int kernel_sel, const uint8_t *d_img, int64_t step,
                   int black_max, hipStream_t stream, uint32_t *d_vproj, uint32_t *d_hproj, double *d_v_sd,
-                  double *d_h_sd, int32_t *d_best, hipEvent_t ev0, hipEvent_t ev1);
+                  double *d_h_sd, int32_t *d_best, hipEvent_t ev0, hipEvent_t ev1, bool want_proj = false);
 
 }  // namespace omr
 

@@ -109,11 +109,11 @@ hipError_t launch_tables(const double *d_Minv, SweepDims d, int round_delta, int
 
 __global__ __launch_bounds__(GEN_WAVES *OMR_WAVE) void sweep_generic_kernel(
     const uint32_t *__restrict__ bits, SweepDims d, const int32_t *__restrict__ adelta,
-    const int32_t *__restrict__ bdelta, const int2_t *__restrict__ xy0, uint32_t *__restrict__ vproj,
-    uint32_t *__restrict__ hproj)
+    const int32_t *__restrict__ bdelta, const int2_t *__restrict__ xy0, const int32_t *__restrict__ list,
+    uint32_t *__restrict__ vproj, uint32_t *__restrict__ hproj)
 {
     __shared__ uint32_t hacc[GEN_BAND];
-    const int a = blockIdx.z;
+    const int a = list ? list[blockIdx.z] : (int)blockIdx.z;
     const int lane = threadIdx.x & 63;
     const int x = blockIdx.x * (GEN_WAVES * OMR_WAVE) + threadIdx.x;
     const int y0 = blockIdx.y * GEN_BAND;
@@ -153,13 +153,14 @@ __global__ __launch_bounds__(GEN_WAVES *OMR_WAVE) void sweep_generic_kernel(
 }
 
 hipError_t launch_sweep_generic(const uint32_t *d_bits, SweepDims d, const int32_t *d_adelta,
-                                const int32_t *d_bdelta, const int2_t *d_xy0, uint32_t *d_vproj, uint32_t *d_hproj,
-                                hipStream_t s)
+                                const int32_t *d_bdelta, const int2_t *d_xy0, const int32_t *d_list, int n_list,
+                                uint32_t *d_vproj, uint32_t *d_hproj, hipStream_t s)
 {
-    if (d.A <= 0) return hipSuccess;
-    dim3 grid((d.cols + GEN_WAVES * OMR_WAVE - 1) / (GEN_WAVES * OMR_WAVE), (d.rows + GEN_BAND - 1) / GEN_BAND, d.A);
+    const int nz = d_list ? n_list : d.A;
+    if (nz <= 0) return hipSuccess;
+    dim3 grid((d.cols + GEN_WAVES * OMR_WAVE - 1) / (GEN_WAVES * OMR_WAVE), (d.rows + GEN_BAND - 1) / GEN_BAND, nz);
     hipLaunchKernelGGL(sweep_generic_kernel, grid, dim3(GEN_WAVES * OMR_WAVE), 0, s, d_bits, d, d_adelta, d_bdelta,
-                       d_xy0, d_vproj, d_hproj);
+                       d_xy0, d_list, d_vproj, d_hproj);
     return hipGetLastError();
 }
 
@@ -176,11 +177,11 @@ hipError_t launch_sweep_generic(const uint32_t *d_bits, SweepDims d, const int32
 __global__ __launch_bounds__(LDS_WAVES *OMR_WAVE) void sweep_lds_kernel(
     const uint32_t *__restrict__ bits, SweepDims d, const int32_t *__restrict__ adelta,
     const int32_t *__restrict__ bdelta, const int2_t *__restrict__ xy0, const LdsTile *__restrict__ tiles,
-    uint32_t *__restrict__ vproj, uint32_t *__restrict__ hproj)
+    const int32_t *__restrict__ list, uint32_t *__restrict__ vproj, uint32_t *__restrict__ hproj)
 {
     __shared__ uint32_t slab_all[LDS_WAVES * LDS_SLAB_WORDS];
     __shared__ uint32_t hacc[LDS_BAND];
-    const int a = blockIdx.z;
+    const int a = list ? list[blockIdx.z] : (int)blockIdx.z;
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     uint32_t *slab = slab_all + wave * LDS_SLAB_WORDS;
@@ -321,14 +322,14 @@ __global__ __launch_bounds__(LDS_WAVES *OMR_WAVE) void sweep_lds_kernel(
 }
 
 hipError_t launch_sweep_lds(const uint32_t *d_bits, SweepDims d, const int32_t *d_adelta, const int32_t *d_bdelta,
-                            const int2_t *d_xy0, const LdsTile *d_tiles, int max_rows_per_tile, uint32_t *d_vproj,
-                            uint32_t *d_hproj, hipStream_t s)
+                            const int2_t *d_xy0, const LdsTile *d_tiles, const int32_t *d_list, int n_list,
+                            uint32_t *d_vproj, uint32_t *d_hproj, hipStream_t s)
 {
-    (void)max_rows_per_tile;
-    if (d.A <= 0) return hipSuccess;
-    dim3 grid((d.cols + LDS_WAVES * OMR_WAVE - 1) / (LDS_WAVES * OMR_WAVE), (d.rows + LDS_BAND - 1) / LDS_BAND, d.A);
+    const int nz = d_list ? n_list : d.A;
+    if (nz <= 0) return hipSuccess;
+    dim3 grid((d.cols + LDS_WAVES * OMR_WAVE - 1) / (LDS_WAVES * OMR_WAVE), (d.rows + LDS_BAND - 1) / LDS_BAND, nz);
     hipLaunchKernelGGL(sweep_lds_kernel, grid, dim3(LDS_WAVES * OMR_WAVE), 0, s, d_bits, d, d_adelta, d_bdelta, d_xy0,
-                       d_tiles, d_vproj, d_hproj);
+                       d_tiles, d_list, d_vproj, d_hproj);
     return hipGetLastError();
 }
 
@@ -346,6 +347,9 @@ hipError_t launch_sweep_lds(const uint32_t *d_bits, SweepDims d, const int32_t *
 
 __global__ __launch_bounds__(SD_THREADS) void stddev_kernel(const uint32_t *__restrict__ vproj,
                                                             const uint32_t *__restrict__ hproj, SweepDims d,
+                                                            const int32_t *__restrict__ mode,
+                                                            const uint16_t *__restrict__ vpart, int Gv,
+                                                            const uint16_t *__restrict__ hpart, int Gh,
                                                             double *__restrict__ v_sd, double *__restrict__ h_sd)
 {
     __shared__ double sq[SD_CHUNK];
@@ -355,9 +359,19 @@ __global__ __launch_bounds__(SD_THREADS) void stddev_kernel(const uint32_t *__re
     const int axis = blockIdx.x & 1;  // 0: vertical projection (per column), 1: horizontal (per row)
     const int n = axis ? d.rows : d.cols;
     const uint32_t *__restrict__ p = axis ? hproj + (int64_t)a * d.rows : vproj + (int64_t)a * d.cols;
+    // run-merged candidates deliver their counts as G partial u16 vectors (exact integers either way)
+    const bool parts = mode && mode[a] != 0;
+    const int G = axis ? Gh : Gv;
+    const uint16_t *__restrict__ q = axis ? hpart + (int64_t)a * Gh * d.rows : vpart + (int64_t)a * Gv * d.cols;
+    auto value = [&](int i) -> uint32_t {
+        if (!parts) return p[i];
+        uint32_t t = 0;
+        for (int g = 0; g < G; g++) t += q[(int64_t)g * n + i];
+        return t;
+    };
 
     unsigned long long s = 0;
-    for (int i = threadIdx.x; i < n; i += SD_THREADS) s += p[i];
+    for (int i = threadIdx.x; i < n; i += SD_THREADS) s += value(i);
     for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
     __syncthreads();
@@ -372,7 +386,7 @@ __global__ __launch_bounds__(SD_THREADS) void stddev_kernel(const uint32_t *__re
     for (int base = 0; base < n; base += SD_CHUNK) {
         const int m = min(SD_CHUNK, n - base);
         for (int i = threadIdx.x; i < m; i += SD_THREADS) {
-            const double dv = (double)p[base + i] - mean;
+            const double dv = (double)value(base + i) - mean;
             sq[i] = dv * dv;
         }
         __syncthreads();
@@ -398,11 +412,13 @@ __global__ __launch_bounds__(SD_THREADS) void stddev_kernel(const uint32_t *__re
     }
 }
 
-hipError_t launch_stddev(const uint32_t *d_vproj, const uint32_t *d_hproj, SweepDims d, double *d_v_sd,
+hipError_t launch_stddev(const uint32_t *d_vproj, const uint32_t *d_hproj, SweepDims d, const int32_t *d_mode,
+                         const uint16_t *d_vpart, int Gv, const uint16_t *d_hpart, int Gh, double *d_v_sd,
                          double *d_h_sd, hipStream_t s)
 {
     if (d.A <= 0) return hipSuccess;
-    hipLaunchKernelGGL(stddev_kernel, dim3(2 * d.A), dim3(SD_THREADS), 0, s, d_vproj, d_hproj, d, d_v_sd, d_h_sd);
+    hipLaunchKernelGGL(stddev_kernel, dim3(2 * d.A), dim3(SD_THREADS), 0, s, d_vproj, d_hproj, d, d_mode, d_vpart, Gv,
+                       d_hpart, Gh, d_v_sd, d_h_sd);
     return hipGetLastError();
 }
 

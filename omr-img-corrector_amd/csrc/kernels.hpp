@@ -37,17 +37,67 @@ hipError_t launch_tables(const double *d_Minv, SweepDims d, int round_delta, int
 // Generic sweep: every (candidate, dst pixel) gathers its source bit from global memory.
 // vproj [A][cols], hproj [A][rows] must be zero on entry (integer atomics).
 hipError_t launch_sweep_generic(const uint32_t *d_bits, SweepDims d, const int32_t *d_adelta,
-                                const int32_t *d_bdelta, const int2_t *d_xy0, uint32_t *d_vproj,
-                                uint32_t *d_hproj, hipStream_t s);
+                                const int32_t *d_bdelta, const int2_t *d_xy0, const int32_t *d_list,
+                                int n_list, uint32_t *d_vproj, uint32_t *d_hproj, hipStream_t s);
 
 // LDS-staged sweep (rotation-like matrices whose per-wave source window fits the LDS budget).
+// d_list (may be NULL = all candidates): the candidates to sweep, n_list of them.
 hipError_t launch_sweep_lds(const uint32_t *d_bits, SweepDims d, const int32_t *d_adelta,
                             const int32_t *d_bdelta, const int2_t *d_xy0, const LdsTile *d_tiles,
-                            int max_rows_per_tile, uint32_t *d_vproj, uint32_t *d_hproj,
+                            const int32_t *d_list, int n_list, uint32_t *d_vproj, uint32_t *d_hproj,
                             hipStream_t s);
 
+// ---- run-merging ("S") sweep ---------------------------------------------------------------
+// One pass counts, for every destination row r of every listed candidate, the black samples
+//     sum_c src[(RT[r].y + CB[c]) >> 10][(RT[r].x + CA[c]) >> 10]
+// 32 destination columns at a time.  Pass H (row counts): RT = (X0,Y0), CA = adelta, CB = bdelta,
+// src = bit image.  Pass V (column counts) is the same sum on the TRANSPOSED bit image with the
+// roles of the tables swapped: RT = (bdelta, adelta), CA = Y0, CB = X0.
+#define OMR_RUN_TUPLES 40
+struct RunTab {                        // per (candidate, 32-column word); 3648 B, 16-B aligned
+    uint32_t tupY[OMR_RUN_TUPLES][8];  // [id][level]: destination bits that read source row level
+    uint32_t tupX[OMR_RUN_TUPLES][2];  // [id][s-1]:   destination bits whose source column lags by s
+    uint8_t idxY[1024];                // row-coordinate fraction -> tupY id
+    uint8_t idxX[1024];                // bit-coordinate fraction -> tupX id
+};
+struct RunMeta {  // per (candidate, word)
+    int32_t ca0;    // CA[c0]
+    int32_t cb0;    // CB[c0] + (base_off << 10)
+    int32_t nlev;   // source rows a word can touch (1..8)
+    int32_t smax;   // largest column lag (0..2)
+    uint32_t valid; // destination bits that exist (last word of a row)
+    int32_t ok;     // 0: this word cannot be run-merged (candidate falls back to the gather kernel)
+    int32_t pad0, pad1;
+};
+struct RunPass {  // one orientation
+    const uint32_t *src;  // bit image of this orientation
+    int32_t src_rows, src_wpr;
+    const int2_t *RT;     // [A][NR]
+    const int32_t *CA;    // [A][NC]
+    const int32_t *CB;    // [A][NC]
+    int32_t NR, NC, NW;   // NW = ceil(NC / 32)
+    const RunTab *tabs;   // [A][NW]
+    const RunMeta *meta;  // [A][NW]
+    uint16_t *part;       // [A][G][NR] partial counts, G = ceil(NW / 8)
+    int32_t G;
+    int32_t dbg;          // development switches (0 in production)
+};
+hipError_t launch_transpose_bits(const uint32_t *d_bits, int rows, int cols, int wpr, uint32_t *d_bitsT, int wprT,
+                                 hipStream_t s);
+hipError_t launch_vtables(SweepDims d, const int32_t *d_adelta, const int32_t *d_bdelta, const int2_t *d_xy0,
+                          int2_t *d_rtv, int32_t *d_cav, int32_t *d_cbv, hipStream_t s);
+hipError_t launch_runtab(const int32_t *d_CA, const int32_t *d_CB, int A, int NC, int NW, RunTab *d_tabs,
+                         RunMeta *d_meta, hipStream_t s);
+// d_list: n_list candidate indices; d_guard[a] != 0 when a window did not fit for candidate a.
+hipError_t launch_runs(const RunPass &p, const int32_t *d_list, int n_list, int32_t *d_guard, hipStream_t s);
+// vproj/hproj (u32) += partial counts of the listed candidates (only when the caller wants them)
+hipError_t launch_fold_parts(const uint16_t *d_part, int G, int NR, const int32_t *d_list, int n_list,
+                             uint32_t *d_proj, hipStream_t s);
+
 // calculate.rs:13-23 on the integer projections: one block per (candidate, axis).
+// d_mode (may be NULL): per candidate, != 0 -> read the run-merging partials instead of vproj/hproj.
 hipError_t launch_stddev(const uint32_t *d_vproj, const uint32_t *d_hproj, SweepDims d,
+                         const int32_t *d_mode, const uint16_t *d_vpart, int Gv, const uint16_t *d_hpart, int Gh,
                          double *d_v_sd, double *d_h_sd, hipStream_t s);
 
 // projection.rs:125-190 arg-max (lowest index on exact ties).

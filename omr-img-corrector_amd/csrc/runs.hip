@@ -1,0 +1,516 @@
+// runs.hip -- the run-merging ("S") sweep kernels for gfx950.
+//
+// Why: the gather kernels (kernels.hip) spend ~12 VALU operations per destination sample and are
+// VALU-issue bound (profiles/r01_pmc_sweep.md).  For the small angles of a deskew sweep a
+// destination row is a sequence of RUNS of consecutive source bits: the source row changes every
+// 1/|sin t| pixels and the source column stutters every 1/(1-cos t) pixels.  This kernel builds 32
+// destination pixels at once:
+//     bit i of word (r, w) = src[Rb + gy(i)][Xb + i - st(i)],
+//     gy(i) = (fy + cb(i)) >> 10,  st(i) = -((fx - ea(i)) >> 10),   ea(i) = 1024 i - ca(i)
+// where (Xb, fx) / (Rb, fy) are the integer / 10-bit fraction parts of the word's first sample and
+// ca, cb are the column tables relative to the word start.  gy and st depend only on
+// (candidate, word, fraction): the plan ENUMERATES all 1024 fractions per (candidate, word) from the
+// integer tables of OpenCV's warpAffine (no threshold arithmetic, so bit-exact by construction) and
+// stores the <= 33 distinct mask tuples (RunTab).  Per word the kernel then needs two byte look-ups,
+// one 32-bit unaligned window per source row (LDS, ds_read2 + v_alignbit), and one and/or per row.
+// Row counts come from this pass on the bit image, column counts from the SAME pass on the
+// transposed bit image with the tables' roles swapped -- no cross-lane reduction anywhere.
+#include <hip/hip_runtime.h>
+#include <stdlib.h>
+
+#include "kernels.hpp"
+
+namespace omr {
+
+#define RUN_K 8            // destination words per block column group
+#define RUN_BAND 512       // destination rows per band (8 waves x 64 lanes)
+#define RUN_PITCH 21       // window row pitch in words (20 data words + 1 spill word), odd
+#define RUN_PITCHB (RUN_PITCH * 4)
+#define RUN_WIN_ROWS 576
+#define RUN_TAB_BYTES 3648
+#define RUN_TUPX_OFS 1280
+#define RUN_IDXY_OFS 1600
+#define RUN_IDXX_OFS 2624
+#define RUN_META_OFS (RUN_K * RUN_TAB_BYTES)  // RUN_K x (ca0, cb0)
+#define RUN_WIN_OFS (RUN_META_OFS + RUN_K * 8)
+#define RUN_LDS_BYTES (RUN_WIN_OFS + RUN_WIN_ROWS * RUN_PITCHB)
+
+static_assert(sizeof(RunTab) == RUN_TAB_BYTES, "RunTab layout");
+static_assert(sizeof(RunMeta) == 32, "RunMeta layout");
+
+// ------------------------------------------------------------------------------------------
+// bit-matrix transpose: bitsT[x][y] = bits[y][x].  One wave = 64 source rows x 32 columns.
+__global__ __launch_bounds__(256) void transpose_bits_kernel(const uint32_t *__restrict__ bits, int rows, int cols,
+                                                             int wpr, uint32_t *__restrict__ bitsT, int wprT)
+{
+    const int lane = threadIdx.x & 63;
+    const int w = blockIdx.x;                                   // source word column
+    const int y0 = (blockIdx.y * 4 + (threadIdx.x >> 6)) * 64;  // first source row of this wave
+    if (y0 >= wprT * 32) return;
+    const int y = y0 + lane;
+    const uint32_t word = (y < rows) ? bits[(int64_t)y * wpr + w] : 0u;
+    unsigned long long mine = 0;
+#pragma unroll
+    for (int c = 0; c < 32; c++) {
+        const unsigned long long m = __ballot((word >> c) & 1u);
+        if (lane == c) mine = m;
+    }
+    const int x = w * 32 + lane;
+    if (lane < 32 && x < cols) {
+        const int wy = y0 >> 5;
+        uint32_t *o = bitsT + (int64_t)x * wprT + wy;
+        if (wy < wprT) o[0] = (uint32_t)mine;
+        if (wy + 1 < wprT) o[1] = (uint32_t)(mine >> 32);
+    }
+}
+
+hipError_t launch_transpose_bits(const uint32_t *d_bits, int rows, int cols, int wpr, uint32_t *d_bitsT, int wprT,
+                                 hipStream_t s)
+{
+    dim3 grid((cols + 31) / 32, (wprT * 32 + 255) / 256);
+    hipLaunchKernelGGL(transpose_bits_kernel, grid, dim3(256), 0, s, d_bits, rows, cols, wpr, d_bitsT, wprT);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// Tables of the transposed pass: RT_V[x] = (bdelta[x], adelta[x]), CA_V[y] = Y0[y], CB_V[y] = X0[y].
+__global__ __launch_bounds__(256) void vtables_kernel(SweepDims d, const int32_t *__restrict__ adelta,
+                                                      const int32_t *__restrict__ bdelta,
+                                                      const int2_t *__restrict__ xy0, int2_t *__restrict__ rtv,
+                                                      int32_t *__restrict__ cav, int32_t *__restrict__ cbv)
+{
+    const int a = blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < d.cols) {
+        int2_t v;
+        v.x = bdelta[(int64_t)a * d.cols + i];
+        v.y = adelta[(int64_t)a * d.cols + i];
+        rtv[(int64_t)a * d.cols + i] = v;
+    } else if (i - d.cols < d.rows) {
+        const int y = i - d.cols;
+        const int2_t s0 = xy0[(int64_t)a * d.rows + y];
+        cav[(int64_t)a * d.rows + y] = s0.y;
+        cbv[(int64_t)a * d.rows + y] = s0.x;
+    }
+}
+
+hipError_t launch_vtables(SweepDims d, const int32_t *d_adelta, const int32_t *d_bdelta, const int2_t *d_xy0,
+                          int2_t *d_rtv, int32_t *d_cav, int32_t *d_cbv, hipStream_t s)
+{
+    dim3 grid((d.cols + d.rows + 255) / 256, d.A);
+    hipLaunchKernelGGL(vtables_kernel, grid, dim3(256), 0, s, d, d_adelta, d_bdelta, d_xy0, d_rtv, d_cav, d_cbv);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// RunTab builder: block = one (candidate, word), thread = one 10-bit fraction f.
+__device__ __forceinline__ int block_dedupe_1024(bool change, int *s_wave)
+{
+    // exclusive count of `change` flags before this thread, over a 1024-thread block
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned long long m = __ballot(change);
+    const int before = __popcll(m & ((1ull << lane) - 1ull));
+    __syncthreads();
+    if (lane == 0) s_wave[wave] = __popcll(m);
+    __syncthreads();
+    int base = 0;
+    for (int k = 0; k < wave; k++) base += s_wave[k];
+    return base + before;
+}
+
+__global__ __launch_bounds__(1024) void runtab_kernel(const int32_t *__restrict__ CA, const int32_t *__restrict__ CB,
+                                                      int NC, int NW, RunTab *__restrict__ tabs,
+                                                      RunMeta *__restrict__ meta)
+{
+    __shared__ int s_ca[32], s_cb[32];
+    __shared__ uint32_t s_tup[1024][9];  // padded: conflict-free row compare
+    __shared__ int s_wave[16];
+    __shared__ int s_bad, s_smax;
+    const int w = blockIdx.x, a = blockIdx.y, c0 = w * 32, f = threadIdx.x;
+    const int32_t *ca_row = CA + (int64_t)a * NC, *cb_row = CB + (int64_t)a * NC;
+    if (f < 32) {
+        // columns past the end of the row (last word only) are don't-cares: the pass kernel masks
+        // them with RunMeta::valid.  Give them lag 0 and the row of the last real column so they add
+        // neither a level nor a validity failure.
+        const int c = min(c0 + f, NC - 1);
+        s_ca[f] = (c0 + f < NC) ? ca_row[c] - ca_row[c0] : 1024 * f;
+        s_cb[f] = cb_row[c] - cb_row[c0];
+    }
+    if (f == 0) {
+        s_bad = 0;
+        s_smax = 0;
+    }
+    __syncthreads();
+    int cbmin = 0, cbmax = 0;
+#pragma unroll
+    for (int i = 0; i < 32; i++) {
+        cbmin = min(cbmin, s_cb[i]);
+        cbmax = max(cbmax, s_cb[i]);
+    }
+    bool bad = false;
+    int base_off = 0, nlev = 1;
+    if (cbmin >= 0) {
+        nlev = ((1023 + cbmax) >> 10) + 1;
+    } else if (cbmax <= 0) {
+        base_off = cbmin >> 10;  // floor: the lowest level any fraction can reach
+        nlev = 1 - base_off;
+    } else {
+        bad = true;
+    }
+    if (nlev > 8) {
+        bad = true;
+        nlev = 8;
+    }
+    // ---- row-level masks of this fraction
+    uint32_t my[8];
+#pragma unroll
+    for (int lv = 0; lv < 8; lv++) my[lv] = 0;
+#pragma unroll
+    for (int i = 0; i < 32; i++) {
+        const int lv = ((f + s_cb[i]) >> 10) - base_off;
+        if (lv < 0 || lv > 7) bad = true;
+#pragma unroll
+        for (int k = 0; k < 8; k++) my[k] |= (lv == k ? 1u : 0u) << i;
+    }
+#pragma unroll
+    for (int lv = 0; lv < 8; lv++) s_tup[f][lv] = my[lv];
+    __syncthreads();
+    bool change = f == 0;
+    if (f > 0) {
+#pragma unroll
+        for (int lv = 0; lv < 8; lv++) change |= s_tup[f - 1][lv] != my[lv];
+    }
+    int idy = block_dedupe_1024(change, s_wave) + (change ? 1 : 0) - 1;  // inclusive count - 1
+    RunTab *T = tabs + ((int64_t)a * NW + w);
+    if (idy >= OMR_RUN_TUPLES) {
+        bad = true;
+        idy = 0;
+    } else if (change) {
+#pragma unroll
+        for (int lv = 0; lv < 8; lv++) T->tupY[idy][lv] = my[lv];
+    }
+    T->idxY[f] = (uint8_t)idy;
+    // ---- column-lag masks of this fraction: st(i) = -((f - ea(i)) >> 10), ea(i) = 1024 i - ca(i)
+    uint32_t sx1 = 0, sx2 = 0;
+    int smax = 0;
+#pragma unroll
+    for (int i = 0; i < 32; i++) {
+        const int ea = 1024 * i - s_ca[i];
+        const int st = -((f - ea) >> 10);
+        if (st < 0 || st > 2 || st > i) bad = true;
+        sx1 |= (st == 1 ? 1u : 0u) << i;
+        sx2 |= (st == 2 ? 1u : 0u) << i;
+        smax = max(smax, st);
+    }
+    __syncthreads();
+    s_tup[f][0] = sx1;
+    s_tup[f][1] = sx2;
+    __syncthreads();
+    change = f == 0 || s_tup[f - 1][0] != sx1 || s_tup[f - 1][1] != sx2;
+    int idx = block_dedupe_1024(change, s_wave) + (change ? 1 : 0) - 1;
+    if (idx >= OMR_RUN_TUPLES) {
+        bad = true;
+        idx = 0;
+    } else if (change) {
+        T->tupX[idx][0] = sx1;
+        T->tupX[idx][1] = sx2;
+    }
+    T->idxX[f] = (uint8_t)idx;
+    if (bad) s_bad = 1;
+    if (smax > 0) atomicMax(&s_smax, min(smax, 2));
+    __syncthreads();
+    if (f == 0) {
+        RunMeta m;
+        m.ca0 = ca_row[c0];
+        m.cb0 = cb_row[c0] + base_off * 1024;
+        m.nlev = nlev;
+        m.smax = s_smax;
+        m.valid = (c0 + 32 <= NC) ? 0xffffffffu : ((1u << (NC - c0)) - 1u);
+        m.ok = s_bad ? 0 : 1;
+        m.pad0 = m.pad1 = 0;
+        meta[(int64_t)a * NW + w] = m;
+    }
+}
+
+hipError_t launch_runtab(const int32_t *d_CA, const int32_t *d_CB, int A, int NC, int NW, RunTab *d_tabs,
+                         RunMeta *d_meta, hipStream_t s)
+{
+    hipLaunchKernelGGL(runtab_kernel, dim3(NW, A), dim3(1024), 0, s, d_CA, d_CB, NC, NW, d_tabs, d_meta);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// The pass kernel.  Block = (candidate, group of RUN_K words); it walks all destination rows in
+// bands of 512 (8 waves x 64 lanes, lane = destination row).
+__device__ __forceinline__ uint32_t lds_u8(const char *lds, int ofs) { return *(const uint8_t *)(lds + ofs); }
+
+// The words of one band for one wave (lane = destination row).  NLEV / SMAX are uniform for the
+// whole block (maxima over its words; unused levels have empty masks), so the block dispatches
+// once per band to a straight-line specialisation.  Two words are in flight together: both
+// fraction look-ups and all 2 x NLEV window reads are issued before anything is consumed, which is
+// what hides the LDS latency at 4 waves per SIMD.
+template <int NLEV, int SMAX>
+__device__ __forceinline__ uint32_t merge_word(const uint32_t *d0, const uint32_t *d1, const uint32_t sh,
+                                               const uint4 s03, const uint4 s47, const uint2 sx)
+{
+    const uint32_t sel[8] = {s03.x, s03.y, s03.z, s03.w, s47.x, s47.y, s47.z, s47.w};
+    uint32_t D = 0;
+#pragma unroll
+    for (int lv = 0; lv < NLEV; lv++) {
+        const uint32_t W = __builtin_amdgcn_alignbit(d1[lv], d0[lv], sh);
+        uint32_t U = W;
+        if (SMAX >= 1) U = (sx.x & (W << 1)) | (~sx.x & U);
+        if (SMAX >= 2) U = (sx.y & (W << 2)) | (~sx.y & U);
+        D = lv == 0 ? (U & sel[0]) : (D | (U & sel[lv]));
+    }
+    return D;
+}
+
+template <int NLEV, int SMAX>
+__device__ __forceinline__ uint32_t band_words(const char *lds, const int kw, const int rx, const int ry,
+                                               const uint32_t valid_last)
+{
+    uint32_t cnt = 0;
+#pragma unroll 1
+    for (int k = 0; k < kw; k += 2) {
+        const int ka = k, kb = min(k + 1, kw - 1);  // odd tail: word b repeats word a and is dropped
+        const int2 ma = *(const int2 *)(lds + RUN_META_OFS + ka * 8);  // same address in every lane
+        const int2 mb = *(const int2 *)(lds + RUN_META_OFS + kb * 8);
+        const int ta = ka * RUN_TAB_BYTES, tb = kb * RUN_TAB_BYTES;
+        const int A0a = rx + ma.x, B0a = ry + ma.y, A0b = rx + mb.x, B0b = ry + mb.y;
+        const uint32_t idya = lds_u8(lds, ta + RUN_IDXY_OFS + (B0a & 1023));
+        const uint32_t idyb = lds_u8(lds, tb + RUN_IDXY_OFS + (B0b & 1023));
+        uint32_t idxa = 0, idxb = 0;
+        if (SMAX > 0) {
+            idxa = lds_u8(lds, ta + RUN_IDXX_OFS + (A0a & 1023));
+            idxb = lds_u8(lds, tb + RUN_IDXX_OFS + (A0b & 1023));
+        }
+        const int addra = RUN_WIN_OFS + __mul24(B0a >> 10, RUN_PITCHB) + ((A0a >> 13) & ~3);
+        const int addrb = RUN_WIN_OFS + __mul24(B0b >> 10, RUN_PITCHB) + ((A0b >> 13) & ~3);
+        uint32_t a0[NLEV], a1[NLEV], b0[NLEV], b1[NLEV];
+#pragma unroll
+        for (int lv = 0; lv < NLEV; lv++) {
+            a0[lv] = *(const uint32_t *)(lds + addra + lv * RUN_PITCHB);
+            a1[lv] = *(const uint32_t *)(lds + addra + lv * RUN_PITCHB + 4);
+        }
+#pragma unroll
+        for (int lv = 0; lv < NLEV; lv++) {
+            b0[lv] = *(const uint32_t *)(lds + addrb + lv * RUN_PITCHB);
+            b1[lv] = *(const uint32_t *)(lds + addrb + lv * RUN_PITCHB + 4);
+        }
+        const uint4 *tya = (const uint4 *)(lds + ta + (idya << 5));
+        const uint4 *tyb = (const uint4 *)(lds + tb + (idyb << 5));
+        const uint4 z4 = make_uint4(0, 0, 0, 0);
+        const uint4 sa03 = tya[0], sa47 = NLEV > 4 ? tya[1] : z4;
+        const uint4 sb03 = tyb[0], sb47 = NLEV > 4 ? tyb[1] : z4;
+        uint2 sxa = make_uint2(0, 0), sxb = make_uint2(0, 0);
+        if (SMAX > 0) {
+            sxa = *(const uint2 *)(lds + ta + RUN_TUPX_OFS + (idxa << 3));
+            sxb = *(const uint2 *)(lds + tb + RUN_TUPX_OFS + (idxb << 3));
+        }
+        uint32_t Da = merge_word<NLEV, SMAX>(a0, a1, (uint32_t)(A0a >> 10), sa03, sa47, sxa);
+        uint32_t Db = merge_word<NLEV, SMAX>(b0, b1, (uint32_t)(A0b >> 10), sb03, sb47, sxb);
+        if (ka == kw - 1) Da &= valid_last;
+        if (kb == kw - 1) Db &= valid_last;
+        cnt += __popc(Da);
+        if (kb != ka) cnt += __popc(Db);
+    }
+    return cnt;
+}
+
+template <int SMAX>
+__device__ __forceinline__ uint32_t band_words_s(const char *lds, const int kw, const int rx, const int ry,
+                                                 const uint32_t valid_last, const int nlev)
+{
+    switch (nlev) {
+    case 1: return band_words<1, SMAX>(lds, kw, rx, ry, valid_last);
+    case 2: return band_words<2, SMAX>(lds, kw, rx, ry, valid_last);
+    case 3: return band_words<3, SMAX>(lds, kw, rx, ry, valid_last);
+    case 4: return band_words<4, SMAX>(lds, kw, rx, ry, valid_last);
+    case 5: return band_words<5, SMAX>(lds, kw, rx, ry, valid_last);
+    case 6: return band_words<6, SMAX>(lds, kw, rx, ry, valid_last);
+    case 7: return band_words<7, SMAX>(lds, kw, rx, ry, valid_last);
+    default: return band_words<8, SMAX>(lds, kw, rx, ry, valid_last);
+    }
+}
+
+struct RunGeom {  // source window of one band (wave-uniform)
+    int wxw, wy0, nrows;
+    bool fits;
+};
+
+__global__ __launch_bounds__(RUN_BAND) void runs_kernel(RunPass p, const int32_t *__restrict__ list,
+                                                        int32_t *__restrict__ guard)
+{
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int a = __builtin_amdgcn_readfirstlane(list[blockIdx.y]);
+    const int g = blockIdx.x;
+    const int w0 = g * RUN_K;
+    const int kw = min(RUN_K, p.NW - w0);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+    // ---- stage the run tables of this block's words (16-byte copies)
+    {
+        const uint4 *src = (const uint4 *)(p.tabs + ((int64_t)a * p.NW + w0));
+        uint4 *dst = (uint4 *)lds;
+        const int n16 = kw * (RUN_TAB_BYTES / 16);
+        constexpr int TP = (RUN_K * (RUN_TAB_BYTES / 16) + RUN_BAND - 1) / RUN_BAND;  // 4 pieces per thread
+        uint4 tv[TP];
+#pragma unroll
+        for (int n = 0; n < TP; n++) {  // all loads in flight before the first LDS write
+            const int i = tid + n * RUN_BAND;
+            tv[n] = i < n16 ? src[i] : make_uint4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int n = 0; n < TP; n++) {
+            const int i = tid + n * RUN_BAND;
+            if (i < n16) dst[i] = tv[n];
+        }
+    }
+    // block-uniform word constants: (ca0, cb0) pairs go to LDS (read back as a broadcast), the
+    // level / lag bounds become the block's maxima, the valid mask matters for the last word only
+    const RunMeta *__restrict__ mt = p.meta + ((int64_t)a * p.NW + w0);
+    int nlev_blk = 1, smax_blk = 0;
+    for (int k = 0; k < kw; k++) {
+        nlev_blk = max(nlev_blk, __builtin_amdgcn_readfirstlane(mt[k].nlev));
+        smax_blk = max(smax_blk, __builtin_amdgcn_readfirstlane(mt[k].smax));
+    }
+    const uint32_t valid_last = (uint32_t)__builtin_amdgcn_readfirstlane((int)mt[kw - 1].valid);
+    if (tid < kw) *(int2 *)(lds + RUN_META_OFS + tid * 8) = make_int2(mt[tid].ca0, mt[tid].cb0);
+    const int2_t *__restrict__ RT = p.RT + (int64_t)a * p.NR;
+    const int32_t *__restrict__ CA = p.CA + (int64_t)a * p.NC;
+    const int32_t *__restrict__ CB = p.CB + (int64_t)a * p.NC;
+    const int c_first = w0 * 32;
+    const int c_last = min(p.NC, (w0 + kw) * 32) - 1;
+    const int ca_f = __builtin_amdgcn_readfirstlane(CA[c_first]), ca_l = __builtin_amdgcn_readfirstlane(CA[c_last]);
+    const int cb_f = __builtin_amdgcn_readfirstlane(CB[c_first]), cb_l = __builtin_amdgcn_readfirstlane(CB[c_last]);
+    uint16_t *__restrict__ out = p.part + ((int64_t)a * p.G + g) * p.NR;
+
+    // source bounding box of a band x word group: the map is monotone in r and in c, so the four
+    // corner samples bound it.  The corner rows' (X0, Y0) are fetched one band ahead of their use.
+    auto corners = [&](int yb, int2_t &t0, int2_t &t1) {
+        const int yy = min(yb, p.NR - 1);
+        t0 = RT[yy];
+        t1 = RT[min(p.NR, yy + RUN_BAND) - 1];
+    };
+    auto geometry = [&](const int2_t t0, const int2_t t1) -> RunGeom {
+        RunGeom q;
+        const int t0x = __builtin_amdgcn_readfirstlane(t0.x), t0y = __builtin_amdgcn_readfirstlane(t0.y);
+        const int t1x = __builtin_amdgcn_readfirstlane(t1.x), t1y = __builtin_amdgcn_readfirstlane(t1.y);
+        const int minbit = min(min(t0x + ca_f, t0x + ca_l), min(t1x + ca_f, t1x + ca_l)) >> 10;
+        const int maxbit = max(max(t0x + ca_f, t0x + ca_l), max(t1x + ca_f, t1x + ca_l)) >> 10;
+        const int minrow = min(min(t0y + cb_f, t0y + cb_l), min(t1y + cb_f, t1y + cb_l)) >> 10;
+        const int maxrow = max(max(t0y + cb_f, t0y + cb_l), max(t1y + cb_f, t1y + cb_l)) >> 10;
+        q.wxw = (minbit >> 5) & ~3;  // first window word (multiple of 4: 16-byte loads)
+        q.wy0 = minrow - 7;          // a word reads up to 7 rows beside its true samples
+        q.nrows = maxrow - minrow + 15;
+        q.fits = ((maxbit >> 5) + 1 - q.wxw) <= (RUN_PITCH - 1) && q.nrows <= RUN_WIN_ROWS;
+        return q;
+    };
+    // The window (nrows x 5 aligned 16-byte pieces, zero outside the image) is fetched into
+    // registers one band ahead -- piece i = tid + 512 n, row = i / 5 -- so the fetch of band b+1
+    // overlaps the compute of band b and every wave carries the same share.
+    constexpr int PIECES = (RUN_WIN_ROWS * 5 + RUN_BAND - 1) / RUN_BAND;  // 6
+    uint4 pre[PIECES];
+    auto prefetch = [&](const RunGeom &q) {
+#pragma unroll
+        for (int n = 0; n < PIECES; n++) {
+            const int i = tid + n * RUN_BAND;
+            const int row = i / 5, j = i - row * 5;
+            const int gy = q.wy0 + row, gw = q.wxw + 4 * j;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (q.fits && row < q.nrows && (unsigned)gy < (unsigned)p.src_rows && gw >= 0 && gw + 3 < p.src_wpr)
+                v = *(const uint4 *)(p.src + (int64_t)gy * p.src_wpr + gw);
+            pre[n] = v;
+        }
+    };
+    auto commit = [&](const RunGeom &q) {
+#pragma unroll
+        for (int n = 0; n < PIECES; n++) {
+            const int i = tid + n * RUN_BAND;
+            const int row = i / 5, j = i - row * 5;
+            if (row < q.nrows) {
+                uint32_t *d = (uint32_t *)(lds + RUN_WIN_OFS + row * RUN_PITCHB + j * 16);
+                d[0] = pre[n].x;
+                d[1] = pre[n].y;
+                d[2] = pre[n].z;
+                d[3] = pre[n].w;
+                if (j == 4) d[4] = 0;  // spill word
+            }
+        }
+    };
+
+    int2_t c0, c1;
+    corners(0, c0, c1);
+    RunGeom cur = geometry(c0, c1);
+    prefetch(cur);
+    corners(RUN_BAND, c0, c1);  // next band's corners: in flight until the end of the first iteration
+    int2_t rt = RT[min(wave * 64 + lane, p.NR - 1)];
+    for (int yb = 0; yb < p.NR; yb += RUN_BAND) {
+        const int r = yb + wave * 64 + lane;
+        __syncthreads();  // previous band's readers are done (first pass: tables and meta staged)
+        if (cur.fits) {
+            if (!(p.dbg & 2)) commit(cur);
+        } else if (tid == 0) {
+            guard[a] = 1;
+        }
+        __syncthreads();
+        const RunGeom now = cur;
+        const int2_t rt_now = rt;
+        if (yb + RUN_BAND < p.NR) {
+            cur = geometry(c0, c1);
+            if (!(p.dbg & 2)) prefetch(cur);
+            corners(yb + 2 * RUN_BAND, c0, c1);
+            rt = RT[min(r + RUN_BAND, p.NR - 1)];
+        }
+        if (now.fits && yb + wave * 64 < p.NR && !(p.dbg & 1)) {
+            const int rx = rt_now.x - (now.wxw << 15);  // window-local fixed point
+            const int ry = rt_now.y - (now.wy0 << 10);
+            uint32_t cnt = 0;
+            if (smax_blk == 1) cnt = band_words_s<1>(lds, kw, rx, ry, valid_last, nlev_blk);
+            else if (smax_blk == 0) cnt = band_words_s<0>(lds, kw, rx, ry, valid_last, nlev_blk);
+            else cnt = band_words_s<2>(lds, kw, rx, ry, valid_last, nlev_blk);
+            if (r < p.NR) out[r] = (uint16_t)cnt;
+        }
+    }
+}
+
+hipError_t launch_runs(const RunPass &p0, const int32_t *d_list, int n_list, int32_t *d_guard, hipStream_t s)
+{
+    if (n_list <= 0) return hipSuccess;
+    RunPass p = p0;
+    {
+        const char *e = getenv("OMR_RUNS_DBG");
+        p.dbg = e ? atoi(e) : 0;
+    }
+    // per device and idempotent; cheap enough to repeat (the batch entry points use every device)
+    hipError_t e = hipFuncSetAttribute((const void *)runs_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       RUN_LDS_BYTES);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(runs_kernel, dim3(p.G, n_list), dim3(RUN_BAND), RUN_LDS_BYTES, s, p, d_list, d_guard);
+    return hipGetLastError();
+}
+
+// proj[a][r] += sum_g part[a][g][r] for the listed candidates
+__global__ __launch_bounds__(256) void fold_parts_kernel(const uint16_t *__restrict__ part, int G, int NR,
+                                                         const int32_t *__restrict__ list,
+                                                         uint32_t *__restrict__ proj)
+{
+    const int a = list[blockIdx.y];
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= NR) return;
+    uint32_t s = 0;
+    for (int g = 0; g < G; g++) s += part[((int64_t)a * G + g) * NR + r];
+    proj[(int64_t)a * NR + r] += s;
+}
+
+hipError_t launch_fold_parts(const uint16_t *d_part, int G, int NR, const int32_t *d_list, int n_list,
+                             uint32_t *d_proj, hipStream_t s)
+{
+    if (n_list <= 0) return hipSuccess;
+    hipLaunchKernelGGL(fold_parts_kernel, dim3((NR + 255) / 256, n_list), dim3(256), 0, s, d_part, G, NR, d_list,
+                       d_proj);
+    return hipGetLastError();
+}
+
+}  // namespace omr

@@ -54,6 +54,7 @@ SYMBOLS = {
     "omr_sweep_plan_last_kernel_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
     "omr_sweep_plan_set_timing": (C.c_int, [C.c_void_p, C.c_int32]),
     "omr_sweep_plan_set_kernel": (C.c_int, [C.c_void_p, C.c_int32]),
+    "omr_sweep_plan_info": (C.c_int, [C.c_void_p, i32p, i32p]),
     "omr_sweep_plan_tables": (C.c_int, [C.c_void_p, C.c_int32, i32p, i32p, i32p, i32p]),
     "omr_batch_create": (C.c_int, [C.c_int32, C.c_int32, C.c_uint16, C.c_double, C.c_double, C.c_int32, C.c_int32,
                                    C.POINTER(C.c_void_p)]),

@@ -93,6 +93,12 @@ class SweepPlan:
         check(lib().omr_sweep_plan_last_kernel_ms(self.handle, C.byref(ms)))
         return ms.value
 
+    def info(self):
+        """(candidates on the run-merging kernel, candidates on the gather kernels)"""
+        r, g = C.c_int32(), C.c_int32()
+        check(lib().omr_sweep_plan_info(self.handle, C.byref(r), C.byref(g)))
+        return r.value, g.value
+
     def tables(self, a):
         ad, bd = np.zeros(self.cols, np.int32), np.zeros(self.cols, np.int32)
         X0, Y0 = np.zeros(self.rows, np.int32), np.zeros(self.rows, np.int32)

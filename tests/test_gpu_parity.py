@@ -13,7 +13,7 @@ from oics.types import RotateClipStrategy
 
 pytestmark = pytest.mark.gpu
 
-GENERIC, LDS = 1, 2
+GENERIC, LDS, RUNS = 1, 2, 3
 
 
 def load(path):
@@ -36,7 +36,7 @@ def test_device_present():
     assert oics.lib().omr_device_count() >= 1
 
 
-@pytest.mark.parametrize("kernel", [GENERIC, LDS])
+@pytest.mark.parametrize("kernel", [GENERIC, LDS, RUNS])
 def test_golden_vectors(golden_dir, kernel):
     files = sorted(f for f in glob.glob(os.path.join(golden_dir, "*.npz")) if "frontend" not in f)
     assert len(files) >= 9
@@ -47,7 +47,7 @@ def test_golden_vectors(golden_dir, kernel):
         try:
             plan.set_kernel(kernel)
         except oics.OmrError:
-            assert kernel == LDS
+            assert kernel in (LDS, RUNS)
             plan.close()
             continue
         vp, hp, vs, hs, best = plan.run(b)
@@ -79,9 +79,14 @@ def test_shapes_and_both_kernels(oracle, shape):
     rng = np.random.Generator(np.random.PCG64(rows * 1000 + cols))
     b = np.where(rng.random((rows, cols)) < 0.3, 0, 255).astype(np.uint8)
     exp = oracle.sweep(b, 45, 1.5)
-    for kernel in (GENERIC, LDS):
+    for kernel in (GENERIC, LDS, RUNS):
         plan = projection.SweepPlan(rows, cols, 45, 1.5)
-        plan.set_kernel(kernel)
+        try:
+            plan.set_kernel(kernel)
+        except oics.OmrError:
+            assert kernel == RUNS
+            plan.close()
+            continue
         got = plan.run(b)
         plan.close()
         assert_sweep_equal(got, exp, "%s kernel %d" % (shape, kernel))
@@ -228,12 +233,13 @@ def test_headline_size_against_oracle(oracle):
     b, theta = synth.make_binary_card(3508, 2480, 2)
     plan = projection.SweepPlan(3508, 2480, 10, 0.05)
     results = {}
-    for kernel in (LDS, GENERIC):
+    for kernel in (LDS, GENERIC, RUNS):
         plan.set_kernel(kernel)
         results[kernel] = plan.run(b)
     plan.close()
-    got = results[LDS]
-    assert_sweep_equal(results[GENERIC], got, "generic vs lds")
+    got = results[RUNS]
+    assert_sweep_equal(results[GENERIC], got, "generic vs runs")
+    assert_sweep_equal(results[LDS], got, "lds vs runs")
     # size-independent properties
     total = (b == 0).sum()
     assert (got[0].sum(axis=1) == got[1].sum(axis=1)).all()  # both projections count the same pixels
@@ -311,3 +317,33 @@ def test_device_argmax_tie_policy(oracle):
         torch.cuda.synchronize()
         lowest, accept = oracle.argmax_path1(v, h)
         assert int(out.item()) == lowest, (trial, n)
+
+
+def test_run_merging_kernel_covers_the_headline_sweep():
+    # every candidate of +-10 deg @ 0.05 deg on an A4 scan must qualify for the run-merging kernel
+    plan = projection.SweepPlan(3508, 2480, 10, 0.05)
+    assert plan.info() == (400, 0)
+    plan.close()
+    # the app's default +-45 deg sweep is split: small angles run-merged, steep ones gathered
+    plan = projection.SweepPlan(1150, 1240, 45, 0.2)
+    n_runs, n_gather = plan.info()
+    assert n_runs > 80 and n_gather > 80 and n_runs + n_gather == 450
+    plan.close()
+
+
+@pytest.mark.parametrize("shape,max_angle,step", [((700, 500), 20, 0.5), ((513, 1031), 12, 0.25), ((40, 2000), 8, 1.0),
+                                                  ((2000, 37), 8, 1.0), ((257, 255), 45, 0.9)])
+def test_run_merging_kernel_odd_shapes(oracle, shape, max_angle, step):
+    rows, cols = shape
+    rng = np.random.Generator(np.random.PCG64(rows + 7 * cols))
+    # blocky random content: long runs plus isolated pixels
+    b = np.where(rng.random((rows // 4 + 1, cols // 4 + 1)) < 0.3, 0, 255).astype(np.uint8)
+    b = np.kron(b, np.ones((4, 4), np.uint8))[:rows, :cols].copy()
+    b[rng.random(b.shape) < 0.02] = 0
+    exp = oracle.sweep(b, max_angle, step)
+    plan = projection.SweepPlan(rows, cols, max_angle, step)
+    plan.set_kernel(RUNS)
+    assert plan.info()[0] > 0
+    got = plan.run(b)
+    plan.close()
+    assert_sweep_equal(got, exp, str(shape))

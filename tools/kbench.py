@@ -23,7 +23,7 @@ hs = torch.zeros(A, dtype=torch.float64, device=dev)
 best = torch.zeros(1, dtype=torch.int32, device=dev)
 s = torch.cuda.Stream()
 ref = None
-for name, sel in (("generic", 1), ("lds", 2)):
+for name, sel in (("generic", 1), ("lds", 2), ("runs", 3)):
     plan = projection.SweepPlan(ROWS, COLS, 10, 0.05)
     plan.set_kernel(sel)
     plan.set_timing(True)
