@@ -135,15 +135,22 @@ def main():
     # a real batch job where it happens once)
     all_best = odist.gather_results(best, B * world, rank, world)
 
-    # roofline leg: sweep-kernel duration from HIP events recorded on the streams the kernel is
-    # launched on, over the same K steps
+    # roofline leg: duration of a scan's sweep stage from HIP events recorded on the stream the
+    # kernels are launched on, over the same K steps.  The stage is `launches` kernel launches: the
+    # run-merging kernel (both projections in one launch) plus the gather kernel when
+    # some candidates do not qualify for run-merging; the dominant kernel's mean launch time is
+    # stage / launches and one launch carries 1/launches of the scan's algorithmic bytes.
+    n_runs, n_gather = batch.info()
+    launches = (1 if n_runs > 0 else 0) + (1 if n_gather > 0 else 0)
     batch.set_timing(True)
     for _ in range(args.steps):
         step()
     k_sum_ms, k_n = batch.kernel_ms()
     batch.set_timing(False)
-    kernel_ms = k_sum_ms / max(1, k_n)
-    algo_bytes = float(A) * ROWS * COLS  # binarised image streamed once per candidate
+    stage_ms = k_sum_ms / max(1, k_n)
+    kernel_ms = stage_ms / launches
+    algo_bytes_scan = float(A) * ROWS * COLS  # binarised image streamed once per candidate
+    algo_bytes = algo_bytes_scan / launches
     achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
 
     total_scans = B * world * args.steps
@@ -179,8 +186,11 @@ def main():
                        "parallelism": "scan-sharded x%d, host-side gather" % world, "streams_per_gpu": args.streams},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                         "kernel": "sweep (fused rotate + project)", "kernel_ms": kernel_ms,
-                         "algorithmic_bytes_per_launch": algo_bytes, "launches_timed": k_n},
+                         "kernel": "omr::runs_kernel (run-merging rotate+project, both projections per launch)"
+                                   if n_runs > 0 else "omr::sweep_lds_kernel (gather rotate+project)",
+                         "kernel_ms": kernel_ms, "launches_per_scan": launches, "sweep_stage_ms_per_scan": stage_ms,
+                         "algorithmic_bytes_per_launch": algo_bytes, "algorithmic_bytes_per_scan": algo_bytes_scan,
+                         "scans_timed": k_n, "candidates_run_merged": n_runs, "candidates_gathered": n_gather},
             "accuracy_ok": acc_ok,
             "gathered_results": int(all_best.numel()),
         }

@@ -160,8 +160,13 @@ int omr_batch_run_device(omr_batch_ctx *ctx, const uint8_t *d_scans, int64_t sca
                          int64_t step_bytes, int32_t n, int32_t black_max, int32_t *d_best_idx,
                          double *d_v_sd, double *d_h_sd);
 int omr_batch_sync(omr_batch_ctx *ctx);
-/* Sum of the sweep-kernel durations (ms) and their count since the last call (timing must be
- * enabled with omr_batch_set_timing). Synchronises. */
+/* Sum over scans of the sweep-stage duration (ms; HIP events on the launch stream around the
+ * sweep kernels of a scan: one run-merging launch (row pass and column pass) plus one gather
+ * launch when some candidates do not qualify) and the number of scans timed since the last call
+ * (timing must be enabled with omr_batch_set_timing). Synchronises. */
+/* Split of the candidates between the run-merging kernel and the gather kernels (see
+ * omr_sweep_plan_info). */
+int omr_batch_info(const omr_batch_ctx *ctx, int32_t *n_runs, int32_t *n_gather);
 int omr_batch_set_timing(omr_batch_ctx *ctx, int32_t enabled);
 int omr_batch_kernel_ms(omr_batch_ctx *ctx, double *sum_ms, int32_t *launches);
 

@@ -190,8 +190,8 @@ int SweepTables::build_runs()
     host_mode.assign((size_t)A, 0);
     NWh = (cols + 31) / 32;
     NWv = (rows + 31) / 32;
-    Gh = (NWh + 7) / 8;
-    Gv = (NWv + 7) / 8;
+    Gh = (NWh + OMR_RUN_K - 1) / OMR_RUN_K;
+    Gv = (NWv + OMR_RUN_K - 1) / OMR_RUN_K;
     wprT = (NWv + 3) & ~3;
     const size_t tab_bytes = (size_t)A * (size_t)(NWh + NWv) * sizeof(RunTab);
     const char *off = getenv("OMR_DISABLE_RUNS");
@@ -232,8 +232,7 @@ int SweepTables::build_runs()
                rows, cols, NWh, tabsH.as<RunTab>(), metaH.as<RunMeta>(), hp.as<uint16_t>(), Gh, 0};
     RunPass pv{z1.as<uint32_t>(), cols, wprT, rtv.as<int2_t>(), cav.as<int32_t>(), cbv.as<int32_t>(),
                cols, rows, NWv, tabsV.as<RunTab>(), metaV.as<RunMeta>(), vp.as<uint16_t>(), Gv, 0};
-    OMR_HIP(launch_runs(ph, all.as<int32_t>(), A, gd.as<int32_t>(), nullptr));
-    OMR_HIP(launch_runs(pv, all.as<int32_t>(), A, gd.as<int32_t>(), nullptr));
+    OMR_HIP(launch_runs(ph, pv, all.as<int32_t>(), A, gd.as<int32_t>(), nullptr));
     std::vector<int32_t> g((size_t)A);
     std::vector<RunMeta> mh((size_t)A * NWh), mv((size_t)A * NWv);
     OMR_HIP(hipMemcpy(g.data(), gd.p, sizeof(int32_t) * (size_t)A, hipMemcpyDeviceToHost));
@@ -290,7 +289,8 @@ int SweepScratch::create(const SweepTables &t)
 
 int enqueue_sweep(const SweepTables &t, SweepScratch &s, int kernel_sel, const uint8_t *d_img, int64_t step,
                   int black_max, hipStream_t stream, uint32_t *d_vproj, uint32_t *d_hproj, double *d_v_sd,
-                  double *d_h_sd, int32_t *d_best, hipEvent_t ev0, hipEvent_t ev1, bool want_proj)
+                  double *d_h_sd, int32_t *d_best, hipEvent_t ev0, hipEvent_t ev1, bool want_proj,
+                  hipStream_t post_stream, hipEvent_t ev_mid)
 {
     const SweepDims &d = t.dims;
     if (!d_img) return fail(OMR_ERR_BADARG, "null image");
@@ -334,8 +334,7 @@ int enqueue_sweep(const SweepTables &t, SweepScratch &s, int kernel_sel, const u
         RunPass pv{s.bitsT.as<uint32_t>(), d.cols, t.wprT, t.rtv.as<int2_t>(), t.cav.as<int32_t>(),
                    t.cbv.as<int32_t>(), d.cols, d.rows, t.NWv, t.tabsV.as<RunTab>(), t.metaV.as<RunMeta>(),
                    s.vpart.as<uint16_t>(), t.Gv, 0};
-        OMR_HIP(launch_runs(ph, t.list_runs.as<int32_t>(), t.n_runs, s.guard.as<int32_t>(), stream));
-        OMR_HIP(launch_runs(pv, t.list_runs.as<int32_t>(), t.n_runs, s.guard.as<int32_t>(), stream));
+        OMR_HIP(launch_runs(ph, pv, t.list_runs.as<int32_t>(), t.n_runs, s.guard.as<int32_t>(), stream));
     }
     if (n_g > 0) {
         if (gather_lds)
@@ -346,6 +345,12 @@ int enqueue_sweep(const SweepTables &t, SweepScratch &s, int kernel_sel, const u
                                          t.xy0.as<int2_t>(), glist, n_g, vp, hp, stream));
     }
     if (ev1) OMR_HIP(hipEventRecord(ev1, stream));
+    if (post_stream && ev_mid) {
+        // the latency-bound tail runs on its own stream so the next scan's sweep can start
+        OMR_HIP(hipEventRecord(ev_mid, stream));
+        OMR_HIP(hipStreamWaitEvent(post_stream, ev_mid, 0));
+        stream = post_stream;
+    }
     if (use_runs && want_proj) {
         OMR_HIP(launch_fold_parts(s.hpart.as<uint16_t>(), t.Gh, d.rows, t.list_runs.as<int32_t>(), t.n_runs, hp, stream));
         OMR_HIP(launch_fold_parts(s.vpart.as<uint16_t>(), t.Gv, d.cols, t.list_runs.as<int32_t>(), t.n_runs, vp, stream));
@@ -375,8 +380,10 @@ omr_batch_ctx::~omr_batch_ctx()
         (void)hipEventDestroy(e.first);
         (void)hipEventDestroy(e.second);
     }
-    for (auto e : joins) (void)hipEventDestroy(e);
+    for (auto e : ev_mid) (void)hipEventDestroy(e);
+    for (auto e : ev_post) (void)hipEventDestroy(e);
     for (auto s : streams) (void)hipStreamDestroy(s);
+    for (auto s : post_streams) (void)hipStreamDestroy(s);
 }
 
 extern "C" {
@@ -597,18 +604,38 @@ int omr_batch_create(int32_t rows, int32_t cols, uint16_t max_angle, double step
     int rc = c->tables.create(rows, cols, M.data(), A, device);
     if (rc) return rc;
     for (int i = 0; i < n_streams; i++) {
-        c->scratch.emplace_back(new SweepScratch);
-        rc = c->scratch.back()->create(c->tables);
-        if (rc) return rc;
-        hipStream_t s;
+        hipStream_t s, ps;
         OMR_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
         c->streams.push_back(s);
+        OMR_HIP(hipStreamCreateWithFlags(&ps, hipStreamNonBlocking));
+        c->post_streams.push_back(ps);
+        c->issued.push_back(0);
+        for (int h = 0; h < 2; h++) {
+            c->scratch.emplace_back(new SweepScratch);
+            rc = c->scratch.back()->create(c->tables);
+            if (rc) return rc;
+            hipEvent_t e0, e1;
+            OMR_HIP(hipEventCreateWithFlags(&e0, hipEventDisableTiming));
+            OMR_HIP(hipEventCreateWithFlags(&e1, hipEventDisableTiming));
+            c->ev_mid.push_back(e0);
+            c->ev_post.push_back(e1);
+            c->post_pending.push_back(0);
+        }
     }
     *ctx_out = c.release();
     return OMR_OK;
 }
 
 void omr_batch_destroy(omr_batch_ctx *ctx) { delete ctx; }
+
+int omr_batch_info(const omr_batch_ctx *ctx, int32_t *n_runs, int32_t *n_gather)
+{
+    if (!ctx) return fail(OMR_ERR_BADARG, "null ctx");
+    const bool runs = ctx->tables.runs_built && ctx->tables.n_runs > 0;
+    if (n_runs) *n_runs = runs ? ctx->tables.n_runs : 0;
+    if (n_gather) *n_gather = runs ? ctx->tables.n_gather : ctx->tables.dims.A;
+    return OMR_OK;
+}
 
 int omr_batch_set_timing(omr_batch_ctx *ctx, int32_t enabled)
 {
@@ -639,10 +666,20 @@ int omr_batch_run_device(omr_batch_ctx *ctx, const uint8_t *d_scans, int64_t sca
             e1 = ctx->events[ctx->events_used].second;
             ctx->events_used++;
         }
-        int rc = enqueue_sweep(ctx->tables, *ctx->scratch[k], KERNEL_AUTO, d_scans + (size_t)i * scan_stride,
+        const int set = 2 * k + (int)(ctx->issued[k] & 1);
+        ctx->issued[k]++;
+        // this scratch set's previous std-dev / arg-max must have read its projections
+        if (ctx->post_pending[set]) OMR_HIP(hipStreamWaitEvent(ctx->streams[k], ctx->ev_post[set], 0));
+        int rc = enqueue_sweep(ctx->tables, *ctx->scratch[set], KERNEL_AUTO, d_scans + (size_t)i * scan_stride,
                                step_bytes, black_max, ctx->streams[k], nullptr, nullptr,
                                d_v_sd ? d_v_sd + (size_t)i * A : nullptr, d_h_sd ? d_h_sd + (size_t)i * A : nullptr,
-                               d_best_idx ? d_best_idx + i : nullptr, e0, e1);
+                               d_best_idx ? d_best_idx + i : nullptr, e0, e1, false, ctx->post_streams[k],
+                               ctx->ev_mid[set]);
+        if (!rc) {
+            if (hipEventRecord(ctx->ev_post[set], ctx->post_streams[k]) != hipSuccess)
+                return fail(OMR_ERR_GPU, "hipEventRecord failed");
+            ctx->post_pending[set] = 1;
+        }
         if (rc) return rc;
     }
     return OMR_OK;
@@ -653,6 +690,7 @@ int omr_batch_sync(omr_batch_ctx *ctx)
     if (!ctx) return fail(OMR_ERR_BADARG, "null ctx");
     OMR_HIP(hipSetDevice(ctx->tables.device));
     for (auto s : ctx->streams) OMR_HIP(hipStreamSynchronize(s));
+    for (auto s : ctx->post_streams) OMR_HIP(hipStreamSynchronize(s));
     return OMR_OK;
 }
 

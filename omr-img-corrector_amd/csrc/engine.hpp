@@ -76,7 +76,8 @@ enum KernelSel { KERNEL_AUTO = 0, KERNEL_GENERIC = 1, KERNEL_LDS = 2, KERNEL_RUN
 // Enqueue pack -> sweep -> std-dev -> arg-max for one device-resident scan.
 int enqueue_sweep(const SweepTables &t, SweepScratch &s, int kernel_sel, const uint8_t *d_img, int64_t step,
                   int black_max, hipStream_t stream, uint32_t *d_vproj, uint32_t *d_hproj, double *d_v_sd,
-                  double *d_h_sd, int32_t *d_best, hipEvent_t ev0, hipEvent_t ev1, bool want_proj = false);
+                  double *d_h_sd, int32_t *d_best, hipEvent_t ev0, hipEvent_t ev1, bool want_proj = false,
+                  hipStream_t post_stream = nullptr, hipEvent_t ev_mid = nullptr);
 
 }  // namespace omr
 
@@ -96,10 +97,14 @@ struct omr_batch_ctx {
     omr::SweepTables tables;
     int N = 0;
     double step = 0;
-    std::vector<std::unique_ptr<omr::SweepScratch>> scratch;
-    std::vector<hipStream_t> streams;
+    // per main stream: two scratch sets used alternately, a post stream for the latency-bound
+    // std-dev / arg-max kernels (they overlap the next scan's sweep), and the events that order them
+    std::vector<std::unique_ptr<omr::SweepScratch>> scratch;  // [2 * n_streams]
+    std::vector<hipStream_t> streams, post_streams;
+    std::vector<hipEvent_t> ev_mid, ev_post;                   // [2 * n_streams]
+    std::vector<char> post_pending;                            // [2 * n_streams]
+    std::vector<uint64_t> issued;                              // scans issued per main stream
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
-    std::vector<hipEvent_t> joins;
     size_t events_used = 0;
     bool timing = false;
     std::mutex mu;

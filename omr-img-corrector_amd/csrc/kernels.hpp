@@ -54,6 +54,9 @@ hipError_t launch_sweep_lds(const uint32_t *d_bits, SweepDims d, const int32_t *
 // src = bit image.  Pass V (column counts) is the same sum on the TRANSPOSED bit image with the
 // roles of the tables swapped: RT = (bdelta, adelta), CA = Y0, CB = X0.
 #define OMR_RUN_TUPLES 40
+#ifndef OMR_RUN_K
+#define OMR_RUN_K 8  // destination words per run-merging block (partials are per group of OMR_RUN_K words)
+#endif
 struct RunTab {                        // per (candidate, 32-column word); 3648 B, 16-B aligned
     uint32_t tupY[OMR_RUN_TUPLES][8];  // [id][level]: destination bits that read source row level
     uint32_t tupX[OMR_RUN_TUPLES][2];  // [id][s-1]:   destination bits whose source column lags by s
@@ -78,7 +81,7 @@ struct RunPass {  // one orientation
     int32_t NR, NC, NW;   // NW = ceil(NC / 32)
     const RunTab *tabs;   // [A][NW]
     const RunMeta *meta;  // [A][NW]
-    uint16_t *part;       // [A][G][NR] partial counts, G = ceil(NW / 8)
+    uint16_t *part;       // [A][G][NR] partial counts, G = ceil(NW / OMR_RUN_K)
     int32_t G;
     int32_t dbg;          // development switches (0 in production)
 };
@@ -89,7 +92,8 @@ hipError_t launch_vtables(SweepDims d, const int32_t *d_adelta, const int32_t *d
 hipError_t launch_runtab(const int32_t *d_CA, const int32_t *d_CB, int A, int NC, int NW, RunTab *d_tabs,
                          RunMeta *d_meta, hipStream_t s);
 // d_list: n_list candidate indices; d_guard[a] != 0 when a window did not fit for candidate a.
-hipError_t launch_runs(const RunPass &p, const int32_t *d_list, int n_list, int32_t *d_guard, hipStream_t s);
+hipError_t launch_runs(const RunPass &ph, const RunPass &pv, const int32_t *d_list, int n_list, int32_t *d_guard,
+                       hipStream_t s);
 // vproj/hproj (u32) += partial counts of the listed candidates (only when the caller wants them)
 hipError_t launch_fold_parts(const uint16_t *d_part, int G, int NR, const int32_t *d_list, int n_list,
                              uint32_t *d_proj, hipStream_t s);

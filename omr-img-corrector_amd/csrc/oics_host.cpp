@@ -640,7 +640,7 @@ int omr_sweep_batch(const omr_image *scans, int32_t n, uint16_t max_angle, doubl
                 hipStream_t s = ctx->streams[k];
                 OMR_HIP(hipMemcpy2DAsync(dimg[k].p, (size_t)cols, scans[i].data, (size_t)scans[i].step_bytes,
                                          (size_t)cols, (size_t)rows, hipMemcpyHostToDevice, s));
-                rc = enqueue_sweep(ctx->tables, *ctx->scratch[k], KERNEL_AUTO, dimg[k].as<uint8_t>(), cols, 0, s,
+                rc = enqueue_sweep(ctx->tables, *ctx->scratch[2 * k], KERNEL_AUTO, dimg[k].as<uint8_t>(), cols, 0, s,
                                    nullptr, nullptr, dvs.as<double>() + (size_t)j * A, dhs.as<double>() + (size_t)j * A,
                                    dbest.as<int32_t>() + j, nullptr, nullptr);
                 if (rc) return rc;

@@ -22,18 +22,22 @@
 
 namespace omr {
 
-#define RUN_K 8            // destination words per block column group
+#define RUN_K OMR_RUN_K    // destination words per block column group (kernels.hpp)
 #define RUN_BAND 512       // destination rows per band (8 waves x 64 lanes)
-#define RUN_PITCH 21       // window row pitch in words (20 data words + 1 spill word), odd
+#define RUN_QUADS ((RUN_K * 32 + 127 + 96) / 128 + 2)  // aligned 4-word pieces per window row
+#define RUN_PITCH (RUN_QUADS * 4 + 1)  // window row pitch in words (data words + 1 spill word), odd
 #define RUN_PITCHB (RUN_PITCH * 4)
 #define RUN_WIN_ROWS 576
 #define RUN_TAB_BYTES 3648
 #define RUN_TUPX_OFS 1280
 #define RUN_IDXY_OFS 1600
 #define RUN_IDXX_OFS 2624
-#define RUN_META_OFS (RUN_K * RUN_TAB_BYTES)  // RUN_K x (ca0, cb0)
-#define RUN_WIN_OFS (RUN_META_OFS + RUN_K * 8)
-#define RUN_LDS_BYTES (RUN_WIN_OFS + RUN_WIN_ROWS * RUN_PITCHB)
+// LDS layout: window first (so a level's row offset fits ds_read2's 8-bit offset fields), then
+// the RUN_K (ca0, cb0) pairs, then the RUN_K run tables
+#define RUN_WIN_OFS 0
+#define RUN_META_OFS (RUN_WIN_ROWS * RUN_PITCHB)
+#define RUN_TABS_OFS (RUN_META_OFS + RUN_K * 8)
+#define RUN_LDS_BYTES (RUN_TABS_OFS + RUN_K * RUN_TAB_BYTES)
 
 static_assert(sizeof(RunTab) == RUN_TAB_BYTES, "RunTab layout");
 static_assert(sizeof(RunMeta) == 32, "RunMeta layout");
@@ -276,7 +280,7 @@ __device__ __forceinline__ uint32_t band_words(const char *lds, const int kw, co
         const int ka = k, kb = min(k + 1, kw - 1);  // odd tail: word b repeats word a and is dropped
         const int2 ma = *(const int2 *)(lds + RUN_META_OFS + ka * 8);  // same address in every lane
         const int2 mb = *(const int2 *)(lds + RUN_META_OFS + kb * 8);
-        const int ta = ka * RUN_TAB_BYTES, tb = kb * RUN_TAB_BYTES;
+        const int ta = RUN_TABS_OFS + ka * RUN_TAB_BYTES, tb = RUN_TABS_OFS + kb * RUN_TAB_BYTES;
         const int A0a = rx + ma.x, B0a = ry + ma.y, A0b = rx + mb.x, B0b = ry + mb.y;
         const uint32_t idya = lds_u8(lds, ta + RUN_IDXY_OFS + (B0a & 1023));
         const uint32_t idyb = lds_u8(lds, tb + RUN_IDXY_OFS + (B0b & 1023));
@@ -339,12 +343,17 @@ struct RunGeom {  // source window of one band (wave-uniform)
     bool fits;
 };
 
-__global__ __launch_bounds__(RUN_BAND) void runs_kernel(RunPass p, const int32_t *__restrict__ list,
+// blockIdx.z selects the projection: 0 = row counts on the bit image, 1 = column counts on the
+// transposed bit image.  Both run in ONE launch so their tails overlap.
+__global__ __launch_bounds__(RUN_BAND) void runs_kernel(const RunPass ph, const RunPass pv,
+                                                        const int32_t *__restrict__ list,
                                                         int32_t *__restrict__ guard)
 {
     extern __shared__ __attribute__((aligned(16))) char lds[];
+    const RunPass &p = blockIdx.z ? pv : ph;
     const int a = __builtin_amdgcn_readfirstlane(list[blockIdx.y]);
     const int g = blockIdx.x;
+    if (g >= p.G) return;
     const int w0 = g * RUN_K;
     const int kw = min(RUN_K, p.NW - w0);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -352,7 +361,7 @@ __global__ __launch_bounds__(RUN_BAND) void runs_kernel(RunPass p, const int32_t
     // ---- stage the run tables of this block's words (16-byte copies)
     {
         const uint4 *src = (const uint4 *)(p.tabs + ((int64_t)a * p.NW + w0));
-        uint4 *dst = (uint4 *)lds;
+        uint4 *dst = (uint4 *)(lds + RUN_TABS_OFS);
         const int n16 = kw * (RUN_TAB_BYTES / 16);
         constexpr int TP = (RUN_K * (RUN_TAB_BYTES / 16) + RUN_BAND - 1) / RUN_BAND;  // 4 pieces per thread
         uint4 tv[TP];
@@ -407,35 +416,44 @@ __global__ __launch_bounds__(RUN_BAND) void runs_kernel(RunPass p, const int32_t
         q.fits = ((maxbit >> 5) + 1 - q.wxw) <= (RUN_PITCH - 1) && q.nrows <= RUN_WIN_ROWS;
         return q;
     };
-    // The window (nrows x 5 aligned 16-byte pieces, zero outside the image) is fetched into
-    // registers one band ahead -- piece i = tid + 512 n, row = i / 5 -- so the fetch of band b+1
-    // overlaps the compute of band b and every wave carries the same share.
-    constexpr int PIECES = (RUN_WIN_ROWS * 5 + RUN_BAND - 1) / RUN_BAND;  // 6
+    // The window (nrows x RUN_QUADS aligned 16-byte pieces, zero outside the image) is fetched into
+    // registers one band ahead -- piece i = tid + 512 n, row = i / RUN_QUADS -- so the fetch of band b+1
+    // overlaps the compute of band b and every wave carries the same share.  A thread's pieces sit
+    // at the same window positions in every band: their row / word / LDS offsets are computed once.
+    constexpr int PIECES = (RUN_WIN_ROWS * RUN_QUADS + RUN_BAND - 1) / RUN_BAND;
+    int pc_row[PIECES], pc_w4[PIECES], pc_lds[PIECES];
+    int64_t pc_src[PIECES];
+#pragma unroll
+    for (int n = 0; n < PIECES; n++) {
+        const int i = tid + n * RUN_BAND;
+        pc_row[n] = i / RUN_QUADS;
+        pc_w4[n] = 4 * (i - pc_row[n] * RUN_QUADS);
+        pc_lds[n] = RUN_WIN_OFS + pc_row[n] * RUN_PITCHB + pc_w4[n] * 4;
+        pc_src[n] = (int64_t)pc_row[n] * p.src_wpr + pc_w4[n];
+    }
     uint4 pre[PIECES];
     auto prefetch = [&](const RunGeom &q) {
+        const uint32_t *base = p.src + ((int64_t)q.wy0 * p.src_wpr + q.wxw);  // wave-uniform
+        const int row_lo = -q.wy0, row_hi = min(q.nrows, p.src_rows - q.wy0);  // rows inside the image
+        const int w_lo = -q.wxw, w_hi = p.src_wpr - q.wxw - 3;                 // 4-word pieces inside a row
 #pragma unroll
         for (int n = 0; n < PIECES; n++) {
-            const int i = tid + n * RUN_BAND;
-            const int row = i / 5, j = i - row * 5;
-            const int gy = q.wy0 + row, gw = q.wxw + 4 * j;
             uint4 v = make_uint4(0, 0, 0, 0);
-            if (q.fits && row < q.nrows && (unsigned)gy < (unsigned)p.src_rows && gw >= 0 && gw + 3 < p.src_wpr)
-                v = *(const uint4 *)(p.src + (int64_t)gy * p.src_wpr + gw);
+            if (q.fits && pc_row[n] >= row_lo && pc_row[n] < row_hi && pc_w4[n] >= w_lo && pc_w4[n] < w_hi)
+                v = *(const uint4 *)(base + pc_src[n]);
             pre[n] = v;
         }
     };
     auto commit = [&](const RunGeom &q) {
 #pragma unroll
         for (int n = 0; n < PIECES; n++) {
-            const int i = tid + n * RUN_BAND;
-            const int row = i / 5, j = i - row * 5;
-            if (row < q.nrows) {
-                uint32_t *d = (uint32_t *)(lds + RUN_WIN_OFS + row * RUN_PITCHB + j * 16);
+            if (pc_row[n] < q.nrows) {
+                uint32_t *d = (uint32_t *)(lds + pc_lds[n]);
                 d[0] = pre[n].x;
                 d[1] = pre[n].y;
                 d[2] = pre[n].z;
                 d[3] = pre[n].w;
-                if (j == 4) d[4] = 0;  // spill word
+                if (pc_w4[n] == 4 * (RUN_QUADS - 1)) d[4] = 0;  // spill word
             }
         }
     };
@@ -475,19 +493,21 @@ __global__ __launch_bounds__(RUN_BAND) void runs_kernel(RunPass p, const int32_t
     }
 }
 
-hipError_t launch_runs(const RunPass &p0, const int32_t *d_list, int n_list, int32_t *d_guard, hipStream_t s)
+hipError_t launch_runs(const RunPass &ph0, const RunPass &pv0, const int32_t *d_list, int n_list, int32_t *d_guard,
+                       hipStream_t s)
 {
     if (n_list <= 0) return hipSuccess;
-    RunPass p = p0;
+    RunPass ph = ph0, pv = pv0;
     {
         const char *e = getenv("OMR_RUNS_DBG");
-        p.dbg = e ? atoi(e) : 0;
+        ph.dbg = pv.dbg = e ? atoi(e) : 0;
     }
     // per device and idempotent; cheap enough to repeat (the batch entry points use every device)
     hipError_t e = hipFuncSetAttribute((const void *)runs_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                        RUN_LDS_BYTES);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(runs_kernel, dim3(p.G, n_list), dim3(RUN_BAND), RUN_LDS_BYTES, s, p, d_list, d_guard);
+    hipLaunchKernelGGL(runs_kernel, dim3(ph.G > pv.G ? ph.G : pv.G, n_list, 2), dim3(RUN_BAND), RUN_LDS_BYTES, s, ph,
+                       pv, d_list, d_guard);
     return hipGetLastError();
 }
 

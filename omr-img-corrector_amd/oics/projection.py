@@ -147,6 +147,11 @@ class Batch:
     def sync(self):
         check(lib().omr_batch_sync(self.handle))
 
+    def info(self):
+        r, g = C.c_int32(), C.c_int32()
+        check(lib().omr_batch_info(self.handle, C.byref(r), C.byref(g)))
+        return r.value, g.value
+
     def set_timing(self, on):
         check(lib().omr_batch_set_timing(self.handle, 1 if on else 0))
 
