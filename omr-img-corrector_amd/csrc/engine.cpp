@@ -179,8 +179,8 @@ int SweepTables::create(int rows, int cols, const double *fwd_M, int A, int dev)
     return build_runs();
 }
 
-// Run tables for both passes, then a dry run of the pass kernels on an all-white scan: window
-// geometry does not depend on the pixels, so a candidate whose windows fit once always fits.
+// Run tables, then a dry run of the kernel on an all-white scan: window geometry does not depend
+// on the pixels, so a candidate whose windows fit once always fits.
 int SweepTables::build_runs()
 {
     const int rows = dims.rows, cols = dims.cols, A = dims.A;
@@ -189,74 +189,52 @@ int SweepTables::build_runs()
     n_gather = A;
     host_mode.assign((size_t)A, 0);
     NWh = (cols + 31) / 32;
-    NWv = (rows + 31) / 32;
     Gh = (NWh + OMR_RUN_K - 1) / OMR_RUN_K;
-    Gv = (NWv + OMR_RUN_K - 1) / OMR_RUN_K;
-    wprT = (NWv + 3) & ~3;
-    const size_t tab_bytes = (size_t)A * (size_t)(NWh + NWv) * sizeof(RunTab);
+    const size_t tab_bytes = (size_t)A * (size_t)NWh * sizeof(RunTab);
     const char *off = getenv("OMR_DISABLE_RUNS");
     if ((off && off[0] == '1') || tab_bytes > ((size_t)3 << 30)) return OMR_OK;  // gather kernels only
-    OMR_HIP(rtv.alloc(sizeof(int2_t) * (size_t)A * cols));
-    OMR_HIP(cav.alloc(sizeof(int32_t) * (size_t)A * rows));
-    OMR_HIP(cbv.alloc(sizeof(int32_t) * (size_t)A * rows));
     OMR_HIP(tabsH.alloc(sizeof(RunTab) * (size_t)A * NWh));
-    OMR_HIP(tabsV.alloc(sizeof(RunTab) * (size_t)A * NWv));
     OMR_HIP(metaH.alloc(sizeof(RunMeta) * (size_t)A * NWh));
-    OMR_HIP(metaV.alloc(sizeof(RunMeta) * (size_t)A * NWv));
     OMR_HIP(mode.alloc(sizeof(int32_t) * (size_t)A));
     OMR_HIP(list_runs.alloc(sizeof(int32_t) * (size_t)A));
     OMR_HIP(list_gather.alloc(sizeof(int32_t) * (size_t)A));
     OMR_HIP(hipMemset(tabsH.p, 0, tabsH.bytes));
-    OMR_HIP(hipMemset(tabsV.p, 0, tabsV.bytes));
-    OMR_HIP(launch_vtables(dims, adelta.as<int32_t>(), bdelta.as<int32_t>(), xy0.as<int2_t>(), rtv.as<int2_t>(),
-                           cav.as<int32_t>(), cbv.as<int32_t>(), nullptr));
     OMR_HIP(launch_runtab(adelta.as<int32_t>(), bdelta.as<int32_t>(), A, cols, NWh, tabsH.as<RunTab>(),
                           metaH.as<RunMeta>(), nullptr));
-    OMR_HIP(launch_runtab(cav.as<int32_t>(), cbv.as<int32_t>(), A, rows, NWv, tabsV.as<RunTab>(), metaV.as<RunMeta>(),
-                          nullptr));
     // dry run
-    DevBuf z0, z1, hp, vp, gd, all;
+    DevBuf z0, hp, vp, gd, all;
     OMR_HIP(z0.alloc(sizeof(uint32_t) * (size_t)rows * dims.wpr));
-    OMR_HIP(z1.alloc(sizeof(uint32_t) * (size_t)cols * wprT));
     OMR_HIP(hp.alloc(sizeof(uint16_t) * (size_t)A * Gh * rows));
-    OMR_HIP(vp.alloc(sizeof(uint16_t) * (size_t)A * Gv * cols));
+    OMR_HIP(vp.alloc(sizeof(uint32_t) * (size_t)A * cols));
     OMR_HIP(gd.alloc(sizeof(int32_t) * (size_t)A));
     OMR_HIP(all.alloc(sizeof(int32_t) * (size_t)A));
     OMR_HIP(hipMemset(z0.p, 0, z0.bytes));
-    OMR_HIP(hipMemset(z1.p, 0, z1.bytes));
     OMR_HIP(hipMemset(gd.p, 0, gd.bytes));
     std::vector<int32_t> idx((size_t)A);
     for (int a = 0; a < A; a++) idx[a] = a;
     OMR_HIP(hipMemcpy(all.p, idx.data(), sizeof(int32_t) * (size_t)A, hipMemcpyHostToDevice));
     RunPass ph{z0.as<uint32_t>(), rows, dims.wpr, xy0.as<int2_t>(), adelta.as<int32_t>(), bdelta.as<int32_t>(),
                rows, cols, NWh, tabsH.as<RunTab>(), metaH.as<RunMeta>(), hp.as<uint16_t>(), Gh, 0};
-    RunPass pv{z1.as<uint32_t>(), cols, wprT, rtv.as<int2_t>(), cav.as<int32_t>(), cbv.as<int32_t>(),
-               cols, rows, NWv, tabsV.as<RunTab>(), metaV.as<RunMeta>(), vp.as<uint16_t>(), Gv, 0};
-    OMR_HIP(launch_runs(ph, pv, all.as<int32_t>(), A, gd.as<int32_t>(), nullptr));
+    OMR_HIP(launch_runs(ph, all.as<int32_t>(), A, gd.as<int32_t>(), vp.as<uint32_t>(), nullptr));
     std::vector<int32_t> g((size_t)A);
-    std::vector<RunMeta> mh((size_t)A * NWh), mv((size_t)A * NWv);
+    std::vector<RunMeta> mh((size_t)A * NWh);
     OMR_HIP(hipMemcpy(g.data(), gd.p, sizeof(int32_t) * (size_t)A, hipMemcpyDeviceToHost));
     OMR_HIP(hipMemcpy(mh.data(), metaH.p, sizeof(RunMeta) * mh.size(), hipMemcpyDeviceToHost));
-    OMR_HIP(hipMemcpy(mv.data(), metaV.p, sizeof(RunMeta) * mv.size(), hipMemcpyDeviceToHost));
     if (getenv("OMR_DEBUG")) {
-        int ng = 0, nh = 0, nv = 0;
+        int ng = 0, nh = 0;
         for (int a = 0; a < A; a++) {
             ng += g[a] != 0;
-            bool bh = false, bv = false;
+            bool bh = false;
             for (int w = 0; w < NWh; w++) bh |= mh[(size_t)a * NWh + w].ok == 0;
-            for (int w = 0; w < NWv; w++) bv |= mv[(size_t)a * NWv + w].ok == 0;
             nh += bh;
-            nv += bv;
         }
-        const RunMeta &m0 = mh[0], &m1 = mv[0];
-        fprintf(stderr, "[omr] runs: A=%d guard-fail=%d metaH-bad=%d metaV-bad=%d | H[0,0]: nlev=%d smax=%d ok=%d cb0=%d ca0=%d | V[0,0]: nlev=%d smax=%d ok=%d\n",
-                A, ng, nh, nv, m0.nlev, m0.smax, m0.ok, m0.cb0, m0.ca0, m1.nlev, m1.smax, m1.ok);
+        fprintf(stderr, "[omr] runs: A=%d guard-fail=%d meta-bad=%d | [0,0]: nlev=%d smax=%d ok=%d\n", A, ng, nh,
+                mh[0].nlev, mh[0].smax, mh[0].ok);
     }
     std::vector<int32_t> lr, lg;
     for (int a = 0; a < A; a++) {
         bool ok = g[a] == 0;
         for (int w = 0; ok && w < NWh; w++) ok = mh[(size_t)a * NWh + w].ok != 0;
-        for (int w = 0; ok && w < NWv; w++) ok = mv[(size_t)a * NWv + w].ok != 0;
         host_mode[a] = ok ? 1 : 0;
         (ok ? lr : lg).push_back(a);
     }
@@ -273,9 +251,7 @@ int SweepScratch::create(const SweepTables &t)
 {
     const SweepDims &d = t.dims;
     if (t.runs_built && t.n_runs > 0) {
-        OMR_HIP(bitsT.alloc(sizeof(uint32_t) * (size_t)d.cols * t.wprT));
         OMR_HIP(hpart.alloc(sizeof(uint16_t) * (size_t)d.A * t.Gh * d.rows));
-        OMR_HIP(vpart.alloc(sizeof(uint16_t) * (size_t)d.A * t.Gv * d.cols));
         OMR_HIP(guard.alloc(sizeof(int32_t) * (size_t)d.A));
     }
     OMR_HIP(bits.alloc(sizeof(uint32_t) * (size_t)d.rows * d.wpr));
@@ -303,7 +279,7 @@ int enqueue_sweep(const SweepTables &t, SweepScratch &s, int kernel_sel, const u
     else if (kernel_sel == KERNEL_LDS) {
         if (!t.lds_ok) return fail(OMR_ERR_BADARG, "a candidate's source window does not fit the LDS slab");
     } else {
-        use_runs = t.runs_built && t.n_runs > 0 && s.bitsT.p != nullptr;
+        use_runs = t.runs_built && t.n_runs > 0 && s.hpart.p != nullptr;
         if (kernel_sel == KERNEL_RUNS && !use_runs)
             return fail(OMR_ERR_BADARG, "no candidate of this plan qualifies for the run-merging kernel");
         if (use_runs) {
@@ -318,23 +294,18 @@ int enqueue_sweep(const SweepTables &t, SweepScratch &s, int kernel_sel, const u
     uint32_t *hp = d_hproj ? d_hproj : s.hproj.as<uint32_t>();
     double *vs = d_v_sd ? d_v_sd : s.vsd.as<double>();
     double *hs = d_h_sd ? d_h_sd : s.hsd.as<double>();
-    if (n_g > 0 || want_proj) {
-        OMR_HIP(hipMemsetAsync(vp, 0, sizeof(uint32_t) * (size_t)d.A * d.cols, stream));
-        OMR_HIP(hipMemsetAsync(hp, 0, sizeof(uint32_t) * (size_t)d.A * d.rows, stream));
-    }
+    // The gather kernels accumulate with integer atomics -> their rows of vproj / hproj start at 0;
+    // the run-merging kernel stores complete column counts itself and needs hproj only when the
+    // caller asked for the projections (its row counts live in the u16 partials).
+    if (n_g > 0) OMR_HIP(hipMemsetAsync(vp, 0, sizeof(uint32_t) * (size_t)d.A * d.cols, stream));
+    if (n_g > 0 || want_proj) OMR_HIP(hipMemsetAsync(hp, 0, sizeof(uint32_t) * (size_t)d.A * d.rows, stream));
     OMR_HIP(launch_pack_bits(d_img, step, d.rows, d.cols, black_max, s.bits.as<uint32_t>(), d.wpr, stream));
-    if (use_runs)
-        OMR_HIP(launch_transpose_bits(s.bits.as<uint32_t>(), d.rows, d.cols, d.wpr, s.bitsT.as<uint32_t>(), t.wprT,
-                                      stream));
     if (ev0) OMR_HIP(hipEventRecord(ev0, stream));
     if (use_runs) {
         RunPass ph{s.bits.as<uint32_t>(), d.rows, d.wpr, t.xy0.as<int2_t>(), t.adelta.as<int32_t>(),
                    t.bdelta.as<int32_t>(), d.rows, d.cols, t.NWh, t.tabsH.as<RunTab>(), t.metaH.as<RunMeta>(),
                    s.hpart.as<uint16_t>(), t.Gh, 0};
-        RunPass pv{s.bitsT.as<uint32_t>(), d.cols, t.wprT, t.rtv.as<int2_t>(), t.cav.as<int32_t>(),
-                   t.cbv.as<int32_t>(), d.cols, d.rows, t.NWv, t.tabsV.as<RunTab>(), t.metaV.as<RunMeta>(),
-                   s.vpart.as<uint16_t>(), t.Gv, 0};
-        OMR_HIP(launch_runs(ph, pv, t.list_runs.as<int32_t>(), t.n_runs, s.guard.as<int32_t>(), stream));
+        OMR_HIP(launch_runs(ph, t.list_runs.as<int32_t>(), t.n_runs, s.guard.as<int32_t>(), vp, stream));
     }
     if (n_g > 0) {
         if (gather_lds)
@@ -351,12 +322,10 @@ int enqueue_sweep(const SweepTables &t, SweepScratch &s, int kernel_sel, const u
         OMR_HIP(hipStreamWaitEvent(post_stream, ev_mid, 0));
         stream = post_stream;
     }
-    if (use_runs && want_proj) {
+    if (use_runs && want_proj)
         OMR_HIP(launch_fold_parts(s.hpart.as<uint16_t>(), t.Gh, d.rows, t.list_runs.as<int32_t>(), t.n_runs, hp, stream));
-        OMR_HIP(launch_fold_parts(s.vpart.as<uint16_t>(), t.Gv, d.cols, t.list_runs.as<int32_t>(), t.n_runs, vp, stream));
-    }
-    OMR_HIP(launch_stddev(vp, hp, d, use_runs ? t.mode.as<int32_t>() : nullptr, s.vpart.as<uint16_t>(), t.Gv,
-                          s.hpart.as<uint16_t>(), t.Gh, vs, hs, stream));
+    OMR_HIP(launch_stddev(vp, hp, d, use_runs ? t.mode.as<int32_t>() : nullptr, s.hpart.as<uint16_t>(), t.Gh, vs, hs,
+                          stream));
     if (d_best) OMR_HIP(launch_argmax_path1(vs, hs, d.A, d_best, stream));
     return OMR_OK;
 }

@@ -53,11 +53,11 @@ struct SweepTables {
     bool lds_ok = false;
     int max_rows_per_tile = 0;
     std::vector<double> host_minv;
-    // run-merging ("S") kernels: transposed-pass tables, per-(candidate, word) run tables, and the
-    // split of the candidates into run-merged ones and ones left to the gather kernels
+    // run-merging ("S") kernel: per-(candidate, word) run tables and the split of the candidates
+    // into run-merged ones and ones left to the gather kernels
     bool runs_built = false;
-    int wprT = 0, NWh = 0, NWv = 0, Gh = 0, Gv = 0;
-    DevBuf rtv, cav, cbv, tabsH, metaH, tabsV, metaV, list_runs, list_gather, mode;
+    int NWh = 0, Gh = 0;
+    DevBuf tabsH, metaH, list_runs, list_gather, mode;
     int n_runs = 0, n_gather = 0;
     std::vector<int32_t> host_mode;
     int create(int rows, int cols, const double *fwd_M, int A, int device);
@@ -67,7 +67,7 @@ struct SweepTables {
 // Mutable per-stream scratch: bit image, integer projections, scores.
 struct SweepScratch {
     DevBuf bits, vproj, hproj, vsd, hsd, best;
-    DevBuf bitsT, hpart, vpart, guard;  // run-merging scratch
+    DevBuf hpart, guard;  // run-merging scratch: u16 row-count partials per word group
     int create(const SweepTables &t);
 };
 

@@ -348,11 +348,12 @@ hipError_t launch_sweep_lds(const uint32_t *d_bits, SweepDims d, const int32_t *
 __global__ __launch_bounds__(SD_THREADS) void stddev_kernel(const uint32_t *__restrict__ vproj,
                                                             const uint32_t *__restrict__ hproj, SweepDims d,
                                                             const int32_t *__restrict__ mode,
-                                                            const uint16_t *__restrict__ vpart, int Gv,
                                                             const uint16_t *__restrict__ hpart, int Gh,
                                                             double *__restrict__ v_sd, double *__restrict__ h_sd)
 {
-    __shared__ double sq[SD_CHUNK];
+    extern __shared__ __attribute__((aligned(16))) char sd_lds[];
+    double *sq = (double *)sd_lds;                                    // SD_CHUNK squared deviations
+    uint16_t *val = (uint16_t *)(sd_lds + SD_CHUNK * sizeof(double));  // the n counts (each < 32767)
     __shared__ unsigned long long part[SD_THREADS / OMR_WAVE];
     __shared__ double mean_s;
     const int a = blockIdx.x >> 1;
@@ -360,18 +361,22 @@ __global__ __launch_bounds__(SD_THREADS) void stddev_kernel(const uint32_t *__re
     const int n = axis ? d.rows : d.cols;
     const uint32_t *__restrict__ p = axis ? hproj + (int64_t)a * d.rows : vproj + (int64_t)a * d.cols;
     // run-merged candidates deliver their counts as G partial u16 vectors (exact integers either way)
-    const bool parts = mode && mode[a] != 0;
-    const int G = axis ? Gh : Gv;
-    const uint16_t *__restrict__ q = axis ? hpart + (int64_t)a * Gh * d.rows : vpart + (int64_t)a * Gv * d.cols;
-    auto value = [&](int i) -> uint32_t {
-        if (!parts) return p[i];
-        uint32_t t = 0;
-        for (int g = 0; g < G; g++) t += q[(int64_t)g * n + i];
-        return t;
-    };
+    const bool parts = axis == 1 && mode && mode[a] != 0;
+    const int G = Gh;
+    const uint16_t *__restrict__ q = hpart + (int64_t)a * Gh * d.rows;
 
+    // pass 1: the counts, once, into LDS; their integer total
     unsigned long long s = 0;
-    for (int i = threadIdx.x; i < n; i += SD_THREADS) s += value(i);
+    for (int i = threadIdx.x; i < n; i += SD_THREADS) {
+        uint32_t t = 0;
+        if (parts) {
+            for (int g = 0; g < G; g++) t += q[(int64_t)g * n + i];
+        } else {
+            t = p[i];
+        }
+        val[i] = (uint16_t)t;
+        s += t;
+    }
     for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
     __syncthreads();
@@ -386,20 +391,35 @@ __global__ __launch_bounds__(SD_THREADS) void stddev_kernel(const uint32_t *__re
     for (int base = 0; base < n; base += SD_CHUNK) {
         const int m = min(SD_CHUNK, n - base);
         for (int i = threadIdx.x; i < m; i += SD_THREADS) {
-            const double dv = (double)value(base + i) - mean;
+            const double dv = (double)val[base + i] - mean;
             sq[i] = dv * dv;
         }
         __syncthreads();
         if (threadIdx.x == 0) {
-            // the adds form one dependent chain (that order IS the specification); keep 16 LDS
-            // reads in flight ahead of it so the chain runs at f64-add latency, not LDS latency
+            // the adds form one dependent chain (that order IS the specification); two batches of 16
+            // LDS reads are kept in flight so the chain runs at f64-add latency, not LDS latency
             int i = 0;
-            for (; i + 16 <= m; i += 16) {
-                double t[16];
+            double t0[16], t1[16];
+            if (m >= 16) {
 #pragma unroll
-                for (int j = 0; j < 16; j++) t[j] = sq[i + j];
+                for (int j = 0; j < 16; j++) t0[j] = sq[j];
+            }
+            for (; i + 32 <= m; i += 32) {
 #pragma unroll
-                for (int j = 0; j < 16; j++) acc = acc + t[j];
+                for (int j = 0; j < 16; j++) t1[j] = sq[i + 16 + j];
+#pragma unroll
+                for (int j = 0; j < 16; j++) acc = acc + t0[j];
+                if (i + 48 <= m) {
+#pragma unroll
+                    for (int j = 0; j < 16; j++) t0[j] = sq[i + 32 + j];
+                }
+#pragma unroll
+                for (int j = 0; j < 16; j++) acc = acc + t1[j];
+            }
+            if (i + 16 <= m) {  // t0 holds sq[i .. i+15]
+#pragma unroll
+                for (int j = 0; j < 16; j++) acc = acc + t0[j];
+                i += 16;
             }
             for (; i < m; i++) acc = acc + sq[i];
         }
@@ -413,12 +433,13 @@ __global__ __launch_bounds__(SD_THREADS) void stddev_kernel(const uint32_t *__re
 }
 
 hipError_t launch_stddev(const uint32_t *d_vproj, const uint32_t *d_hproj, SweepDims d, const int32_t *d_mode,
-                         const uint16_t *d_vpart, int Gv, const uint16_t *d_hpart, int Gh, double *d_v_sd,
-                         double *d_h_sd, hipStream_t s)
+                         const uint16_t *d_hpart, int Gh, double *d_v_sd, double *d_h_sd, hipStream_t s)
 {
     if (d.A <= 0) return hipSuccess;
-    hipLaunchKernelGGL(stddev_kernel, dim3(2 * d.A), dim3(SD_THREADS), 0, s, d_vproj, d_hproj, d, d_mode, d_vpart, Gv,
-                       d_hpart, Gh, d_v_sd, d_h_sd);
+    const int n = d.rows > d.cols ? d.rows : d.cols;
+    const size_t lds = SD_CHUNK * sizeof(double) + (((size_t)n * 2 + 15) & ~(size_t)15);
+    hipLaunchKernelGGL(stddev_kernel, dim3(2 * d.A), dim3(SD_THREADS), lds, s, d_vproj, d_hproj, d, d_mode, d_hpart, Gh,
+                       d_v_sd, d_h_sd);
     return hipGetLastError();
 }
 

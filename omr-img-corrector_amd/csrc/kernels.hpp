@@ -48,11 +48,9 @@ hipError_t launch_sweep_lds(const uint32_t *d_bits, SweepDims d, const int32_t *
                             hipStream_t s);
 
 // ---- run-merging ("S") sweep ---------------------------------------------------------------
-// One pass counts, for every destination row r of every listed candidate, the black samples
-//     sum_c src[(RT[r].y + CB[c]) >> 10][(RT[r].x + CA[c]) >> 10]
-// 32 destination columns at a time.  Pass H (row counts): RT = (X0,Y0), CA = adelta, CB = bdelta,
-// src = bit image.  Pass V (column counts) is the same sum on the TRANSPOSED bit image with the
-// roles of the tables swapped: RT = (bdelta, adelta), CA = Y0, CB = X0.
+// For every listed candidate the kernel builds 32 destination pixels at a time,
+//     bit(r, c) = src[(RT[r].y + CB[c]) >> 10][(RT[r].x + CA[c]) >> 10],   RT = (X0, Y0), CA = adelta, CB = bdelta,
+// and counts them per destination row and per destination column.
 #define OMR_RUN_TUPLES 40
 #ifndef OMR_RUN_K
 #define OMR_RUN_K 8  // destination words per run-merging block (partials are per group of OMR_RUN_K words)
@@ -85,24 +83,23 @@ struct RunPass {  // one orientation
     int32_t G;
     int32_t dbg;          // development switches (0 in production)
 };
-hipError_t launch_transpose_bits(const uint32_t *d_bits, int rows, int cols, int wpr, uint32_t *d_bitsT, int wprT,
-                                 hipStream_t s);
-hipError_t launch_vtables(SweepDims d, const int32_t *d_adelta, const int32_t *d_bdelta, const int2_t *d_xy0,
-                          int2_t *d_rtv, int32_t *d_cav, int32_t *d_cbv, hipStream_t s);
 hipError_t launch_runtab(const int32_t *d_CA, const int32_t *d_CB, int A, int NC, int NW, RunTab *d_tabs,
                          RunMeta *d_meta, hipStream_t s);
 // d_list: n_list candidate indices; d_guard[a] != 0 when a window did not fit for candidate a.
-hipError_t launch_runs(const RunPass &ph, const RunPass &pv, const int32_t *d_list, int n_list, int32_t *d_guard,
+// Row counts go to p.part (u16 partials per word group), column counts to d_vproj[a][NC] (complete,
+// plain stores).
+hipError_t launch_runs(const RunPass &p, const int32_t *d_list, int n_list, int32_t *d_guard, uint32_t *d_vproj,
                        hipStream_t s);
 // vproj/hproj (u32) += partial counts of the listed candidates (only when the caller wants them)
 hipError_t launch_fold_parts(const uint16_t *d_part, int G, int NR, const int32_t *d_list, int n_list,
                              uint32_t *d_proj, hipStream_t s);
 
 // calculate.rs:13-23 on the integer projections: one block per (candidate, axis).
-// d_mode (may be NULL): per candidate, != 0 -> read the run-merging partials instead of vproj/hproj.
+// d_mode (may be NULL): per candidate, != 0 -> its row counts are the run-merging kernel's u16
+// partials (d_hpart, Gh vectors per candidate) instead of d_hproj; column counts are always d_vproj.
 hipError_t launch_stddev(const uint32_t *d_vproj, const uint32_t *d_hproj, SweepDims d,
-                         const int32_t *d_mode, const uint16_t *d_vpart, int Gv, const uint16_t *d_hpart, int Gh,
-                         double *d_v_sd, double *d_h_sd, hipStream_t s);
+                         const int32_t *d_mode, const uint16_t *d_hpart, int Gh, double *d_v_sd, double *d_h_sd,
+                         hipStream_t s);
 
 // projection.rs:125-190 arg-max (lowest index on exact ties).
 hipError_t launch_argmax_path1(const double *d_v_sd, const double *d_h_sd, int A, int32_t *d_best,

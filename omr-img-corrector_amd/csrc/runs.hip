@@ -43,70 +43,6 @@ static_assert(sizeof(RunTab) == RUN_TAB_BYTES, "RunTab layout");
 static_assert(sizeof(RunMeta) == 32, "RunMeta layout");
 
 // ------------------------------------------------------------------------------------------
-// bit-matrix transpose: bitsT[x][y] = bits[y][x].  One wave = 64 source rows x 32 columns.
-__global__ __launch_bounds__(256) void transpose_bits_kernel(const uint32_t *__restrict__ bits, int rows, int cols,
-                                                             int wpr, uint32_t *__restrict__ bitsT, int wprT)
-{
-    const int lane = threadIdx.x & 63;
-    const int w = blockIdx.x;                                   // source word column
-    const int y0 = (blockIdx.y * 4 + (threadIdx.x >> 6)) * 64;  // first source row of this wave
-    if (y0 >= wprT * 32) return;
-    const int y = y0 + lane;
-    const uint32_t word = (y < rows) ? bits[(int64_t)y * wpr + w] : 0u;
-    unsigned long long mine = 0;
-#pragma unroll
-    for (int c = 0; c < 32; c++) {
-        const unsigned long long m = __ballot((word >> c) & 1u);
-        if (lane == c) mine = m;
-    }
-    const int x = w * 32 + lane;
-    if (lane < 32 && x < cols) {
-        const int wy = y0 >> 5;
-        uint32_t *o = bitsT + (int64_t)x * wprT + wy;
-        if (wy < wprT) o[0] = (uint32_t)mine;
-        if (wy + 1 < wprT) o[1] = (uint32_t)(mine >> 32);
-    }
-}
-
-hipError_t launch_transpose_bits(const uint32_t *d_bits, int rows, int cols, int wpr, uint32_t *d_bitsT, int wprT,
-                                 hipStream_t s)
-{
-    dim3 grid((cols + 31) / 32, (wprT * 32 + 255) / 256);
-    hipLaunchKernelGGL(transpose_bits_kernel, grid, dim3(256), 0, s, d_bits, rows, cols, wpr, d_bitsT, wprT);
-    return hipGetLastError();
-}
-
-// ------------------------------------------------------------------------------------------
-// Tables of the transposed pass: RT_V[x] = (bdelta[x], adelta[x]), CA_V[y] = Y0[y], CB_V[y] = X0[y].
-__global__ __launch_bounds__(256) void vtables_kernel(SweepDims d, const int32_t *__restrict__ adelta,
-                                                      const int32_t *__restrict__ bdelta,
-                                                      const int2_t *__restrict__ xy0, int2_t *__restrict__ rtv,
-                                                      int32_t *__restrict__ cav, int32_t *__restrict__ cbv)
-{
-    const int a = blockIdx.y;
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < d.cols) {
-        int2_t v;
-        v.x = bdelta[(int64_t)a * d.cols + i];
-        v.y = adelta[(int64_t)a * d.cols + i];
-        rtv[(int64_t)a * d.cols + i] = v;
-    } else if (i - d.cols < d.rows) {
-        const int y = i - d.cols;
-        const int2_t s0 = xy0[(int64_t)a * d.rows + y];
-        cav[(int64_t)a * d.rows + y] = s0.y;
-        cbv[(int64_t)a * d.rows + y] = s0.x;
-    }
-}
-
-hipError_t launch_vtables(SweepDims d, const int32_t *d_adelta, const int32_t *d_bdelta, const int2_t *d_xy0,
-                          int2_t *d_rtv, int32_t *d_cav, int32_t *d_cbv, hipStream_t s)
-{
-    dim3 grid((d.cols + d.rows + 255) / 256, d.A);
-    hipLaunchKernelGGL(vtables_kernel, grid, dim3(256), 0, s, d, d_adelta, d_bdelta, d_xy0, d_rtv, d_cav, d_cbv);
-    return hipGetLastError();
-}
-
-// ------------------------------------------------------------------------------------------
 // RunTab builder: block = one (candidate, word), thread = one 10-bit fraction f.
 __device__ __forceinline__ int block_dedupe_1024(bool change, int *s_wave)
 {
@@ -244,15 +180,32 @@ hipError_t launch_runtab(const int32_t *d_CA, const int32_t *d_CB, int A, int NC
 }
 
 // ------------------------------------------------------------------------------------------
-// The pass kernel.  Block = (candidate, group of RUN_K words); it walks all destination rows in
-// bands of 512 (8 waves x 64 lanes, lane = destination row).
+// The sweep kernel.  Block = (candidate, group of RUN_K words = 256 destination columns); it walks
+// ALL destination rows in bands of 512 (8 waves x 64 lanes, lane = destination row).
+//   row counts   : popcount of the lane's words, one u16 partial per (row, word group)
+//   column counts: every lane keeps a 3-plane bit-sliced counter per word (its rows of up to 7
+//                  bands); the counters are reduced across the 64 lanes with one
+//                  v_add_co_u32 (shift + carry-out = ballot of the top bit) and one s_bcnt1 per bit,
+//                  added up in LDS over the 8 waves and stored once per block (no atomics).
 __device__ __forceinline__ uint32_t lds_u8(const char *lds, int ofs) { return *(const uint8_t *)(lds + ofs); }
 
-// The words of one band for one wave (lane = destination row).  NLEV / SMAX are uniform for the
-// whole block (maxima over its words; unused levels have empty masks), so the block dispatches
-// once per band to a straight-line specialisation.  Two words are in flight together: both
-// fraction look-ups and all 2 x NLEV window reads are issued before anything is consumed, which is
-// what hides the LDS latency at 4 waves per SIMD.
+template <int LANE>
+__device__ __forceinline__ uint32_t write_lane_imm(uint32_t vreg, uint32_t value)
+{
+    asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(vreg) : "s"(value), "n"(LANE));
+    return vreg;
+}
+
+// x <<= 1 and the number of lanes whose top bit was set, in one VALU + one SALU instruction
+__device__ __forceinline__ uint32_t shl1_count(uint32_t &x)
+{
+    uint32_t n;
+    unsigned long long m;
+    asm volatile("v_add_co_u32_e64 %0, %1, %0, %0\n\ts_bcnt1_i32_b64 %2, %1" : "+v"(x), "=&s"(m), "=s"(n) : : "scc");
+    return n;
+}
+
+// one word: NLEV unaligned 32-bit windows -> destination word
 template <int NLEV, int SMAX>
 __device__ __forceinline__ uint32_t merge_word(const uint32_t *d0, const uint32_t *d1, const uint32_t sh,
                                                const uint4 s03, const uint4 s47, const uint2 sx)
@@ -270,17 +223,25 @@ __device__ __forceinline__ uint32_t merge_word(const uint32_t *d0, const uint32_
     return D;
 }
 
+// The RUN_K words of one band for one wave.  NLEV / SMAX are uniform for the whole block (maxima
+// over its words; unused levels have empty masks), so the block dispatches once per band to a
+// straight-line specialisation.  Words are processed two at a time: both fraction look-ups and all
+// 2 x NLEV window reads are issued before anything is consumed (LDS latency hiding at 4 waves per
+// SIMD).  Words past the end of the row are exact copies of the last real word with an empty mask.
 template <int NLEV, int SMAX>
-__device__ __forceinline__ uint32_t band_words(const char *lds, const int kw, const int rx, const int ry,
-                                               const uint32_t valid_last)
+__device__ __forceinline__ uint32_t band_words(const char *lds, const int rx, const int ry, const int kw,
+                                               const uint32_t valid_last, const uint32_t lane_ok,
+                                               uint32_t (&c0)[RUN_K], uint32_t (&c1)[RUN_K], uint32_t (&c2)[RUN_K])
 {
     uint32_t cnt = 0;
-#pragma unroll 1
-    for (int k = 0; k < kw; k += 2) {
-        const int ka = k, kb = min(k + 1, kw - 1);  // odd tail: word b repeats word a and is dropped
-        const int2 ma = *(const int2 *)(lds + RUN_META_OFS + ka * 8);  // same address in every lane
-        const int2 mb = *(const int2 *)(lds + RUN_META_OFS + kb * 8);
-        const int ta = RUN_TABS_OFS + ka * RUN_TAB_BYTES, tb = RUN_TABS_OFS + kb * RUN_TAB_BYTES;
+#pragma unroll
+    for (int k = 0; k < RUN_K; k += 2) {
+        // keep the pairs apart: without this fence the scheduler hoists all four pairs' loads and the
+        // kernel needs 180 VGPRs (2 waves per SIMD instead of 4)
+        __builtin_amdgcn_sched_barrier(0);
+        const int2 ma = *(const int2 *)(lds + RUN_META_OFS + k * 8);  // same address in every lane
+        const int2 mb = *(const int2 *)(lds + RUN_META_OFS + (k + 1) * 8);
+        const int ta = RUN_TABS_OFS + k * RUN_TAB_BYTES, tb = ta + RUN_TAB_BYTES;
         const int A0a = rx + ma.x, B0a = ry + ma.y, A0b = rx + mb.x, B0b = ry + mb.y;
         const uint32_t idya = lds_u8(lds, ta + RUN_IDXY_OFS + (B0a & 1023));
         const uint32_t idyb = lds_u8(lds, tb + RUN_IDXY_OFS + (B0b & 1023));
@@ -312,30 +273,65 @@ __device__ __forceinline__ uint32_t band_words(const char *lds, const int kw, co
             sxa = *(const uint2 *)(lds + ta + RUN_TUPX_OFS + (idxa << 3));
             sxb = *(const uint2 *)(lds + tb + RUN_TUPX_OFS + (idxb << 3));
         }
-        uint32_t Da = merge_word<NLEV, SMAX>(a0, a1, (uint32_t)(A0a >> 10), sa03, sa47, sxa);
-        uint32_t Db = merge_word<NLEV, SMAX>(b0, b1, (uint32_t)(A0b >> 10), sb03, sb47, sxb);
-        if (ka == kw - 1) Da &= valid_last;
-        if (kb == kw - 1) Db &= valid_last;
-        cnt += __popc(Da);
-        if (kb != ka) cnt += __popc(Db);
+        // word masks: everything for words before the row's last, `valid` for the last, nothing after
+        const uint32_t wma = k < kw - 1 ? 0xffffffffu : (k == kw - 1 ? valid_last : 0u);
+        const uint32_t wmb = k + 1 < kw - 1 ? 0xffffffffu : (k + 1 == kw - 1 ? valid_last : 0u);
+        const uint32_t Da = merge_word<NLEV, SMAX>(a0, a1, (uint32_t)(A0a >> 10), sa03, sa47, sxa) & wma & lane_ok;
+        const uint32_t Db = merge_word<NLEV, SMAX>(b0, b1, (uint32_t)(A0b >> 10), sb03, sb47, sxb) & wmb & lane_ok;
+        cnt += __popc(Da) + __popc(Db);
+        // bit-sliced add of a 1-bit value per column into the 3-plane counters (k is a constant after
+        // unrolling, so the counters stay in registers)
+#define RUN_ACC(KA)                        \
+    {                                      \
+        uint32_t t = c0[KA] & Da;          \
+        c2[KA] |= c1[KA] & t;              \
+        c1[KA] ^= t;                       \
+        c0[KA] ^= Da;                      \
+        t = c0[KA + 1] & Db;               \
+        c2[KA + 1] |= c1[KA + 1] & t;      \
+        c1[KA + 1] ^= t;                   \
+        c0[KA + 1] ^= Db;                  \
+    }
+        RUN_ACC(k)
+#undef RUN_ACC
     }
     return cnt;
 }
 
 template <int SMAX>
-__device__ __forceinline__ uint32_t band_words_s(const char *lds, const int kw, const int rx, const int ry,
-                                                 const uint32_t valid_last, const int nlev)
+__device__ __forceinline__ uint32_t band_words_s(const char *lds, const int rx, const int ry, const int kw,
+                                                 const uint32_t valid_last, const uint32_t lane_ok,
+                                                 uint32_t (&c0)[RUN_K], uint32_t (&c1)[RUN_K], uint32_t (&c2)[RUN_K],
+                                                 const int nlev)
 {
     switch (nlev) {
-    case 1: return band_words<1, SMAX>(lds, kw, rx, ry, valid_last);
-    case 2: return band_words<2, SMAX>(lds, kw, rx, ry, valid_last);
-    case 3: return band_words<3, SMAX>(lds, kw, rx, ry, valid_last);
-    case 4: return band_words<4, SMAX>(lds, kw, rx, ry, valid_last);
-    case 5: return band_words<5, SMAX>(lds, kw, rx, ry, valid_last);
-    case 6: return band_words<6, SMAX>(lds, kw, rx, ry, valid_last);
-    case 7: return band_words<7, SMAX>(lds, kw, rx, ry, valid_last);
-    default: return band_words<8, SMAX>(lds, kw, rx, ry, valid_last);
+    case 1: return band_words<1, SMAX>(lds, rx, ry, kw, valid_last, lane_ok, c0, c1, c2);
+    case 2: return band_words<2, SMAX>(lds, rx, ry, kw, valid_last, lane_ok, c0, c1, c2);
+    case 3: return band_words<3, SMAX>(lds, rx, ry, kw, valid_last, lane_ok, c0, c1, c2);
+    case 4: return band_words<4, SMAX>(lds, rx, ry, kw, valid_last, lane_ok, c0, c1, c2);
+    case 5: return band_words<5, SMAX>(lds, rx, ry, kw, valid_last, lane_ok, c0, c1, c2);
+    case 6: return band_words<6, SMAX>(lds, rx, ry, kw, valid_last, lane_ok, c0, c1, c2);
+    case 7: return band_words<7, SMAX>(lds, rx, ry, kw, valid_last, lane_ok, c0, c1, c2);
+    default: return band_words<8, SMAX>(lds, rx, ry, kw, valid_last, lane_ok, c0, c1, c2);
     }
+}
+
+// Reduce one word's 3-plane counters over the 64 lanes and add the 32 column totals to colacc.
+// Columns come out most-significant bit first.
+__device__ __forceinline__ void flush_word(uint32_t p0, uint32_t p1, uint32_t p2, uint32_t *colacc, const int lane)
+{
+    uint32_t tot[32];
+#pragma unroll
+    for (int b = 31; b >= 0; b--) {
+        const uint32_t n0 = shl1_count(p0), n1 = shl1_count(p1), n2 = shl1_count(p2);
+        tot[b] = n0 + 2u * n1 + 4u * n2;
+    }
+    uint32_t v = 0;
+#define WL(B) v = write_lane_imm<B>(v, tot[B]);
+    WL(0) WL(1) WL(2) WL(3) WL(4) WL(5) WL(6) WL(7) WL(8) WL(9) WL(10) WL(11) WL(12) WL(13) WL(14) WL(15)
+    WL(16) WL(17) WL(18) WL(19) WL(20) WL(21) WL(22) WL(23) WL(24) WL(25) WL(26) WL(27) WL(28) WL(29) WL(30) WL(31)
+#undef WL
+    if (lane < 32 && v) atomicAdd(&colacc[lane], v);
 }
 
 struct RunGeom {  // source window of one band (wave-uniform)
@@ -343,37 +339,37 @@ struct RunGeom {  // source window of one band (wave-uniform)
     bool fits;
 };
 
-// blockIdx.z selects the projection: 0 = row counts on the bit image, 1 = column counts on the
-// transposed bit image.  Both run in ONE launch so their tails overlap.
-__global__ __launch_bounds__(RUN_BAND) void runs_kernel(const RunPass ph, const RunPass pv,
-                                                        const int32_t *__restrict__ list,
-                                                        int32_t *__restrict__ guard)
+#define RUN_FLUSH_BANDS 7  // 3-plane counters hold up to 7 rows per lane
+
+__global__ __launch_bounds__(RUN_BAND, 4) void runs_kernel(const RunPass p, const int32_t *__restrict__ list,
+                                                        int32_t *__restrict__ guard, uint32_t *__restrict__ vproj)
 {
     extern __shared__ __attribute__((aligned(16))) char lds[];
-    const RunPass &p = blockIdx.z ? pv : ph;
+    __shared__ uint32_t colacc[RUN_K * 32];
     const int a = __builtin_amdgcn_readfirstlane(list[blockIdx.y]);
     const int g = blockIdx.x;
-    if (g >= p.G) return;
     const int w0 = g * RUN_K;
     const int kw = min(RUN_K, p.NW - w0);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
-    // ---- stage the run tables of this block's words (16-byte copies)
+    // ---- stage the run tables of this block's words (16-byte copies; words past the end of the
+    //      row repeat the last real word so that every lane address stays meaningful)
     {
         const uint4 *src = (const uint4 *)(p.tabs + ((int64_t)a * p.NW + w0));
         uint4 *dst = (uint4 *)(lds + RUN_TABS_OFS);
-        const int n16 = kw * (RUN_TAB_BYTES / 16);
-        constexpr int TP = (RUN_K * (RUN_TAB_BYTES / 16) + RUN_BAND - 1) / RUN_BAND;  // 4 pieces per thread
+        constexpr int W16 = RUN_TAB_BYTES / 16;
+        constexpr int TP = (RUN_K * W16 + RUN_BAND - 1) / RUN_BAND;
         uint4 tv[TP];
 #pragma unroll
         for (int n = 0; n < TP; n++) {  // all loads in flight before the first LDS write
             const int i = tid + n * RUN_BAND;
-            tv[n] = i < n16 ? src[i] : make_uint4(0, 0, 0, 0);
+            const int k = i / W16, c = i - k * W16;
+            tv[n] = i < RUN_K * W16 ? src[min(k, kw - 1) * W16 + c] : make_uint4(0, 0, 0, 0);
         }
 #pragma unroll
         for (int n = 0; n < TP; n++) {
             const int i = tid + n * RUN_BAND;
-            if (i < n16) dst[i] = tv[n];
+            if (i < RUN_K * W16) dst[i] = tv[n];
         }
     }
     // block-uniform word constants: (ca0, cb0) pairs go to LDS (read back as a broadcast), the
@@ -385,7 +381,11 @@ __global__ __launch_bounds__(RUN_BAND) void runs_kernel(const RunPass ph, const 
         smax_blk = max(smax_blk, __builtin_amdgcn_readfirstlane(mt[k].smax));
     }
     const uint32_t valid_last = (uint32_t)__builtin_amdgcn_readfirstlane((int)mt[kw - 1].valid);
-    if (tid < kw) *(int2 *)(lds + RUN_META_OFS + tid * 8) = make_int2(mt[tid].ca0, mt[tid].cb0);
+    if (tid < RUN_K) {
+        const int kk = min(tid, kw - 1);
+        *(int2 *)(lds + RUN_META_OFS + tid * 8) = make_int2(mt[kk].ca0, mt[kk].cb0);
+    }
+    if (tid < RUN_K * 32) colacc[tid] = 0;
     const int2_t *__restrict__ RT = p.RT + (int64_t)a * p.NR;
     const int32_t *__restrict__ CA = p.CA + (int64_t)a * p.NC;
     const int32_t *__restrict__ CB = p.CB + (int64_t)a * p.NC;
@@ -421,15 +421,12 @@ __global__ __launch_bounds__(RUN_BAND) void runs_kernel(const RunPass ph, const 
     // overlaps the compute of band b and every wave carries the same share.  A thread's pieces sit
     // at the same window positions in every band: their row / word / LDS offsets are computed once.
     constexpr int PIECES = (RUN_WIN_ROWS * RUN_QUADS + RUN_BAND - 1) / RUN_BAND;
-    int pc_row[PIECES], pc_w4[PIECES], pc_lds[PIECES];
-    int64_t pc_src[PIECES];
+    int pc_rw[PIECES];  // window row | first word << 16 of the thread's n-th piece
 #pragma unroll
     for (int n = 0; n < PIECES; n++) {
         const int i = tid + n * RUN_BAND;
-        pc_row[n] = i / RUN_QUADS;
-        pc_w4[n] = 4 * (i - pc_row[n] * RUN_QUADS);
-        pc_lds[n] = RUN_WIN_OFS + pc_row[n] * RUN_PITCHB + pc_w4[n] * 4;
-        pc_src[n] = (int64_t)pc_row[n] * p.src_wpr + pc_w4[n];
+        const int row = i / RUN_QUADS;
+        pc_rw[n] = row | ((4 * (i - row * RUN_QUADS)) << 16);
     }
     uint4 pre[PIECES];
     auto prefetch = [&](const RunGeom &q) {
@@ -438,35 +435,42 @@ __global__ __launch_bounds__(RUN_BAND) void runs_kernel(const RunPass ph, const 
         const int w_lo = -q.wxw, w_hi = p.src_wpr - q.wxw - 3;                 // 4-word pieces inside a row
 #pragma unroll
         for (int n = 0; n < PIECES; n++) {
+            const int row = pc_rw[n] & 0xffff, w4 = pc_rw[n] >> 16;
             uint4 v = make_uint4(0, 0, 0, 0);
-            if (q.fits && pc_row[n] >= row_lo && pc_row[n] < row_hi && pc_w4[n] >= w_lo && pc_w4[n] < w_hi)
-                v = *(const uint4 *)(base + pc_src[n]);
+            if (q.fits && row >= row_lo && row < row_hi && w4 >= w_lo && w4 < w_hi)
+                v = *(const uint4 *)(base + (row * p.src_wpr + w4));
             pre[n] = v;
         }
     };
     auto commit = [&](const RunGeom &q) {
 #pragma unroll
         for (int n = 0; n < PIECES; n++) {
-            if (pc_row[n] < q.nrows) {
-                uint32_t *d = (uint32_t *)(lds + pc_lds[n]);
+            const int row = pc_rw[n] & 0xffff, w4 = pc_rw[n] >> 16;
+            if (row < q.nrows) {
+                uint32_t *d = (uint32_t *)(lds + RUN_WIN_OFS + row * RUN_PITCHB + w4 * 4);
                 d[0] = pre[n].x;
                 d[1] = pre[n].y;
                 d[2] = pre[n].z;
                 d[3] = pre[n].w;
-                if (pc_w4[n] == 4 * (RUN_QUADS - 1)) d[4] = 0;  // spill word
+                if (w4 == 4 * (RUN_QUADS - 1)) d[4] = 0;  // spill word
             }
         }
     };
 
-    int2_t c0, c1;
-    corners(0, c0, c1);
-    RunGeom cur = geometry(c0, c1);
+    uint32_t c0[RUN_K], c1[RUN_K], c2[RUN_K];
+#pragma unroll
+    for (int k = 0; k < RUN_K; k++) c0[k] = c1[k] = c2[k] = 0;
+
+    int2_t cn0, cn1;
+    corners(0, cn0, cn1);
+    RunGeom cur = geometry(cn0, cn1);
     prefetch(cur);
-    corners(RUN_BAND, c0, c1);  // next band's corners: in flight until the end of the first iteration
+    corners(RUN_BAND, cn0, cn1);  // next band's corners: in flight until the end of the first iteration
     int2_t rt = RT[min(wave * 64 + lane, p.NR - 1)];
+    int bands_pending = 0;
     for (int yb = 0; yb < p.NR; yb += RUN_BAND) {
         const int r = yb + wave * 64 + lane;
-        __syncthreads();  // previous band's readers are done (first pass: tables and meta staged)
+        __syncthreads();  // previous band's readers are done (first pass: tables, meta, colacc staged)
         if (cur.fits) {
             if (!(p.dbg & 2)) commit(cur);
         } else if (tid == 0) {
@@ -476,38 +480,52 @@ __global__ __launch_bounds__(RUN_BAND) void runs_kernel(const RunPass ph, const 
         const RunGeom now = cur;
         const int2_t rt_now = rt;
         if (yb + RUN_BAND < p.NR) {
-            cur = geometry(c0, c1);
+            cur = geometry(cn0, cn1);
             if (!(p.dbg & 2)) prefetch(cur);
-            corners(yb + 2 * RUN_BAND, c0, c1);
+            corners(yb + 2 * RUN_BAND, cn0, cn1);
             rt = RT[min(r + RUN_BAND, p.NR - 1)];
         }
         if (now.fits && yb + wave * 64 < p.NR && !(p.dbg & 1)) {
             const int rx = rt_now.x - (now.wxw << 15);  // window-local fixed point
             const int ry = rt_now.y - (now.wy0 << 10);
+            const uint32_t lane_ok = r < p.NR ? 0xffffffffu : 0u;  // rows past the end count nothing
             uint32_t cnt = 0;
-            if (smax_blk == 1) cnt = band_words_s<1>(lds, kw, rx, ry, valid_last, nlev_blk);
-            else if (smax_blk == 0) cnt = band_words_s<0>(lds, kw, rx, ry, valid_last, nlev_blk);
-            else cnt = band_words_s<2>(lds, kw, rx, ry, valid_last, nlev_blk);
+            if (smax_blk == 1) cnt = band_words_s<1>(lds, rx, ry, kw, valid_last, lane_ok, c0, c1, c2, nlev_blk);
+            else if (smax_blk == 0) cnt = band_words_s<0>(lds, rx, ry, kw, valid_last, lane_ok, c0, c1, c2, nlev_blk);
+            else cnt = band_words_s<2>(lds, rx, ry, kw, valid_last, lane_ok, c0, c1, c2, nlev_blk);
             if (r < p.NR) out[r] = (uint16_t)cnt;
         }
+        // the 3-plane counters hold at most 7 rows per lane: reduce them across lanes in time
+        if (++bands_pending == RUN_FLUSH_BANDS || yb + RUN_BAND >= p.NR) {
+            bands_pending = 0;
+            if (!(p.dbg & 4)) {
+#pragma unroll
+                for (int k = 0; k < RUN_K; k++) {
+                    flush_word(c0[k], c1[k], c2[k], colacc + k * 32, lane);
+                    c0[k] = c1[k] = c2[k] = 0;
+                }
+            }
+        }
     }
+    __syncthreads();
+    // column counts of this block's (up to) 256 columns over ALL rows: one plain store each
+    if (tid < RUN_K * 32 && c_first + tid < p.NC) vproj[(int64_t)a * p.NC + c_first + tid] = colacc[tid];
 }
 
-hipError_t launch_runs(const RunPass &ph0, const RunPass &pv0, const int32_t *d_list, int n_list, int32_t *d_guard,
+hipError_t launch_runs(const RunPass &p0, const int32_t *d_list, int n_list, int32_t *d_guard, uint32_t *d_vproj,
                        hipStream_t s)
 {
     if (n_list <= 0) return hipSuccess;
-    RunPass ph = ph0, pv = pv0;
+    RunPass p = p0;
     {
         const char *e = getenv("OMR_RUNS_DBG");
-        ph.dbg = pv.dbg = e ? atoi(e) : 0;
+        p.dbg = e ? atoi(e) : 0;
     }
     // per device and idempotent; cheap enough to repeat (the batch entry points use every device)
     hipError_t e = hipFuncSetAttribute((const void *)runs_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                        RUN_LDS_BYTES);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(runs_kernel, dim3(ph.G > pv.G ? ph.G : pv.G, n_list, 2), dim3(RUN_BAND), RUN_LDS_BYTES, s, ph,
-                       pv, d_list, d_guard);
+    hipLaunchKernelGGL(runs_kernel, dim3(p.G, n_list), dim3(RUN_BAND), RUN_LDS_BYTES, s, p, d_list, d_guard, d_vproj);
     return hipGetLastError();
 }
 
