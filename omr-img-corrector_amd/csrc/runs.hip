@@ -27,7 +27,7 @@ namespace omr {
 #define RUN_QUADS ((RUN_K * 32 + 127 + 96) / 128 + 2)  // aligned 4-word pieces per window row
 #define RUN_PITCH (RUN_QUADS * 4 + 1)  // window row pitch in words (data words + 1 spill word), odd
 #define RUN_PITCHB (RUN_PITCH * 4)
-#define RUN_WIN_ROWS 576
+#define RUN_WIN_ROWS 588   // window rows; 588 x 84 B also holds the 8 x 3 x 512 counter words of a flush
 #define RUN_TAB_BYTES 3648
 #define RUN_TUPX_OFS 1280
 #define RUN_IDXY_OFS 1600
@@ -196,12 +196,36 @@ __device__ __forceinline__ uint32_t write_lane_imm(uint32_t vreg, uint32_t value
     return vreg;
 }
 
-// x <<= 1 and the number of lanes whose top bit was set, in one VALU + one SALU instruction
-__device__ __forceinline__ uint32_t shl1_count(uint32_t &x)
+// Six bit planes of a bit-sliced per-lane number: shift every plane left by one (v_add_co_u32: the
+// carry-out mask IS the ballot of the old top bit), count the carries (s_bcnt1) and return
+// sum_j count_j << j, i.e. the sum over the 64 lanes of the column held in the top bit.  The six
+// VALU adds issue back to back, so their VALU->SGPR latency is overlapped.
+__device__ __forceinline__ uint32_t shl1_sum6(uint32_t &p0, uint32_t &p1, uint32_t &p2, uint32_t &p3, uint32_t &p4,
+                                              uint32_t &p5)
 {
-    uint32_t n;
-    unsigned long long m;
-    asm volatile("v_add_co_u32_e64 %0, %1, %0, %0\n\ts_bcnt1_i32_b64 %2, %1" : "+v"(x), "=&s"(m), "=s"(n) : : "scc");
+    uint32_t n, t;
+    unsigned long long m0, m1, m2, m3, m4, m5;
+    asm("v_add_co_u32_e64 %0, %8, %0, %0\n\t"
+        "v_add_co_u32_e64 %1, %9, %1, %1\n\t"
+        "v_add_co_u32_e64 %2, %10, %2, %2\n\t"
+        "v_add_co_u32_e64 %3, %11, %3, %3\n\t"
+        "v_add_co_u32_e64 %4, %12, %4, %4\n\t"
+        "v_add_co_u32_e64 %5, %13, %5, %5\n\t"
+        "s_bcnt1_i32_b64 %6, %13\n\t"
+        "s_bcnt1_i32_b64 %7, %12\n\t"
+        "s_lshl1_add_u32 %6, %6, %7\n\t"
+        "s_bcnt1_i32_b64 %7, %11\n\t"
+        "s_lshl1_add_u32 %6, %6, %7\n\t"
+        "s_bcnt1_i32_b64 %7, %10\n\t"
+        "s_lshl1_add_u32 %6, %6, %7\n\t"
+        "s_bcnt1_i32_b64 %7, %9\n\t"
+        "s_lshl1_add_u32 %6, %6, %7\n\t"
+        "s_bcnt1_i32_b64 %7, %8\n\t"
+        "s_lshl1_add_u32 %6, %6, %7"
+        : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3), "+v"(p4), "+v"(p5), "=&s"(n), "=&s"(t), "=&s"(m0), "=&s"(m1),
+          "=&s"(m2), "=&s"(m3), "=&s"(m4), "=&s"(m5)
+        :
+        : "scc");
     return n;
 }
 
@@ -316,22 +340,65 @@ __device__ __forceinline__ uint32_t band_words_s(const char *lds, const int rx, 
     }
 }
 
-// Reduce one word's 3-plane counters over the 64 lanes and add the 32 column totals to colacc.
-// Columns come out most-significant bit first.
-__device__ __forceinline__ void flush_word(uint32_t p0, uint32_t p1, uint32_t p2, uint32_t *colacc, const int lane)
+// Column counts of one word group: every lane holds a 3-plane bit-sliced counter per word (its rows
+// of the last <= 7 bands).  All 512 lanes park their counters in LDS (the window region is free
+// between bands); wave w then owns word w: it adds the 8 waves' counters lane-wise into a 6-plane
+// number (bit-sliced ripple adds), sums that over its 64 lanes with shl1_sum6 -- one column per
+// step, most significant bit first -- and adds the 32 column totals to colacc.
+// (reduce_columns is deliberately NOT inlined: its 32 scalar totals and asm temporaries would
+// otherwise raise the register pressure of the band loop, which runs at exactly 128 VGPRs.)
+__device__ __noinline__ void reduce_columns(const char *lds, uint32_t *colacc, const int tid)
 {
+    const uint32_t *park = (const uint32_t *)(lds + RUN_WIN_OFS);  // [word][plane][512 lanes]
+    const int lane = tid & 63, wave = tid >> 6;
+    const uint32_t *mine = park + (wave * 3) * RUN_BAND + lane;  // word `wave`
+    uint32_t s0 = mine[0], s1 = mine[RUN_BAND], s2 = mine[2 * RUN_BAND], s3 = 0, s4 = 0, s5 = 0;
+#pragma unroll
+    for (int wv = 1; wv < 8; wv++) {
+        const uint32_t x0 = mine[wv * 64], x1 = mine[RUN_BAND + wv * 64], x2 = mine[2 * RUN_BAND + wv * 64];
+        uint32_t c = s0 & x0;  // bit-sliced s += x
+        s0 ^= x0;
+        uint32_t t = s1 ^ x1 ^ c;
+        c = (s1 & x1) | (c & (s1 ^ x1));
+        s1 = t;
+        t = s2 ^ x2 ^ c;
+        c = (s2 & x2) | (c & (s2 ^ x2));
+        s2 = t;
+        t = s3 ^ c;
+        c &= s3;
+        s3 = t;
+        t = s4 ^ c;
+        c &= s4;
+        s4 = t;
+        s5 ^= c;
+    }
     uint32_t tot[32];
 #pragma unroll
-    for (int b = 31; b >= 0; b--) {
-        const uint32_t n0 = shl1_count(p0), n1 = shl1_count(p1), n2 = shl1_count(p2);
-        tot[b] = n0 + 2u * n1 + 4u * n2;
-    }
+    for (int b = 31; b >= 0; b--) tot[b] = shl1_sum6(s0, s1, s2, s3, s4, s5);
     uint32_t v = 0;
 #define WL(B) v = write_lane_imm<B>(v, tot[B]);
     WL(0) WL(1) WL(2) WL(3) WL(4) WL(5) WL(6) WL(7) WL(8) WL(9) WL(10) WL(11) WL(12) WL(13) WL(14) WL(15)
     WL(16) WL(17) WL(18) WL(19) WL(20) WL(21) WL(22) WL(23) WL(24) WL(25) WL(26) WL(27) WL(28) WL(29) WL(30) WL(31)
 #undef WL
-    if (lane < 32 && v) atomicAdd(&colacc[lane], v);
+    if (lane < 32) colacc[wave * 32 + lane] += v;  // only this wave touches word `wave`
+}
+
+__device__ __forceinline__ void flush_columns(char *lds, uint32_t (&c0)[RUN_K], uint32_t (&c1)[RUN_K],
+                                              uint32_t (&c2)[RUN_K], uint32_t *colacc, const int tid)
+{
+    static_assert(RUN_K == 8 && RUN_BAND == 512, "one wave per word");
+    static_assert(RUN_K * 3 * RUN_BAND * 4 <= RUN_WIN_ROWS * RUN_PITCHB, "counter scratch must fit the window");
+    uint32_t *park = (uint32_t *)(lds + RUN_WIN_OFS);  // [word][plane][512 lanes]
+    __syncthreads();  // every wave is done with the window of the last band
+#pragma unroll
+    for (int k = 0; k < RUN_K; k++) {
+        park[(k * 3 + 0) * RUN_BAND + tid] = c0[k];
+        park[(k * 3 + 1) * RUN_BAND + tid] = c1[k];
+        park[(k * 3 + 2) * RUN_BAND + tid] = c2[k];
+        c0[k] = c1[k] = c2[k] = 0;
+    }
+    __syncthreads();
+    reduce_columns(lds, colacc, tid);
 }
 
 struct RunGeom {  // source window of one band (wave-uniform)
@@ -498,13 +565,7 @@ __global__ __launch_bounds__(RUN_BAND, 4) void runs_kernel(const RunPass p, cons
         // the 3-plane counters hold at most 7 rows per lane: reduce them across lanes in time
         if (++bands_pending == RUN_FLUSH_BANDS || yb + RUN_BAND >= p.NR) {
             bands_pending = 0;
-            if (!(p.dbg & 4)) {
-#pragma unroll
-                for (int k = 0; k < RUN_K; k++) {
-                    flush_word(c0[k], c1[k], c2[k], colacc + k * 32, lane);
-                    c0[k] = c1[k] = c2[k] = 0;
-                }
-            }
+            if (!(p.dbg & 4)) flush_columns(lds, c0, c1, c2, colacc, tid);
         }
     }
     __syncthreads();
