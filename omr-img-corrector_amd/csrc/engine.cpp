@@ -573,10 +573,13 @@ int omr_batch_create(int32_t rows, int32_t cols, uint16_t max_angle, double step
     int rc = c->tables.create(rows, cols, M.data(), A, device);
     if (rc) return rc;
     for (int i = 0; i < n_streams; i++) {
+        // the sweep stream outranks the post stream: std-dev / arg-max fill the gaps, never the reverse
+        int prio_lo = 0, prio_hi = 0;
+        OMR_HIP(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
         hipStream_t s, ps;
-        OMR_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+        OMR_HIP(hipStreamCreateWithPriority(&s, hipStreamNonBlocking, prio_hi));
         c->streams.push_back(s);
-        OMR_HIP(hipStreamCreateWithFlags(&ps, hipStreamNonBlocking));
+        OMR_HIP(hipStreamCreateWithPriority(&ps, hipStreamNonBlocking, prio_lo));
         c->post_streams.push_back(ps);
         c->issued.push_back(0);
         for (int h = 0; h < 2; h++) {

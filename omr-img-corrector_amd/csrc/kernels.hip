@@ -47,9 +47,48 @@ __global__ __launch_bounds__(256) void pack_bits_kernel(const uint8_t *__restric
     if ((lane & 31) == 0 && w < wpr) bits[(int64_t)y * wpr + w] = (uint32_t)(lane ? (m >> 32) : m);
 }
 
+// Wide form for 16-byte aligned rows: a lane loads 16 pixels (one dwordx4), turns each dword
+// into a 4-bit mask with a SWAR "byte < n" test (n = black_max + 1 <= 128) and a multiply that
+// gathers the four byte flags, and a lane pair assembles one 32-bit word.  8.7 MB A4 scans pack at
+// HBM speed instead of at one byte load per lane.
+__device__ __forceinline__ uint32_t bytes_lt_nibble(uint32_t x, uint32_t n_rep)
+{
+    // 0x80 in every byte of x that is < n (1 <= n <= 128), exact per byte: setting bit 7 first keeps
+    // the subtraction free of cross-byte borrows; its bit 7 then says (x & 0x7f) >= n
+    const uint32_t t = (x | 0x80808080u) - n_rep;
+    const uint32_t m = ~x & ~t & 0x80808080u;
+    return (((m >> 7) * 0x01020408u) >> 24) & 15u;  // byte flags 0,8,16,24 -> bits 0..3
+}
+
+__global__ __launch_bounds__(256) void pack_bits16_kernel(const uint8_t *__restrict__ img, int64_t step, int rows,
+                                                          int cols, int black_max, uint32_t *__restrict__ bits,
+                                                          int wpr)
+{
+    const int y = blockIdx.y;
+    const int q = blockIdx.x * 256 + threadIdx.x;  // 16-pixel group of this lane
+    const int x0 = q * 16;
+    uint32_t m16 = 0;
+    if (x0 + 16 <= cols) {
+        const uint4 v = *(const uint4 *)(img + (int64_t)y * step + x0);
+        const uint32_t n_rep = (uint32_t)(black_max + 1) * 0x01010101u;
+        m16 = bytes_lt_nibble(v.x, n_rep) | (bytes_lt_nibble(v.y, n_rep) << 4) | (bytes_lt_nibble(v.z, n_rep) << 8) |
+              (bytes_lt_nibble(v.w, n_rep) << 12);
+    } else if (x0 < cols) {
+        for (int j = 0; j < cols - x0; j++) m16 |= ((int)img[(int64_t)y * step + x0 + j] <= black_max ? 1u : 0u) << j;
+    }
+    const uint32_t other = __shfl_xor(m16, 1);
+    const int w = q >> 1;
+    if ((threadIdx.x & 1) == 0 && w < wpr) bits[(int64_t)y * wpr + w] = m16 | (other << 16);
+}
+
 hipError_t launch_pack_bits(const uint8_t *d_img, int64_t step, int rows, int cols, int black_max,
                             uint32_t *d_bits, int wpr, hipStream_t s)
 {
+    if (black_max >= 0 && black_max < 128 && (step & 15) == 0 && ((uintptr_t)d_img & 15) == 0) {
+        dim3 grid((wpr * 2 + 255) / 256, rows);
+        hipLaunchKernelGGL(pack_bits16_kernel, grid, dim3(256), 0, s, d_img, step, rows, cols, black_max, d_bits, wpr);
+        return hipGetLastError();
+    }
     dim3 grid((wpr * 32 + 255) / 256, rows);
     hipLaunchKernelGGL(pack_bits_kernel, grid, dim3(256), 0, s, d_img, step, rows, cols, black_max, d_bits, wpr);
     return hipGetLastError();

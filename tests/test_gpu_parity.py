@@ -347,3 +347,32 @@ def test_run_merging_kernel_odd_shapes(oracle, shape, max_angle, step):
     got = plan.run(b)
     plan.close()
     assert_sweep_equal(got, exp, str(shape))
+
+
+def test_pack_paths_agree(oracle):
+    # wide (16-byte aligned rows) and byte-wise bit-pack must give the same sweep: odd widths, row
+    # pitches that are / are not multiples of 16, both thresholds
+    import torch
+    rng = np.random.Generator(np.random.PCG64(23))
+    dev = torch.device("cuda:0")
+    for (rows, cols, pitch) in ((70, 160, 160), (70, 150, 160), (33, 47, 64), (33, 47, 47), (64, 2480, 2480)):
+        g = rng.integers(0, 256, (rows, cols), dtype=np.uint8)
+        g[rng.random(g.shape) < 0.3] = 0
+        buf = torch.zeros((rows, pitch), dtype=torch.uint8, device=dev)
+        buf[:, :cols] = torch.from_numpy(g).to(dev)
+        for black_max, ref in ((127, oracle.threshold_binary(g)), (0, np.where(g == 0, 0, 255).astype(np.uint8))):
+            exp = oracle.sweep(ref, 5, 1.0, want_proj=True)
+            plan = projection.SweepPlan(rows, cols, 5, 1.0)
+            vs = torch.zeros(plan.A, dtype=torch.float64, device=dev)
+            hs = torch.zeros(plan.A, dtype=torch.float64, device=dev)
+            vp = torch.zeros((plan.A, cols), dtype=torch.int32, device=dev)
+            hp = torch.zeros((plan.A, rows), dtype=torch.int32, device=dev)
+            torch.cuda.synchronize()
+            plan.run_device(buf.data_ptr(), pitch, black_max, None, vp.data_ptr(), hp.data_ptr(), vs.data_ptr(),
+                            hs.data_ptr(), None)
+            torch.cuda.synchronize()
+            plan.close()
+            assert (vp.cpu().numpy().astype(np.uint32) == exp[0]).all(), (rows, cols, pitch, black_max)
+            assert (hp.cpu().numpy().astype(np.uint32) == exp[1]).all(), (rows, cols, pitch, black_max)
+            assert (vs.cpu().numpy().view(np.uint64) == exp[2].view(np.uint64)).all()
+            assert (hs.cpu().numpy().view(np.uint64) == exp[3].view(np.uint64)).all()
