@@ -294,11 +294,12 @@ int enqueue_sweep(const SweepTables &t, SweepScratch &s, int kernel_sel, const u
     uint32_t *hp = d_hproj ? d_hproj : s.hproj.as<uint32_t>();
     double *vs = d_v_sd ? d_v_sd : s.vsd.as<double>();
     double *hs = d_h_sd ? d_h_sd : s.hsd.as<double>();
-    // The gather kernels accumulate with integer atomics -> their rows of vproj / hproj start at 0;
-    // the run-merging kernel stores complete column counts itself and needs hproj only when the
-    // caller asked for the projections (its row counts live in the u16 partials).
-    if (n_g > 0) OMR_HIP(hipMemsetAsync(vp, 0, sizeof(uint32_t) * (size_t)d.A * d.cols, stream));
-    if (n_g > 0 || want_proj) OMR_HIP(hipMemsetAsync(hp, 0, sizeof(uint32_t) * (size_t)d.A * d.rows, stream));
+    // The gather kernels accumulate with integer atomics -> vproj / hproj start at 0 when any
+    // candidate is gathered; the run-merging kernel overwrites its candidates' rows.
+    if (n_g > 0) {
+        OMR_HIP(hipMemsetAsync(vp, 0, sizeof(uint32_t) * (size_t)d.A * d.cols, stream));
+        OMR_HIP(hipMemsetAsync(hp, 0, sizeof(uint32_t) * (size_t)d.A * d.rows, stream));
+    }
     OMR_HIP(launch_pack_bits(d_img, step, d.rows, d.cols, black_max, s.bits.as<uint32_t>(), d.wpr, stream));
     if (ev0) OMR_HIP(hipEventRecord(ev0, stream));
     if (use_runs) {
@@ -322,10 +323,9 @@ int enqueue_sweep(const SweepTables &t, SweepScratch &s, int kernel_sel, const u
         OMR_HIP(hipStreamWaitEvent(post_stream, ev_mid, 0));
         stream = post_stream;
     }
-    if (use_runs && want_proj)
+    if (use_runs)  // row counts of the run-merged candidates: u16 partials per word group -> hproj
         OMR_HIP(launch_fold_parts(s.hpart.as<uint16_t>(), t.Gh, d.rows, t.list_runs.as<int32_t>(), t.n_runs, hp, stream));
-    OMR_HIP(launch_stddev(vp, hp, d, use_runs ? t.mode.as<int32_t>() : nullptr, s.hpart.as<uint16_t>(), t.Gh, vs, hs,
-                          stream));
+    OMR_HIP(launch_stddev(vp, hp, d, vs, hs, stream));
     if (d_best) OMR_HIP(launch_argmax_path1(vs, hs, d.A, d_best, stream));
     return OMR_OK;
 }

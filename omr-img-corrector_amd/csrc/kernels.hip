@@ -382,40 +382,27 @@ hipError_t launch_sweep_lds(const uint32_t *d_bits, SweepDims d, const int32_t *
 // One block per (candidate, axis): all threads square the deviations of a chunk into LDS, then
 // thread 0 folds the chunk in index order (a tree reduction would round differently).
 #define SD_THREADS 256
-#define SD_CHUNK 2048
+#define SD_CHUNK 512
 
+// 4 KiB of LDS per block on purpose: the kernel is a latency chain (one dependent f64 add per
+// element) that runs on the post stream beside the next scan's sweep, whose two blocks per CU
+// leave only ~6 KiB of LDS free -- a fatter block would evict a sweep block from its CU.
 __global__ __launch_bounds__(SD_THREADS) void stddev_kernel(const uint32_t *__restrict__ vproj,
                                                             const uint32_t *__restrict__ hproj, SweepDims d,
-                                                            const int32_t *__restrict__ mode,
-                                                            const uint16_t *__restrict__ hpart, int Gh,
                                                             double *__restrict__ v_sd, double *__restrict__ h_sd)
 {
-    extern __shared__ __attribute__((aligned(16))) char sd_lds[];
-    double *sq = (double *)sd_lds;                                    // SD_CHUNK squared deviations
-    uint16_t *val = (uint16_t *)(sd_lds + SD_CHUNK * sizeof(double));  // the n counts (each < 32767)
+    __shared__ double sq[SD_CHUNK];
     __shared__ unsigned long long part[SD_THREADS / OMR_WAVE];
     __shared__ double mean_s;
     const int a = blockIdx.x >> 1;
     const int axis = blockIdx.x & 1;  // 0: vertical projection (per column), 1: horizontal (per row)
     const int n = axis ? d.rows : d.cols;
     const uint32_t *__restrict__ p = axis ? hproj + (int64_t)a * d.rows : vproj + (int64_t)a * d.cols;
-    // run-merged candidates deliver their counts as G partial u16 vectors (exact integers either way)
-    const bool parts = axis == 1 && mode && mode[a] != 0;
-    const int G = Gh;
-    const uint16_t *__restrict__ q = hpart + (int64_t)a * Gh * d.rows;
 
-    // pass 1: the counts, once, into LDS; their integer total
+    // the integer total: every partial sum of the reference's sequential f64 loop is exact, so the
+    // total converted once is the same number
     unsigned long long s = 0;
-    for (int i = threadIdx.x; i < n; i += SD_THREADS) {
-        uint32_t t = 0;
-        if (parts) {
-            for (int g = 0; g < G; g++) t += q[(int64_t)g * n + i];
-        } else {
-            t = p[i];
-        }
-        val[i] = (uint16_t)t;
-        s += t;
-    }
+    for (int i = threadIdx.x; i < n; i += SD_THREADS) s += p[i];
     for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
     __syncthreads();
@@ -430,7 +417,7 @@ __global__ __launch_bounds__(SD_THREADS) void stddev_kernel(const uint32_t *__re
     for (int base = 0; base < n; base += SD_CHUNK) {
         const int m = min(SD_CHUNK, n - base);
         for (int i = threadIdx.x; i < m; i += SD_THREADS) {
-            const double dv = (double)val[base + i] - mean;
+            const double dv = (double)p[base + i] - mean;
             sq[i] = dv * dv;
         }
         __syncthreads();
@@ -471,14 +458,11 @@ __global__ __launch_bounds__(SD_THREADS) void stddev_kernel(const uint32_t *__re
     }
 }
 
-hipError_t launch_stddev(const uint32_t *d_vproj, const uint32_t *d_hproj, SweepDims d, const int32_t *d_mode,
-                         const uint16_t *d_hpart, int Gh, double *d_v_sd, double *d_h_sd, hipStream_t s)
+hipError_t launch_stddev(const uint32_t *d_vproj, const uint32_t *d_hproj, SweepDims d, double *d_v_sd,
+                         double *d_h_sd, hipStream_t s)
 {
     if (d.A <= 0) return hipSuccess;
-    const int n = d.rows > d.cols ? d.rows : d.cols;
-    const size_t lds = SD_CHUNK * sizeof(double) + (((size_t)n * 2 + 15) & ~(size_t)15);
-    hipLaunchKernelGGL(stddev_kernel, dim3(2 * d.A), dim3(SD_THREADS), lds, s, d_vproj, d_hproj, d, d_mode, d_hpart, Gh,
-                       d_v_sd, d_h_sd);
+    hipLaunchKernelGGL(stddev_kernel, dim3(2 * d.A), dim3(SD_THREADS), 0, s, d_vproj, d_hproj, d, d_v_sd, d_h_sd);
     return hipGetLastError();
 }
 

@@ -90,16 +90,13 @@ hipError_t launch_runtab(const int32_t *d_CA, const int32_t *d_CB, int A, int NC
 // plain stores).
 hipError_t launch_runs(const RunPass &p, const int32_t *d_list, int n_list, int32_t *d_guard, uint32_t *d_vproj,
                        hipStream_t s);
-// vproj/hproj (u32) += partial counts of the listed candidates (only when the caller wants them)
+// hproj[a][r] = sum of the G partial row counts, for the listed (run-merged) candidates
 hipError_t launch_fold_parts(const uint16_t *d_part, int G, int NR, const int32_t *d_list, int n_list,
                              uint32_t *d_proj, hipStream_t s);
 
 // calculate.rs:13-23 on the integer projections: one block per (candidate, axis).
-// d_mode (may be NULL): per candidate, != 0 -> its row counts are the run-merging kernel's u16
-// partials (d_hpart, Gh vectors per candidate) instead of d_hproj; column counts are always d_vproj.
-hipError_t launch_stddev(const uint32_t *d_vproj, const uint32_t *d_hproj, SweepDims d,
-                         const int32_t *d_mode, const uint16_t *d_hpart, int Gh, double *d_v_sd, double *d_h_sd,
-                         hipStream_t s);
+hipError_t launch_stddev(const uint32_t *d_vproj, const uint32_t *d_hproj, SweepDims d, double *d_v_sd,
+                         double *d_h_sd, hipStream_t s);
 
 // projection.rs:125-190 arg-max (lowest index on exact ties).
 hipError_t launch_argmax_path1(const double *d_v_sd, const double *d_h_sd, int A, int32_t *d_best,

@@ -590,7 +590,7 @@ hipError_t launch_runs(const RunPass &p0, const int32_t *d_list, int n_list, int
     return hipGetLastError();
 }
 
-// proj[a][r] += sum_g part[a][g][r] for the listed candidates
+// proj[a][r] = sum_g part[a][g][r] for the listed candidates
 __global__ __launch_bounds__(256) void fold_parts_kernel(const uint16_t *__restrict__ part, int G, int NR,
                                                          const int32_t *__restrict__ list,
                                                          uint32_t *__restrict__ proj)
@@ -600,7 +600,7 @@ __global__ __launch_bounds__(256) void fold_parts_kernel(const uint16_t *__restr
     if (r >= NR) return;
     uint32_t s = 0;
     for (int g = 0; g < G; g++) s += part[((int64_t)a * G + g) * NR + r];
-    proj[(int64_t)a * NR + r] += s;
+    proj[(int64_t)a * NR + r] = s;
 }
 
 hipError_t launch_fold_parts(const uint16_t *d_part, int G, int NR, const int32_t *d_list, int n_list,
