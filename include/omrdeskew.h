@@ -223,6 +223,32 @@ int omr_get_horizontal_projection(const omr_image *bin_u8c1, double *out_rows);
 int omr_get_mat_projection_data(const omr_image *bin_u8c1, double *h_rows, double *v_cols);
 /* transfer::get_projection_standard_deviations (transfer.rs:527-536): (vertical, horizontal) */
 int omr_get_projection_standard_deviations(const omr_image *bin_u8c1, double *v_sd, double *h_sd);
+/* ---- the same stages on device-resident images (enqueue on `stream`, no synchronisation) ----
+ * These are the building blocks of a fully resident pipeline: front end of omr.rs:87-139,
+ * sweep (omr_sweep_plan_run_device / omr_batch_run_device), final deskew of omr.rs:408-445 /
+ * transfer.rs:487-519.  All pointers are device pointers; steps are row pitches in bytes. */
+int omr_rgb_to_gray_device(const uint8_t *d_src, int64_t src_step, int32_t rows, int32_t cols,
+                           int32_t channels, uint8_t *d_dst, int64_t dst_step, void *stream);
+/* erode(3x3 MORPH_ELLIPSE = cross, iterations = 3, BORDER_CONSTANT, default border): omr.rs:98-112 */
+int omr_erode3_device(const uint8_t *d_src, int64_t src_step, int32_t rows, int32_t cols,
+                      uint8_t *d_dst, int64_t dst_step, void *stream);
+/* resize(INTER_AREA) by an integer factor on both axes (resizeAreaFast_): transfer.rs:66-91 with
+ * the callers' 0.2, omr.rs:114-126 with 1240x1150 -> 248x230.  Other factors: -213 (use the
+ * host-image drivers, which build the tap tables). */
+int omr_resize_area_device(const uint8_t *d_src, int64_t src_step, int32_t src_rows, int32_t src_cols,
+                           int32_t channels, uint8_t *d_dst, int64_t dst_step, int32_t dst_rows,
+                           int32_t dst_cols, void *stream);
+int omr_threshold_binary_device(const uint8_t *d_src, int64_t src_step, int32_t rows, int32_t cols,
+                                uint8_t *d_dst, int64_t dst_step, void *stream);
+/* rotate_mat's canvas (transfer.rs:472-498): DEFAULT keeps the size, CONTAIN grows it. */
+int omr_rotate_size(int32_t rows, int32_t cols, double angle_deg, int32_t clip, int32_t *dst_rows,
+                    int32_t *dst_cols);
+/* rotate_mat on device buffers; dst_rows/dst_cols must equal omr_rotate_size()'s answer. */
+int omr_rotate_device(const uint8_t *d_src, int64_t src_step, int32_t rows, int32_t cols,
+                      int32_t channels, double angle_deg, double scale, int32_t interp,
+                      const uint8_t border_value[4], int32_t clip, uint8_t *d_dst, int64_t dst_step,
+                      int32_t dst_rows, int32_t dst_cols, void *stream);
+
 /* calculate::get_arithmetic_mean / get_standard_deviation (calculate.rs:2-10, :13-23) */
 int omr_get_arithmetic_mean(const double *v, size_t n, double *out);
 int omr_get_standard_deviation(const double *v, size_t n, double *out);

@@ -127,4 +127,20 @@ hipError_t launch_warp_linear(const uint8_t *d_src, int64_t sstep, int srows, in
                               uint8_t *d_dst, int64_t dstep, int drows, int dcols,
                               const double *d_Minv, uint32_t border_rgba, hipStream_t s);
 
+// ---- tuned single-channel stage kernels (stages.hip); each falls back to the generic form -------
+hipError_t launch_rgb2gray_fast(const uint8_t *d_src, int64_t sstep, int rows, int cols, int cn, uint8_t *d_dst,
+                                int64_t dstep, hipStream_t s);
+// erode(3x3 cross) x 3 iterations fused (omr.rs:98-112)
+hipError_t launch_erode3x_cross(const uint8_t *d_src, int64_t sstep, int rows, int cols, uint8_t *d_dst, int64_t dstep,
+                                hipStream_t s);
+hipError_t launch_resize_area_int_fast(const uint8_t *d_src, int64_t sstep, int srows, int scols, int cn,
+                                       uint8_t *d_dst, int64_t dstep, int drows, int dcols, int kx, int ky,
+                                       hipStream_t s);
+// 1-channel warpAffine, 4 px per lane; Minv is a HOST pointer (passed by value to the kernel).
+// Returns hipErrorInvalidValue when the destination is not 4-byte aligned (use the generic kernel).
+hipError_t launch_warp_c1_fast(const uint8_t *d_src, int64_t sstep, int srows, int scols, uint8_t *d_dst, int64_t dstep,
+                               int drows, int dcols, const double Minv[6], int interp, int border, hipStream_t s);
+hipError_t launch_threshold_fast(const uint8_t *d_src, int64_t sstep, int rows, int cols, uint8_t *d_dst, int64_t dstep,
+                                 int thresh, int maxval, hipStream_t s);
+
 }  // namespace omr

@@ -202,7 +202,7 @@ int resize_area(const DevImage &src, int drows, int dcols, DevImage *dst, hipStr
     int iscale_x = (int)lrint(scale_x), iscale_y = (int)lrint(scale_y);
     bool is_area_fast = fabs(scale_x - iscale_x) < DBL_EPSILON && fabs(scale_y - iscale_y) < DBL_EPSILON;
     if (is_area_fast) {
-        OMR_HIP(launch_resize_area_int(src.ptr(), src.step(), src.rows, src.cols, src.cn, dst->ptr(), dst->step(),
+        OMR_HIP(launch_resize_area_int_fast(src.ptr(), src.step(), src.rows, src.cols, src.cn, dst->ptr(), dst->step(),
                                        drows, dcols, iscale_x, iscale_y, s));
         return OMR_OK;
     }
@@ -235,7 +235,7 @@ int to_gray(const DevImage &src, DevImage *gray, hipStream_t s)
         return OMR_OK;
     }
     if (src.cn != 3 && src.cn != 4) return fail(OMR_ERR_ASSERT, "RGB2GRAY needs 3 or 4 channels, got %d", src.cn);
-    OMR_HIP(launch_rgb2gray(src.ptr(), src.step(), src.rows, src.cols, src.cn, gray->ptr(), gray->step(), s));
+    OMR_HIP(launch_rgb2gray_fast(src.ptr(), src.step(), src.rows, src.cols, src.cn, gray->ptr(), gray->step(), s));
     return OMR_OK;
 }
 
@@ -404,15 +404,12 @@ int omr_get_result_from_projection(const omr_image *src, uint16_t max_angle, dou
     if ((rc = current_device(&dev))) return rc;
     Stream st;
     if ((rc = st.create())) return rc;
-    DevImage in, gray, e1, e2, scaled;
+    DevImage in, gray, e1, scaled;
     if ((rc = in.upload(src, st.s))) return rc;
     if ((rc = to_gray(in, &gray, st.s))) return rc;  // :88-92
     // :98-112 erode(3x3 cross, iterations = 3)
     if ((rc = e1.alloc(gray.rows, gray.cols, 1))) return rc;
-    if ((rc = e2.alloc(gray.rows, gray.cols, 1))) return rc;
-    OMR_HIP(launch_erode_cross3(gray.ptr(), gray.step(), gray.rows, gray.cols, e1.ptr(), e1.step(), st.s));
-    OMR_HIP(launch_erode_cross3(e1.ptr(), e1.step(), gray.rows, gray.cols, e2.ptr(), e2.step(), st.s));
-    OMR_HIP(launch_erode_cross3(e2.ptr(), e2.step(), gray.rows, gray.cols, e1.ptr(), e1.step(), st.s));
+    OMR_HIP(launch_erode3x_cross(gray.ptr(), gray.step(), gray.rows, gray.cols, e1.ptr(), e1.step(), st.s));
     // :114-126
     int dc = (int)((double)src->cols * scale), dr = (int)((double)src->rows * scale);
     if ((rc = resize_area(e1, dr, dc, &scaled, st.s))) return rc;
@@ -438,7 +435,7 @@ int omr_threshold_binary(const omr_image *gray, uint8_t *dst, int64_t dst_step)
     DevImage in, out;
     if ((rc = in.upload(gray, st.s))) return rc;
     if ((rc = out.alloc(in.rows, in.cols, 1))) return rc;
-    OMR_HIP(launch_threshold(in.ptr(), in.step(), in.rows, in.cols, out.ptr(), out.step(), 127, 255, st.s));
+    OMR_HIP(launch_threshold_fast(in.ptr(), in.step(), in.rows, in.cols, out.ptr(), out.step(), 127, 255, st.s));
     return out.download(dst, dst_step, st.s);
 }
 
@@ -458,7 +455,91 @@ int omr_rgb_to_gray(const omr_image *src, uint8_t *dst, int64_t dst_step)
     return out.download(dst, dst_step, st.s);
 }
 
-// transfer.rs:459-523
+// transfer.rs:459-523: forward matrix and canvas of rotate_mat
+static int rotate_geometry(int rows, int cols, double angle_deg, double scale, int clip, double M[6], int *drows,
+                           int *dcols)
+{
+    if (clip == OMR_CLIP_DEFAULT) {  // :472-486
+        *drows = rows;
+        *dcols = cols;
+        rotation_matrix_2d((float)cols / 2.0f, (float)rows / 2.0f, angle_deg, scale, M);
+    } else if (clip == OMR_CLIP_CONTAIN) {  // :487-519
+        const double CV_PI_ = 3.1415926535897932384626433832795;
+        double sn = fabs(sin(angle_deg * CV_PI_ / 180.0)), cs = fabs(cos(angle_deg * CV_PI_ / 180.0));
+        double rotated_width = ceil((double)rows * sn + (double)cols * cs);
+        double rotated_height = ceil((double)cols * sn + (double)rows * cs);
+        *dcols = (int)rotated_width;
+        *drows = (int)rotated_height;
+        rotation_matrix_2d((float)ceil(rotated_width / 2.0), (float)ceil(rotated_height / 2.0), angle_deg, scale, M);
+        M[2] += ceil((rotated_width - (double)cols) / 2.0);
+        M[5] += ceil((rotated_height - (double)rows) / 2.0);
+    } else {
+        return fail(OMR_ERR_BADARG, "unknown clip strategy %d", clip);
+    }
+    if (*drows <= 0 || *dcols <= 0 || *drows >= 32767 || *dcols >= 32767) return fail(OMR_ERR_ASSERT, "bad canvas size");
+    return OMR_OK;
+}
+
+// launch the warp of rotate_mat on device buffers (1 channel: 4 px / lane; otherwise generic)
+static int rotate_launch(const uint8_t *d_src, int64_t sstep, int rows, int cols, int cn, const double M[6], int interp,
+                         const uint8_t border_value[4], uint8_t *d_dst, int64_t dstep, int drows, int dcols,
+                         hipStream_t s, DevBuf *keep)
+{
+    double Minv[6];
+    invert_affine(M, Minv);
+    if (cn == 1) {
+        hipError_t e = launch_warp_c1_fast(d_src, sstep, rows, cols, d_dst, dstep, drows, dcols, Minv, interp,
+                                           border_value[0], s);
+        if (e == hipSuccess) return OMR_OK;
+        if (e != hipErrorInvalidValue) return fail_gpu("launch_warp_c1_fast", e);
+        (void)hipGetLastError();
+    }
+    OMR_HIP(keep->alloc(sizeof Minv));
+    OMR_HIP(hipMemcpyAsync(keep->p, Minv, sizeof Minv, hipMemcpyHostToDevice, s));
+    OMR_HIP(hipStreamSynchronize(s));  // Minv is a stack buffer
+    uint32_t border = (uint32_t)border_value[0] | ((uint32_t)border_value[1] << 8) | ((uint32_t)border_value[2] << 16) |
+                      ((uint32_t)border_value[3] << 24);
+    if (interp == OMR_INTER_NEAREST)
+        OMR_HIP(launch_warp_nn(d_src, sstep, rows, cols, cn, d_dst, dstep, drows, dcols, keep->as<double>(), border, s));
+    else
+        OMR_HIP(launch_warp_linear(d_src, sstep, rows, cols, cn, d_dst, dstep, drows, dcols, keep->as<double>(), border, s));
+    return OMR_OK;
+}
+
+int omr_rotate_size(int32_t rows, int32_t cols, double angle_deg, int32_t clip, int32_t *dst_rows, int32_t *dst_cols)
+{
+    if (!dst_rows || !dst_cols || rows <= 0 || cols <= 0) return fail(OMR_ERR_BADARG, "bad arguments");
+    double M[6];
+    int dr, dc;
+    int rc = rotate_geometry(rows, cols, angle_deg, 1.0, clip, M, &dr, &dc);
+    if (rc) return rc;
+    *dst_rows = dr;
+    *dst_cols = dc;
+    return OMR_OK;
+}
+
+int omr_rotate_device(const uint8_t *d_src, int64_t src_step, int32_t rows, int32_t cols, int32_t channels,
+                      double angle_deg, double scale, int32_t interp, const uint8_t border_value[4], int32_t clip,
+                      uint8_t *d_dst, int64_t dst_step, int32_t dst_rows, int32_t dst_cols, void *stream)
+{
+    if (!d_src || !d_dst || !border_value) return fail(OMR_ERR_BADARG, "null pointer");
+    if (rows <= 0 || cols <= 0 || rows >= 32767 || cols >= 32767 || channels < 1 || channels > 4)
+        return fail(OMR_ERR_ASSERT, "bad image shape");
+    if (interp != OMR_INTER_NEAREST && interp != OMR_INTER_LINEAR)
+        return fail(OMR_ERR_NOTIMPL, "interpolation flag %d is not implemented", interp);
+    double M[6];
+    int dr, dc;
+    int rc = rotate_geometry(rows, cols, angle_deg, scale, clip, M, &dr, &dc);
+    if (rc) return rc;
+    if (dr != dst_rows || dc != dst_cols) return fail(OMR_ERR_ASSERT, "destination must be %dx%d", dc, dr);
+    if (src_step < (int64_t)cols * channels || dst_step < (int64_t)dc * channels) return fail(OMR_ERR_BADARG, "step too small");
+    DevBuf keep;
+    rc = rotate_launch(d_src, src_step, rows, cols, channels, M, interp, border_value, d_dst, dst_step, dr, dc,
+                       (hipStream_t)stream, &keep);
+    if (!rc && keep.p) OMR_HIP(hipStreamSynchronize((hipStream_t)stream));  // generic path: matrix buffer is freed
+    return rc;
+}
+
 int omr_rotate(const omr_image *src, double angle_deg, double scale, int32_t interp, const uint8_t border_value[4],
                int32_t clip, omr_image_owned *dst)
 {
@@ -467,45 +548,20 @@ int omr_rotate(const omr_image *src, double angle_deg, double scale, int32_t int
     if (!dst || !border_value) return fail(OMR_ERR_BADARG, "null output");
     if (interp != OMR_INTER_NEAREST && interp != OMR_INTER_LINEAR)
         return fail(OMR_ERR_NOTIMPL, "interpolation flag %d is not implemented", interp);
-    double M[6], Minv[6];
+    double M[6];
     int drows, dcols;
-    if (clip == OMR_CLIP_DEFAULT) {  // :472-486
-        drows = src->rows;
-        dcols = src->cols;
-        rotation_matrix_2d((float)src->cols / 2.0f, (float)src->rows / 2.0f, angle_deg, scale, M);
-    } else if (clip == OMR_CLIP_CONTAIN) {  // :487-519
-        const double CV_PI_ = 3.1415926535897932384626433832795;
-        double sn = fabs(sin(angle_deg * CV_PI_ / 180.0)), cs = fabs(cos(angle_deg * CV_PI_ / 180.0));
-        double rotated_width = ceil((double)src->rows * sn + (double)src->cols * cs);
-        double rotated_height = ceil((double)src->cols * sn + (double)src->rows * cs);
-        dcols = (int)rotated_width;
-        drows = (int)rotated_height;
-        rotation_matrix_2d((float)ceil(rotated_width / 2.0), (float)ceil(rotated_height / 2.0), angle_deg, scale, M);
-        M[2] += ceil((rotated_width - (double)src->cols) / 2.0);
-        M[5] += ceil((rotated_height - (double)src->rows) / 2.0);
-    } else {
-        return fail(OMR_ERR_BADARG, "unknown clip strategy %d", clip);
-    }
-    if (drows <= 0 || dcols <= 0 || drows >= 32767 || dcols >= 32767) return fail(OMR_ERR_ASSERT, "bad canvas size");
-    invert_affine(M, Minv);
+    if ((rc = rotate_geometry(src->rows, src->cols, angle_deg, scale, clip, M, &drows, &dcols))) return rc;
     int dev;
     if ((rc = current_device(&dev))) return rc;
     Stream st;
     if ((rc = st.create())) return rc;
     DevImage in, out;
-    DevBuf dM;
+    DevBuf keep;
     if ((rc = in.upload(src, st.s))) return rc;
     if ((rc = out.alloc(drows, dcols, src->channels))) return rc;
-    OMR_HIP(dM.alloc(sizeof Minv));
-    OMR_HIP(hipMemcpyAsync(dM.p, Minv, sizeof Minv, hipMemcpyHostToDevice, st.s));
-    uint32_t border = (uint32_t)border_value[0] | ((uint32_t)border_value[1] << 8) | ((uint32_t)border_value[2] << 16) |
-                      ((uint32_t)border_value[3] << 24);
-    if (interp == OMR_INTER_NEAREST)
-        OMR_HIP(launch_warp_nn(in.ptr(), in.step(), in.rows, in.cols, in.cn, out.ptr(), out.step(), drows, dcols,
-                               dM.as<double>(), border, st.s));
-    else
-        OMR_HIP(launch_warp_linear(in.ptr(), in.step(), in.rows, in.cols, in.cn, out.ptr(), out.step(), drows, dcols,
-                                   dM.as<double>(), border, st.s));
+    if ((rc = rotate_launch(in.ptr(), in.step(), in.rows, in.cols, in.cn, M, interp, border_value, out.ptr(), out.step(),
+                            drows, dcols, st.s, &keep)))
+        return rc;
     dst->rows = drows;
     dst->cols = dcols;
     dst->channels = src->channels;
@@ -515,6 +571,63 @@ int omr_rotate(const omr_image *src, double angle_deg, double scale, int32_t int
     rc = out.download(dst->data, dst->step_bytes, st.s);
     if (rc) omr_image_free(dst);
     return rc;
+}
+
+// ---- device-resident stages --------------------------------------------------------------------
+static int check_dev_image(const void *s, const void *d, int rows, int cols, int64_t sstep, int64_t dstep, int scn,
+                           int dcn)
+{
+    if (!s || !d) return fail(OMR_ERR_BADARG, "null device pointer");
+    if (rows <= 0 || cols <= 0 || rows >= 32767 || cols >= 32767) return fail(OMR_ERR_ASSERT, "bad image shape");
+    if (sstep < (int64_t)cols * scn || dstep < (int64_t)cols * dcn) return fail(OMR_ERR_BADARG, "step too small");
+    return OMR_OK;
+}
+
+int omr_rgb_to_gray_device(const uint8_t *d_src, int64_t src_step, int32_t rows, int32_t cols, int32_t channels,
+                           uint8_t *d_dst, int64_t dst_step, void *stream)
+{
+    if (channels != 3 && channels != 4) return fail(OMR_ERR_ASSERT, "RGB2GRAY needs 3 or 4 channels");
+    int rc = check_dev_image(d_src, d_dst, rows, cols, src_step, dst_step, channels, 1);
+    if (rc) return rc;
+    OMR_HIP(launch_rgb2gray_fast(d_src, src_step, rows, cols, channels, d_dst, dst_step, (hipStream_t)stream));
+    return OMR_OK;
+}
+
+int omr_erode3_device(const uint8_t *d_src, int64_t src_step, int32_t rows, int32_t cols, uint8_t *d_dst,
+                      int64_t dst_step, void *stream)
+{
+    int rc = check_dev_image(d_src, d_dst, rows, cols, src_step, dst_step, 1, 1);
+    if (rc) return rc;
+    if (d_src == d_dst) return fail(OMR_ERR_BADARG, "erode cannot run in place");
+    OMR_HIP(launch_erode3x_cross(d_src, src_step, rows, cols, d_dst, dst_step, (hipStream_t)stream));
+    return OMR_OK;
+}
+
+int omr_resize_area_device(const uint8_t *d_src, int64_t src_step, int32_t src_rows, int32_t src_cols,
+                           int32_t channels, uint8_t *d_dst, int64_t dst_step, int32_t dst_rows, int32_t dst_cols,
+                           void *stream)
+{
+    if (!d_src || !d_dst) return fail(OMR_ERR_BADARG, "null device pointer");
+    if (src_rows <= 0 || src_cols <= 0 || dst_rows <= 0 || dst_cols <= 0 || channels < 1 || channels > 4)
+        return fail(OMR_ERR_ASSERT, "bad image shape");
+    if (src_step < (int64_t)src_cols * channels || dst_step < (int64_t)dst_cols * channels)
+        return fail(OMR_ERR_BADARG, "step too small");
+    double scale_x = 1. / ((double)dst_cols / src_cols), scale_y = 1. / ((double)dst_rows / src_rows);
+    int kx = (int)lrint(scale_x), ky = (int)lrint(scale_y);
+    if (!(scale_x >= 1 && scale_y >= 1) || fabs(scale_x - kx) >= DBL_EPSILON || fabs(scale_y - ky) >= DBL_EPSILON)
+        return fail(OMR_ERR_NOTIMPL, "device INTER_AREA handles integer shrink factors only");
+    OMR_HIP(launch_resize_area_int_fast(d_src, src_step, src_rows, src_cols, channels, d_dst, dst_step, dst_rows,
+                                        dst_cols, kx, ky, (hipStream_t)stream));
+    return OMR_OK;
+}
+
+int omr_threshold_binary_device(const uint8_t *d_src, int64_t src_step, int32_t rows, int32_t cols, uint8_t *d_dst,
+                                int64_t dst_step, void *stream)
+{
+    int rc = check_dev_image(d_src, d_dst, rows, cols, src_step, dst_step, 1, 1);
+    if (rc) return rc;
+    OMR_HIP(launch_threshold_fast(d_src, src_step, rows, cols, d_dst, dst_step, 127, 255, (hipStream_t)stream));
+    return OMR_OK;
 }
 
 // Identity "sweep" = plain projections of the image itself: X = (x*1024 + 512) >> 10 = x.

@@ -84,6 +84,16 @@ SYMBOLS = {
     "omr_get_horizontal_projection": (C.c_int, [C.POINTER(OmrImage), f64p]),
     "omr_get_mat_projection_data": (C.c_int, [C.POINTER(OmrImage), f64p, f64p]),
     "omr_get_projection_standard_deviations": (C.c_int, [C.POINTER(OmrImage), f64p, f64p]),
+    "omr_rgb_to_gray_device": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int64,
+                                         C.c_void_p]),
+    "omr_erode3_device": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p]),
+    "omr_resize_area_device": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int64,
+                                         C.c_int32, C.c_int32, C.c_void_p]),
+    "omr_threshold_binary_device": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_int64,
+                                              C.c_void_p]),
+    "omr_rotate_size": (C.c_int, [C.c_int32, C.c_int32, C.c_double, C.c_int32, i32p, i32p]),
+    "omr_rotate_device": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_double,
+                                    C.c_int32, u8p, C.c_int32, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p]),
     "omr_get_arithmetic_mean": (C.c_int, [f64p, C.c_size_t, f64p]),
     "omr_get_standard_deviation": (C.c_int, [f64p, C.c_size_t, f64p]),
 }

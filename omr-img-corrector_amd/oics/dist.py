@@ -21,7 +21,13 @@ def init(backend=None):
         os.environ.setdefault("MASTER_PORT", "29512")
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        if backend == "nccl":
+            # one process per GPU: bind the device BEFORE the RCCL communicator is created
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend=backend, rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, local_rank, world
 
 

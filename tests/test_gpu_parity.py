@@ -376,3 +376,58 @@ def test_pack_paths_agree(oracle):
             assert (hp.cpu().numpy().astype(np.uint32) == exp[1]).all(), (rows, cols, pitch, black_max)
             assert (vs.cpu().numpy().view(np.uint64) == exp[2].view(np.uint64)).all()
             assert (hs.cpu().numpy().view(np.uint64) == exp[3].view(np.uint64)).all()
+
+
+def test_device_resident_stages_match_oracle(oracle):
+    """Front end (omr.rs:87-139) and final warp (transfer.rs:487-519) on device buffers, tuned
+    1-channel / 4-px-per-lane kernels and their generic fallbacks."""
+    import ctypes as C
+    import torch
+    from oics._lib import check, lib, u8p
+    dev = torch.device("cuda:0")
+    rng = np.random.Generator(np.random.PCG64(31))
+    L = lib()
+    for (rows, cols) in ((1150, 1240), (115, 125), (64, 64), (37, 41)):
+        rgb = rng.integers(0, 256, (rows, cols, 3), dtype=np.uint8)
+        d_rgb = torch.from_numpy(rgb).to(dev)
+        d_gray = torch.empty((rows, cols), dtype=torch.uint8, device=dev)
+        check(L.omr_rgb_to_gray_device(d_rgb.data_ptr(), cols * 3, rows, cols, 3, d_gray.data_ptr(), cols, None))
+        gray = oracle.rgb2gray(rgb)
+        assert (d_gray.cpu().numpy() == gray).all(), (rows, cols)
+        d_er = torch.empty_like(d_gray)
+        check(L.omr_erode3_device(d_gray.data_ptr(), cols, rows, cols, d_er.data_ptr(), cols, None))
+        er = oracle.erode_cross3(gray, 3)
+        assert (d_er.cpu().numpy() == er).all(), (rows, cols)
+        d_th = torch.empty_like(d_gray)
+        check(L.omr_threshold_binary_device(d_gray.data_ptr(), cols, rows, cols, d_th.data_ptr(), cols, None))
+        assert (d_th.cpu().numpy() == oracle.threshold_binary(gray)).all()
+        for k in (2, 5):
+            if rows % k or cols % k:
+                with pytest.raises(oics.OmrError):
+                    check(L.omr_resize_area_device(d_er.data_ptr(), cols, rows, cols, 1, d_th.data_ptr(), cols,
+                                                   rows // k + 1, cols // k, None))
+                continue
+            d_small = torch.empty((rows // k, cols // k), dtype=torch.uint8, device=dev)
+            check(L.omr_resize_area_device(d_er.data_ptr(), cols, rows, cols, 1, d_small.data_ptr(), cols // k,
+                                           rows // k, cols // k, None))
+            assert (d_small.cpu().numpy() == oracle.resize_area(er, rows // k, cols // k)).all(), (rows, cols, k)
+        white = np.array([255, 255, 255, 0], np.uint8)
+        for clip in (0, 1):
+            for interp in (0, 1):
+                for ang in (-7.35, 3.1, 44.0):
+                    dr, dc = C.c_int32(), C.c_int32()
+                    check(L.omr_rotate_size(rows, cols, ang, clip, C.byref(dr), C.byref(dc)))
+                    for (img, d_img, cn) in ((gray, d_gray, 1), (rgb, d_rgb, 3)):
+                        shape = (dr.value, dc.value) if cn == 1 else (dr.value, dc.value, 3)
+                        d_out = torch.empty(shape, dtype=torch.uint8, device=dev)
+                        check(L.omr_rotate_device(d_img.data_ptr(), cols * cn, rows, cols, cn, ang, 1.0, interp,
+                                                  white.ctypes.data_as(u8p), clip, d_out.data_ptr(), dc.value * cn,
+                                                  dr.value, dc.value, None))
+                        torch.cuda.synchronize()
+                        exp = oracle.rotate_mat(img, ang, 1.0, interp=interp, clip=clip)
+                        got = d_out.cpu().numpy()
+                        assert got.shape == exp.shape
+                        if interp == 0:
+                            assert (got == exp).all(), (rows, cols, clip, ang, cn)
+                        else:  # north_star tolerance for the bilinear warp: 1 grey level
+                            assert np.abs(got.astype(int) - exp.astype(int)).max() <= 1, (rows, cols, clip, ang, cn)
