@@ -332,7 +332,11 @@ def test_run_merging_kernel_covers_the_headline_sweep():
 
 
 @pytest.mark.parametrize("shape,max_angle,step", [((700, 500), 20, 0.5), ((513, 1031), 12, 0.25), ((40, 2000), 8, 1.0),
-                                                  ((2000, 37), 8, 1.0), ((257, 255), 45, 0.9)])
+                                                  ((2000, 37), 8, 1.0), ((257, 255), 45, 0.9),
+                                                  # > 7 bands of 512 rows: the column counters flush more than once
+                                                  ((4300, 300), 6, 1.5), ((7700, 70), 3, 1.0),
+                                                  # > 256 columns x many word groups, last group partial
+                                                  ((90, 5000), 4, 2.0)])
 def test_run_merging_kernel_odd_shapes(oracle, shape, max_angle, step):
     rows, cols = shape
     rng = np.random.Generator(np.random.PCG64(rows + 7 * cols))
