@@ -195,12 +195,13 @@ int SweepTables::build_runs()
     if ((off && off[0] == '1') || tab_bytes > ((size_t)3 << 30)) return OMR_OK;  // gather kernels only
     OMR_HIP(tabsH.alloc(sizeof(RunTab) * (size_t)A * NWh));
     OMR_HIP(metaH.alloc(sizeof(RunMeta) * (size_t)A * NWh));
+    OMR_HIP(blkH.alloc(sizeof(RunBlk) * (size_t)A * Gh));
     OMR_HIP(mode.alloc(sizeof(int32_t) * (size_t)A));
     OMR_HIP(list_runs.alloc(sizeof(int32_t) * (size_t)A));
     OMR_HIP(list_gather.alloc(sizeof(int32_t) * (size_t)A));
     OMR_HIP(hipMemset(tabsH.p, 0, tabsH.bytes));
     OMR_HIP(launch_runtab(adelta.as<int32_t>(), bdelta.as<int32_t>(), A, cols, NWh, tabsH.as<RunTab>(),
-                          metaH.as<RunMeta>(), nullptr));
+                          metaH.as<RunMeta>(), blkH.as<RunBlk>(), nullptr));
     // dry run
     DevBuf z0, hp, vp, gd, all;
     OMR_HIP(z0.alloc(sizeof(uint32_t) * (size_t)rows * dims.wpr));
@@ -214,7 +215,7 @@ int SweepTables::build_runs()
     for (int a = 0; a < A; a++) idx[a] = a;
     OMR_HIP(hipMemcpy(all.p, idx.data(), sizeof(int32_t) * (size_t)A, hipMemcpyHostToDevice));
     RunPass ph{z0.as<uint32_t>(), rows, dims.wpr, xy0.as<int2_t>(), adelta.as<int32_t>(), bdelta.as<int32_t>(),
-               rows, cols, NWh, tabsH.as<RunTab>(), metaH.as<RunMeta>(), hp.as<uint16_t>(), Gh, 0};
+               rows, cols, NWh, tabsH.as<RunTab>(), metaH.as<RunMeta>(), blkH.as<RunBlk>(), hp.as<uint16_t>(), Gh, 0};
     OMR_HIP(launch_runs(ph, all.as<int32_t>(), A, gd.as<int32_t>(), vp.as<uint32_t>(), nullptr));
     std::vector<int32_t> g((size_t)A);
     std::vector<RunMeta> mh((size_t)A * NWh);
@@ -305,7 +306,7 @@ int enqueue_sweep(const SweepTables &t, SweepScratch &s, int kernel_sel, const u
     if (use_runs) {
         RunPass ph{s.bits.as<uint32_t>(), d.rows, d.wpr, t.xy0.as<int2_t>(), t.adelta.as<int32_t>(),
                    t.bdelta.as<int32_t>(), d.rows, d.cols, t.NWh, t.tabsH.as<RunTab>(), t.metaH.as<RunMeta>(),
-                   s.hpart.as<uint16_t>(), t.Gh, 0};
+                   t.blkH.as<RunBlk>(), s.hpart.as<uint16_t>(), t.Gh, 0};
         OMR_HIP(launch_runs(ph, t.list_runs.as<int32_t>(), t.n_runs, s.guard.as<int32_t>(), vp, stream));
     }
     if (n_g > 0) {
@@ -505,6 +506,15 @@ int omr_sweep_plan_info(const omr_sweep_plan *plan, int32_t *n_runs, int32_t *n_
     const bool runs = plan->tables.runs_built && plan->tables.n_runs > 0;
     if (n_runs) *n_runs = runs ? plan->tables.n_runs : 0;
     if (n_gather) *n_gather = runs ? plan->tables.n_gather : plan->tables.dims.A;
+    return OMR_OK;
+}
+
+// development aid (not in the public header): phase clocks of runs_kernel under OMR_RUNS_DBG=8
+int omr_debug_runs_stamps(unsigned long long *out8, int reset)
+{
+    if (!out8) return fail(OMR_ERR_BADARG, "null output");
+    OMR_HIP(hipDeviceSynchronize());
+    OMR_HIP(debug_runs_stamps(out8, reset != 0));
     return OMR_OK;
 }
 

@@ -57,7 +57,7 @@ struct SweepTables {
     // into run-merged ones and ones left to the gather kernels
     bool runs_built = false;
     int NWh = 0, Gh = 0;
-    DevBuf tabsH, metaH, list_runs, list_gather, mode;
+    DevBuf tabsH, metaH, blkH, list_runs, list_gather, mode;
     int n_runs = 0, n_gather = 0;
     std::vector<int32_t> host_mode;
     int create(int rows, int cols, const double *fwd_M, int A, int device);

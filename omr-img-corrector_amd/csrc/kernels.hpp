@@ -70,6 +70,13 @@ struct RunMeta {  // per (candidate, word)
     int32_t ok;     // 0: this word cannot be run-merged (candidate falls back to the gather kernel)
     int32_t pad0, pad1;
 };
+struct RunBlk {  // per (candidate, word group): what a sweep block needs before it can fetch
+    int32_t nlev, smax;   // maxima over the group's words
+    uint32_t valid_last;  // RunMeta::valid of the group's last word
+    int32_t ca_f, ca_l;   // CA at the group's first / last column
+    int32_t cb_f, cb_l;   // CB likewise
+    int32_t pad;
+};
 struct RunPass {  // one orientation
     const uint32_t *src;  // bit image of this orientation
     int32_t src_rows, src_wpr;
@@ -79,18 +86,21 @@ struct RunPass {  // one orientation
     int32_t NR, NC, NW;   // NW = ceil(NC / 32)
     const RunTab *tabs;   // [A][NW]
     const RunMeta *meta;  // [A][NW]
+    const RunBlk *blk;    // [A][G]
     uint16_t *part;       // [A][G][NR] partial counts, G = ceil(NW / OMR_RUN_K)
     int32_t G;
     int32_t dbg;          // development switches (0 in production)
 };
 hipError_t launch_runtab(const int32_t *d_CA, const int32_t *d_CB, int A, int NC, int NW, RunTab *d_tabs,
-                         RunMeta *d_meta, hipStream_t s);
+                         RunMeta *d_meta, RunBlk *d_blk, hipStream_t s);
 // d_list: n_list candidate indices; d_guard[a] != 0 when a window did not fit for candidate a.
 // Row counts go to p.part (u16 partials per word group), column counts to d_vproj[a][NC] (complete,
 // plain stores).
 hipError_t launch_runs(const RunPass &p, const int32_t *d_list, int n_list, int32_t *d_guard, uint32_t *d_vproj,
                        hipStream_t s);
 // hproj[a][r] = sum of the G partial row counts, for the listed (run-merged) candidates
+// development aid: phase clocks summed by runs_kernel when OMR_RUNS_DBG=8 (see runs.hip)
+hipError_t debug_runs_stamps(unsigned long long out[8], bool reset);
 hipError_t launch_fold_parts(const uint16_t *d_part, int G, int NR, const int32_t *d_list, int n_list,
                              uint32_t *d_proj, hipStream_t s);
 

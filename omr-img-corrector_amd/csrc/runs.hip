@@ -18,6 +18,8 @@
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "kernels.hpp"
 
 namespace omr {
@@ -37,7 +39,11 @@ namespace omr {
 #define RUN_WIN_OFS 0
 #define RUN_META_OFS (RUN_WIN_ROWS * RUN_PITCHB)
 #define RUN_TABS_OFS (RUN_META_OFS + RUN_K * 8)
-#define RUN_LDS_BYTES (RUN_TABS_OFS + RUN_K * RUN_TAB_BYTES)
+#define RUN_COL_OFS (RUN_TABS_OFS + RUN_K * RUN_TAB_BYTES)  // column totals of the block, u32[RUN_K * 32]
+#define RUN_LDS_BYTES (RUN_COL_OFS + RUN_K * 32 * 4)
+// no static LDS in runs_kernel: the dynamic segment then starts at LDS address 0 and every table
+// offset folds into the ds_read immediate
+static_assert(2 * RUN_LDS_BYTES <= 160 * 1024, "two blocks per CU");
 
 static_assert(sizeof(RunTab) == RUN_TAB_BYTES, "RunTab layout");
 static_assert(sizeof(RunMeta) == 32, "RunMeta layout");
@@ -172,10 +178,42 @@ __global__ __launch_bounds__(1024) void runtab_kernel(const int32_t *__restrict_
     }
 }
 
+// RunBlk of every (candidate, word group): thread = one group
+__global__ __launch_bounds__(256) void runblk_kernel(const int32_t *__restrict__ CA, const int32_t *__restrict__ CB,
+                                                     int A, int NC, int NW, int G,
+                                                     const RunMeta *__restrict__ meta, RunBlk *__restrict__ blk)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= A * G) return;
+    const int a = i / G, g = i - a * G;
+    const int w0 = g * RUN_K, kw = min(RUN_K, NW - w0);
+    const RunMeta *mt = meta + ((int64_t)a * NW + w0);
+    RunBlk b;
+    b.nlev = 1;
+    b.smax = 0;
+    for (int k = 0; k < kw; k++) {
+        b.nlev = max(b.nlev, mt[k].nlev);
+        b.smax = max(b.smax, mt[k].smax);
+    }
+    b.valid_last = mt[kw - 1].valid;
+    const int c_first = w0 * 32, c_last = min(NC, (w0 + kw) * 32) - 1;
+    b.ca_f = CA[(int64_t)a * NC + c_first];
+    b.ca_l = CA[(int64_t)a * NC + c_last];
+    b.cb_f = CB[(int64_t)a * NC + c_first];
+    b.cb_l = CB[(int64_t)a * NC + c_last];
+    b.pad = 0;
+    blk[i] = b;
+}
+
 hipError_t launch_runtab(const int32_t *d_CA, const int32_t *d_CB, int A, int NC, int NW, RunTab *d_tabs,
-                         RunMeta *d_meta, hipStream_t s)
+                         RunMeta *d_meta, RunBlk *d_blk, hipStream_t s)
 {
     hipLaunchKernelGGL(runtab_kernel, dim3(NW, A), dim3(1024), 0, s, d_CA, d_CB, NC, NW, d_tabs, d_meta);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    const int G = (NW + RUN_K - 1) / RUN_K;
+    hipLaunchKernelGGL(runblk_kernel, dim3((A * G + 255) / 256), dim3(256), 0, s, d_CA, d_CB, A, NC, NW, G, d_meta,
+                       d_blk);
     return hipGetLastError();
 }
 
@@ -401,65 +439,53 @@ __device__ __forceinline__ void flush_columns(char *lds, uint32_t (&c0)[RUN_K], 
     reduce_columns(lds, colacc, tid);
 }
 
+// Diagnostic build only (OMR_RUNS_DBG=8): per-block phase clocks of wave 0, summed into a global
+// array [tables, commit+barriers, prefetch-issue, compute, flush, total]; read back with
+// omr_debug_runs_stamps().  No stamp executes in a production run (dbg == 0).
+__device__ unsigned long long g_run_stamps[8];
+__device__ __forceinline__ unsigned long long run_clock()
+{
+    unsigned long long t;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    return t;
+}
+
 struct RunGeom {  // source window of one band (wave-uniform)
     int wxw, wy0, nrows;
+    int nq;  // aligned 4-word pieces per window row that hold samples (3..RUN_QUADS)
     bool fits;
 };
 
 #define RUN_FLUSH_BANDS 7  // 3-plane counters hold up to 7 rows per lane
 
+template <bool STAMP>
 __global__ __launch_bounds__(RUN_BAND, 4) void runs_kernel(const RunPass p, const int32_t *__restrict__ list,
                                                         int32_t *__restrict__ guard, uint32_t *__restrict__ vproj)
 {
     extern __shared__ __attribute__((aligned(16))) char lds[];
-    __shared__ uint32_t colacc[RUN_K * 32];
+    uint32_t *colacc = (uint32_t *)(lds + RUN_COL_OFS);
+    constexpr bool stamp = STAMP;
+    unsigned long long st_t0 = 0, st_prev = 0, st_acc[5] = {0, 0, 0, 0, 0};
+    if (stamp) st_t0 = st_prev = run_clock();
+#define RUN_STAMP(I)                                   \
+    if (stamp) {                                       \
+        const unsigned long long now_ = run_clock();   \
+        st_acc[I] += now_ - st_prev;                   \
+        st_prev = now_;                                \
+    }
     const int a = __builtin_amdgcn_readfirstlane(list[blockIdx.y]);
     const int g = blockIdx.x;
     const int w0 = g * RUN_K;
     const int kw = min(RUN_K, p.NW - w0);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
-    // ---- stage the run tables of this block's words (16-byte copies; words past the end of the
-    //      row repeat the last real word so that every lane address stays meaningful)
-    {
-        const uint4 *src = (const uint4 *)(p.tabs + ((int64_t)a * p.NW + w0));
-        uint4 *dst = (uint4 *)(lds + RUN_TABS_OFS);
-        constexpr int W16 = RUN_TAB_BYTES / 16;
-        constexpr int TP = (RUN_K * W16 + RUN_BAND - 1) / RUN_BAND;
-        uint4 tv[TP];
-#pragma unroll
-        for (int n = 0; n < TP; n++) {  // all loads in flight before the first LDS write
-            const int i = tid + n * RUN_BAND;
-            const int k = i / W16, c = i - k * W16;
-            tv[n] = i < RUN_K * W16 ? src[min(k, kw - 1) * W16 + c] : make_uint4(0, 0, 0, 0);
-        }
-#pragma unroll
-        for (int n = 0; n < TP; n++) {
-            const int i = tid + n * RUN_BAND;
-            if (i < RUN_K * W16) dst[i] = tv[n];
-        }
-    }
-    // block-uniform word constants: (ca0, cb0) pairs go to LDS (read back as a broadcast), the
-    // level / lag bounds become the block's maxima, the valid mask matters for the last word only
-    const RunMeta *__restrict__ mt = p.meta + ((int64_t)a * p.NW + w0);
-    int nlev_blk = 1, smax_blk = 0;
-    for (int k = 0; k < kw; k++) {
-        nlev_blk = max(nlev_blk, __builtin_amdgcn_readfirstlane(mt[k].nlev));
-        smax_blk = max(smax_blk, __builtin_amdgcn_readfirstlane(mt[k].smax));
-    }
-    const uint32_t valid_last = (uint32_t)__builtin_amdgcn_readfirstlane((int)mt[kw - 1].valid);
-    if (tid < RUN_K) {
-        const int kk = min(tid, kw - 1);
-        *(int2 *)(lds + RUN_META_OFS + tid * 8) = make_int2(mt[kk].ca0, mt[kk].cb0);
-    }
-    if (tid < RUN_K * 32) colacc[tid] = 0;
+    // block constants: one scalar load (the address is uniform)
+    const RunBlk bk = p.blk[(int64_t)a * p.G + g];
+    const int nlev_blk = bk.nlev, smax_blk = bk.smax;
+    const uint32_t valid_last = bk.valid_last;
+    const int ca_f = bk.ca_f, ca_l = bk.ca_l, cb_f = bk.cb_f, cb_l = bk.cb_l;
     const int2_t *__restrict__ RT = p.RT + (int64_t)a * p.NR;
-    const int32_t *__restrict__ CA = p.CA + (int64_t)a * p.NC;
-    const int32_t *__restrict__ CB = p.CB + (int64_t)a * p.NC;
     const int c_first = w0 * 32;
-    const int c_last = min(p.NC, (w0 + kw) * 32) - 1;
-    const int ca_f = __builtin_amdgcn_readfirstlane(CA[c_first]), ca_l = __builtin_amdgcn_readfirstlane(CA[c_last]);
-    const int cb_f = __builtin_amdgcn_readfirstlane(CB[c_first]), cb_l = __builtin_amdgcn_readfirstlane(CB[c_last]);
     uint16_t *__restrict__ out = p.part + ((int64_t)a * p.G + g) * p.NR;
 
     // source bounding box of a band x word group: the map is monotone in r and in c, so the four
@@ -480,61 +506,118 @@ __global__ __launch_bounds__(RUN_BAND, 4) void runs_kernel(const RunPass p, cons
         q.wxw = (minbit >> 5) & ~3;  // first window word (multiple of 4: 16-byte loads)
         q.wy0 = minrow - 7;          // a word reads up to 7 rows beside its true samples
         q.nrows = maxrow - minrow + 15;
-        q.fits = ((maxbit >> 5) + 1 - q.wxw) <= (RUN_PITCH - 1) && q.nrows <= RUN_WIN_ROWS;
+        // every selected sample lies in words wxw .. maxbit >> 5; the word after a sample's word is
+        // read too but none of its bits is ever selected, so it may hold anything
+        q.nq = max(3, (((maxbit >> 5) - q.wxw) >> 2) + 1);
+        q.fits = q.nq <= RUN_QUADS && q.nrows <= RUN_WIN_ROWS;
         return q;
     };
-    // The window (nrows x RUN_QUADS aligned 16-byte pieces, zero outside the image) is fetched into
-    // registers one band ahead -- piece i = tid + 512 n, row = i / RUN_QUADS -- so the fetch of band b+1
-    // overlaps the compute of band b and every wave carries the same share.  A thread's pieces sit
-    // at the same window positions in every band: their row / word / LDS offsets are computed once.
+    // The window (nrows x nq aligned 16-byte pieces, zero outside the image) is fetched into
+    // registers one band ahead -- piece i = tid + 512 n, row = i / nq -- so the fetch of band b+1
+    // overlaps the compute of band b and every wave carries the same share.
     constexpr int PIECES = (RUN_WIN_ROWS * RUN_QUADS + RUN_BAND - 1) / RUN_BAND;
-    int pc_rw[PIECES];  // window row | first word << 16 of the thread's n-th piece
-#pragma unroll
-    for (int n = 0; n < PIECES; n++) {
-        const int i = tid + n * RUN_BAND;
-        const int row = i / RUN_QUADS;
-        pc_rw[n] = row | ((4 * (i - row * RUN_QUADS)) << 16);
-    }
+    static_assert(RUN_QUADS == 5 && PIECES * RUN_BAND < 16384, "piece -> row uses 16-bit reciprocals of 3 and 5");
+    // (row, first word) of the thread's n-th piece.  Recomputed where it is used (4 VALU ops) from an
+    // opaque copy of tid: cached or loop-hoisted 64-bit offsets cost more registers than the kernel
+    // has, and every spill reload in the fetch sequence would wait for the loads already in flight.
+    auto piece = [&](auto NQc, int n, int &row, int &w4) {
+        constexpr int NQ = decltype(NQc)::value;
+        int t = tid;
+        asm volatile("" : "+v"(t));
+        const int i = t + n * RUN_BAND;
+        row = NQ == 4 ? (i >> 2) : (int)(((uint32_t)i * (NQ == 3 ? 21846u : 13108u)) >> 16);
+        w4 = 4 * (i - row * NQ);
+    };
     uint4 pre[PIECES];
-    auto prefetch = [&](const RunGeom &q) {
-        const uint32_t *base = p.src + ((int64_t)q.wy0 * p.src_wpr + q.wxw);  // wave-uniform
+    auto prefetch_q = [&](auto NQc, const RunGeom &q) {
+        constexpr int NQ = decltype(NQc)::value;
+        // wave-uniform base + unsigned 32-bit byte offset: one SGPR pair and one VGPR per load
+        const char *base = (const char *)(p.src + ((int64_t)q.wy0 * p.src_wpr + q.wxw));
         const int row_lo = -q.wy0, row_hi = min(q.nrows, p.src_rows - q.wy0);  // rows inside the image
         const int w_lo = -q.wxw, w_hi = p.src_wpr - q.wxw - 3;                 // 4-word pieces inside a row
 #pragma unroll
         for (int n = 0; n < PIECES; n++) {
-            const int row = pc_rw[n] & 0xffff, w4 = pc_rw[n] >> 16;
+            if (n * RUN_BAND >= q.nrows * NQ) break;  // wave-uniform: no piece of this round exists
+            int row, w4;
+            piece(NQc, n, row, w4);
             uint4 v = make_uint4(0, 0, 0, 0);
-            if (q.fits && row >= row_lo && row < row_hi && w4 >= w_lo && w4 < w_hi)
-                v = *(const uint4 *)(base + (row * p.src_wpr + w4));
+            if (row >= row_lo && row < row_hi && w4 >= w_lo && w4 < w_hi)
+                v = *(const uint4 *)(base + (uint32_t)((row * p.src_wpr + w4) * 4));
             pre[n] = v;
         }
     };
-    auto commit = [&](const RunGeom &q) {
+    auto commit_q = [&](auto NQc, const RunGeom &q) {
+        constexpr int NQ = decltype(NQc)::value;
 #pragma unroll
         for (int n = 0; n < PIECES; n++) {
-            const int row = pc_rw[n] & 0xffff, w4 = pc_rw[n] >> 16;
+            if (n * RUN_BAND >= q.nrows * NQ) break;
+            int row, w4;
+            piece(NQc, n, row, w4);
             if (row < q.nrows) {
                 uint32_t *d = (uint32_t *)(lds + RUN_WIN_OFS + row * RUN_PITCHB + w4 * 4);
                 d[0] = pre[n].x;
                 d[1] = pre[n].y;
                 d[2] = pre[n].z;
                 d[3] = pre[n].w;
-                if (w4 == 4 * (RUN_QUADS - 1)) d[4] = 0;  // spill word
             }
         }
     };
+    auto prefetch = [&](const RunGeom &q) {
+        if (!q.fits) return;
+        if (q.nq == 3) prefetch_q(std::integral_constant<int, 3>{}, q);
+        else if (q.nq == 4) prefetch_q(std::integral_constant<int, 4>{}, q);
+        else prefetch_q(std::integral_constant<int, 5>{}, q);
+    };
+    auto commit = [&](const RunGeom &q) {
+        if (q.nq == 3) commit_q(std::integral_constant<int, 3>{}, q);
+        else if (q.nq == 4) commit_q(std::integral_constant<int, 4>{}, q);
+        else commit_q(std::integral_constant<int, 5>{}, q);
+    };
+
+    // ---- prologue: the first band's fetch goes out before the run tables are staged
+    int2_t cn0, cn1;
+    corners(0, cn0, cn1);
+    int2_t rt = RT[min(wave * 64 + lane, p.NR - 1)];
+    // run tables of this block's words (16-byte copies; words past the end of the row repeat the
+    // last real word so that every lane address stays meaningful)
+    constexpr int W16 = RUN_TAB_BYTES / 16;
+    constexpr int TP = (RUN_K * W16 + RUN_BAND - 1) / RUN_BAND;
+    uint4 tv[TP];
+    {
+        const uint4 *src = (const uint4 *)(p.tabs + ((int64_t)a * p.NW + w0));
+#pragma unroll
+        for (int n = 0; n < TP; n++) {
+            const int i = tid + n * RUN_BAND;
+            const int k = i / W16, c = i - k * W16;
+            tv[n] = i < RUN_K * W16 ? src[min(k, kw - 1) * W16 + c] : make_uint4(0, 0, 0, 0);
+        }
+    }
+    int2 mv = make_int2(0, 0);  // (ca0, cb0) of word tid: read back from LDS as a broadcast
+    if (tid < RUN_K) {
+        const RunMeta *__restrict__ mt = p.meta + ((int64_t)a * p.NW + w0);
+        const int kk = min(tid, kw - 1);
+        mv = make_int2(mt[kk].ca0, mt[kk].cb0);
+    }
+    RunGeom cur = geometry(cn0, cn1);
+    prefetch(cur);
+    corners(RUN_BAND, cn0, cn1);  // next band's corners: in flight until the end of the first iteration
+    {
+        uint4 *dst = (uint4 *)(lds + RUN_TABS_OFS);
+#pragma unroll
+        for (int n = 0; n < TP; n++) {
+            const int i = tid + n * RUN_BAND;
+            if (i < RUN_K * W16) dst[i] = tv[n];
+        }
+    }
+    if (tid < RUN_K) *(int2 *)(lds + RUN_META_OFS + tid * 8) = mv;
+    if (tid < RUN_K * 32) colacc[tid] = 0;
 
     uint32_t c0[RUN_K], c1[RUN_K], c2[RUN_K];
 #pragma unroll
     for (int k = 0; k < RUN_K; k++) c0[k] = c1[k] = c2[k] = 0;
 
-    int2_t cn0, cn1;
-    corners(0, cn0, cn1);
-    RunGeom cur = geometry(cn0, cn1);
-    prefetch(cur);
-    corners(RUN_BAND, cn0, cn1);  // next band's corners: in flight until the end of the first iteration
-    int2_t rt = RT[min(wave * 64 + lane, p.NR - 1)];
     int bands_pending = 0;
+    RUN_STAMP(0)
     for (int yb = 0; yb < p.NR; yb += RUN_BAND) {
         const int r = yb + wave * 64 + lane;
         __syncthreads();  // previous band's readers are done (first pass: tables, meta, colacc staged)
@@ -544,6 +627,7 @@ __global__ __launch_bounds__(RUN_BAND, 4) void runs_kernel(const RunPass p, cons
             guard[a] = 1;
         }
         __syncthreads();
+        RUN_STAMP(1)
         const RunGeom now = cur;
         const int2_t rt_now = rt;
         if (yb + RUN_BAND < p.NR) {
@@ -552,6 +636,7 @@ __global__ __launch_bounds__(RUN_BAND, 4) void runs_kernel(const RunPass p, cons
             corners(yb + 2 * RUN_BAND, cn0, cn1);
             rt = RT[min(r + RUN_BAND, p.NR - 1)];
         }
+        RUN_STAMP(2)
         if (now.fits && yb + wave * 64 < p.NR && !(p.dbg & 1)) {
             const int rx = rt_now.x - (now.wxw << 15);  // window-local fixed point
             const int ry = rt_now.y - (now.wy0 << 10);
@@ -562,15 +647,33 @@ __global__ __launch_bounds__(RUN_BAND, 4) void runs_kernel(const RunPass p, cons
             else cnt = band_words_s<2>(lds, rx, ry, kw, valid_last, lane_ok, c0, c1, c2, nlev_blk);
             if (r < p.NR) out[r] = (uint16_t)cnt;
         }
+        RUN_STAMP(3)
         // the 3-plane counters hold at most 7 rows per lane: reduce them across lanes in time
         if (++bands_pending == RUN_FLUSH_BANDS || yb + RUN_BAND >= p.NR) {
             bands_pending = 0;
             if (!(p.dbg & 4)) flush_columns(lds, c0, c1, c2, colacc, tid);
+            RUN_STAMP(4)
         }
     }
     __syncthreads();
     // column counts of this block's (up to) 256 columns over ALL rows: one plain store each
     if (tid < RUN_K * 32 && c_first + tid < p.NC) vproj[(int64_t)a * p.NC + c_first + tid] = colacc[tid];
+    if (stamp && tid == 0) {
+        for (int i = 0; i < 5; i++) atomicAdd(&g_run_stamps[i], st_acc[i]);
+        atomicAdd(&g_run_stamps[5], run_clock() - st_t0);
+        atomicAdd(&g_run_stamps[6], 1ull);
+    }
+#undef RUN_STAMP
+}
+
+hipError_t debug_runs_stamps(unsigned long long out[8], bool reset)
+{
+    hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_run_stamps), 8 * sizeof(unsigned long long));
+    if (e == hipSuccess && reset) {
+        unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        e = hipMemcpyToSymbol(HIP_SYMBOL(g_run_stamps), z, sizeof z);
+    }
+    return e;
 }
 
 hipError_t launch_runs(const RunPass &p0, const int32_t *d_list, int n_list, int32_t *d_guard, uint32_t *d_vproj,
@@ -583,10 +686,10 @@ hipError_t launch_runs(const RunPass &p0, const int32_t *d_list, int n_list, int
         p.dbg = e ? atoi(e) : 0;
     }
     // per device and idempotent; cheap enough to repeat (the batch entry points use every device)
-    hipError_t e = hipFuncSetAttribute((const void *)runs_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       RUN_LDS_BYTES);
+    auto *kern = (p.dbg & 8) ? runs_kernel<true> : runs_kernel<false>;
+    hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, RUN_LDS_BYTES);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(runs_kernel, dim3(p.G, n_list), dim3(RUN_BAND), RUN_LDS_BYTES, s, p, d_list, d_guard, d_vproj);
+    hipLaunchKernelGGL(kern, dim3(p.G, n_list), dim3(RUN_BAND), RUN_LDS_BYTES, s, p, d_list, d_guard, d_vproj);
     return hipGetLastError();
 }
 
