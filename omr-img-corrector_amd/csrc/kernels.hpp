@@ -73,9 +73,9 @@ struct RunMeta {  // per (candidate, word)
 struct RunBlk {  // per (candidate, word group): what a sweep block needs before it can fetch
     int32_t nlev, smax;   // maxima over the group's words
     uint32_t valid_last;  // RunMeta::valid of the group's last word
-    int32_t ca_f, ca_l;   // CA at the group's first / last column
-    int32_t cb_f, cb_l;   // CB likewise
-    int32_t pad;
+    int32_t ca_min, ca_max;  // min / max of CA at the group's first and last column (CA is monotone)
+    int32_t cb_min, cb_max;  // CB likewise
+    int32_t lagbits;      // 2 bits per word pair: the pair's largest column lag
 };
 struct RunPass {  // one orientation
     const uint32_t *src;  // bit image of this orientation

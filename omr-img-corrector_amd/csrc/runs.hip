@@ -191,17 +191,22 @@ __global__ __launch_bounds__(256) void runblk_kernel(const int32_t *__restrict__
     RunBlk b;
     b.nlev = 1;
     b.smax = 0;
+    b.lagbits = 0;
     for (int k = 0; k < kw; k++) {
         b.nlev = max(b.nlev, mt[k].nlev);
         b.smax = max(b.smax, mt[k].smax);
+        b.lagbits |= mt[k].smax << (2 * (k >> 1));  // smax is 0, 1 or 2: OR of a pair = its maximum ...
     }
+    for (int k = 0; k < RUN_K; k += 2)              // ... except 1 | 2 = 3, which means 2
+        if (((b.lagbits >> k) & 3) == 3) b.lagbits &= ~(1 << k);
     b.valid_last = mt[kw - 1].valid;
     const int c_first = w0 * 32, c_last = min(NC, (w0 + kw) * 32) - 1;
-    b.ca_f = CA[(int64_t)a * NC + c_first];
-    b.ca_l = CA[(int64_t)a * NC + c_last];
-    b.cb_f = CB[(int64_t)a * NC + c_first];
-    b.cb_l = CB[(int64_t)a * NC + c_last];
-    b.pad = 0;
+    const int ca_f = CA[(int64_t)a * NC + c_first], ca_l = CA[(int64_t)a * NC + c_last];
+    const int cb_f = CB[(int64_t)a * NC + c_first], cb_l = CB[(int64_t)a * NC + c_last];
+    b.ca_min = min(ca_f, ca_l);
+    b.ca_max = max(ca_f, ca_l);
+    b.cb_min = min(cb_f, cb_l);
+    b.cb_max = max(cb_f, cb_l);
     blk[i] = b;
 }
 
@@ -290,91 +295,115 @@ __device__ __forceinline__ uint32_t merge_word(const uint32_t *d0, const uint32_
 // straight-line specialisation.  Words are processed two at a time: both fraction look-ups and all
 // 2 x NLEV window reads are issued before anything is consumed (LDS latency hiding at 4 waves per
 // SIMD).  Words past the end of the row are exact copies of the last real word with an empty mask.
-template <int NLEV, int SMAX>
-__device__ __forceinline__ uint32_t band_words(const char *lds, const int rx, const int ry, const int kw,
+// One pair of words of one band for one wave.  Both fraction look-ups and all 2 x NLEV window reads
+// are issued before anything is consumed (LDS latency hiding at 4 waves per SIMD).  Words past the
+// end of the row are exact copies of the last real word with an empty mask.
+template <int NLEV, int SMAX, int K>
+__device__ __forceinline__ uint32_t pair_words(const char *lds, const int rx, const int ry, const int kw,
                                                const uint32_t valid_last, const uint32_t lane_ok,
                                                uint32_t (&c0)[RUN_K], uint32_t (&c1)[RUN_K], uint32_t (&c2)[RUN_K])
 {
-    uint32_t cnt = 0;
-#pragma unroll
-    for (int k = 0; k < RUN_K; k += 2) {
-        // keep the pairs apart: without this fence the scheduler hoists all four pairs' loads and the
-        // kernel needs 180 VGPRs (2 waves per SIMD instead of 4)
-        __builtin_amdgcn_sched_barrier(0);
-        const int2 ma = *(const int2 *)(lds + RUN_META_OFS + k * 8);  // same address in every lane
-        const int2 mb = *(const int2 *)(lds + RUN_META_OFS + (k + 1) * 8);
-        const int ta = RUN_TABS_OFS + k * RUN_TAB_BYTES, tb = ta + RUN_TAB_BYTES;
-        const int A0a = rx + ma.x, B0a = ry + ma.y, A0b = rx + mb.x, B0b = ry + mb.y;
-        const uint32_t idya = lds_u8(lds, ta + RUN_IDXY_OFS + (B0a & 1023));
-        const uint32_t idyb = lds_u8(lds, tb + RUN_IDXY_OFS + (B0b & 1023));
-        uint32_t idxa = 0, idxb = 0;
-        if (SMAX > 0) {
-            idxa = lds_u8(lds, ta + RUN_IDXX_OFS + (A0a & 1023));
-            idxb = lds_u8(lds, tb + RUN_IDXX_OFS + (A0b & 1023));
-        }
-        const int addra = RUN_WIN_OFS + __mul24(B0a >> 10, RUN_PITCHB) + ((A0a >> 13) & ~3);
-        const int addrb = RUN_WIN_OFS + __mul24(B0b >> 10, RUN_PITCHB) + ((A0b >> 13) & ~3);
-        uint32_t a0[NLEV], a1[NLEV], b0[NLEV], b1[NLEV];
-#pragma unroll
-        for (int lv = 0; lv < NLEV; lv++) {
-            a0[lv] = *(const uint32_t *)(lds + addra + lv * RUN_PITCHB);
-            a1[lv] = *(const uint32_t *)(lds + addra + lv * RUN_PITCHB + 4);
-        }
-#pragma unroll
-        for (int lv = 0; lv < NLEV; lv++) {
-            b0[lv] = *(const uint32_t *)(lds + addrb + lv * RUN_PITCHB);
-            b1[lv] = *(const uint32_t *)(lds + addrb + lv * RUN_PITCHB + 4);
-        }
-        const uint4 *tya = (const uint4 *)(lds + ta + (idya << 5));
-        const uint4 *tyb = (const uint4 *)(lds + tb + (idyb << 5));
-        const uint4 z4 = make_uint4(0, 0, 0, 0);
-        const uint4 sa03 = tya[0], sa47 = NLEV > 4 ? tya[1] : z4;
-        const uint4 sb03 = tyb[0], sb47 = NLEV > 4 ? tyb[1] : z4;
-        uint2 sxa = make_uint2(0, 0), sxb = make_uint2(0, 0);
-        if (SMAX > 0) {
-            sxa = *(const uint2 *)(lds + ta + RUN_TUPX_OFS + (idxa << 3));
-            sxb = *(const uint2 *)(lds + tb + RUN_TUPX_OFS + (idxb << 3));
-        }
-        // word masks: everything for words before the row's last, `valid` for the last, nothing after
-        const uint32_t wma = k < kw - 1 ? 0xffffffffu : (k == kw - 1 ? valid_last : 0u);
-        const uint32_t wmb = k + 1 < kw - 1 ? 0xffffffffu : (k + 1 == kw - 1 ? valid_last : 0u);
-        const uint32_t Da = merge_word<NLEV, SMAX>(a0, a1, (uint32_t)(A0a >> 10), sa03, sa47, sxa) & wma & lane_ok;
-        const uint32_t Db = merge_word<NLEV, SMAX>(b0, b1, (uint32_t)(A0b >> 10), sb03, sb47, sxb) & wmb & lane_ok;
-        cnt += __popc(Da) + __popc(Db);
-        // bit-sliced add of a 1-bit value per column into the 3-plane counters (k is a constant after
-        // unrolling, so the counters stay in registers)
-#define RUN_ACC(KA)                        \
-    {                                      \
-        uint32_t t = c0[KA] & Da;          \
-        c2[KA] |= c1[KA] & t;              \
-        c1[KA] ^= t;                       \
-        c0[KA] ^= Da;                      \
-        t = c0[KA + 1] & Db;               \
-        c2[KA + 1] |= c1[KA + 1] & t;      \
-        c1[KA + 1] ^= t;                   \
-        c0[KA + 1] ^= Db;                  \
+    constexpr int k = K;
+    const int2 ma = *(const int2 *)(lds + RUN_META_OFS + k * 8);  // same address in every lane
+    const int2 mb = *(const int2 *)(lds + RUN_META_OFS + (k + 1) * 8);
+    const int ta = RUN_TABS_OFS + k * RUN_TAB_BYTES, tb = ta + RUN_TAB_BYTES;
+    const int A0a = rx + ma.x, B0a = ry + ma.y, A0b = rx + mb.x, B0b = ry + mb.y;
+    const uint32_t idya = lds_u8(lds, ta + RUN_IDXY_OFS + (B0a & 1023));
+    const uint32_t idyb = lds_u8(lds, tb + RUN_IDXY_OFS + (B0b & 1023));
+    uint32_t idxa = 0, idxb = 0;
+    if (SMAX > 0) {
+        idxa = lds_u8(lds, ta + RUN_IDXX_OFS + (A0a & 1023));
+        idxb = lds_u8(lds, tb + RUN_IDXX_OFS + (A0b & 1023));
     }
-        RUN_ACC(k)
-#undef RUN_ACC
+    const int addra = RUN_WIN_OFS + __mul24(B0a >> 10, RUN_PITCHB) + ((A0a >> 13) & ~3);
+    const int addrb = RUN_WIN_OFS + __mul24(B0b >> 10, RUN_PITCHB) + ((A0b >> 13) & ~3);
+    uint32_t a0[NLEV], a1[NLEV], b0[NLEV], b1[NLEV];
+#pragma unroll
+    for (int lv = 0; lv < NLEV; lv++) {
+        a0[lv] = *(const uint32_t *)(lds + addra + lv * RUN_PITCHB);
+        a1[lv] = *(const uint32_t *)(lds + addra + lv * RUN_PITCHB + 4);
     }
+#pragma unroll
+    for (int lv = 0; lv < NLEV; lv++) {
+        b0[lv] = *(const uint32_t *)(lds + addrb + lv * RUN_PITCHB);
+        b1[lv] = *(const uint32_t *)(lds + addrb + lv * RUN_PITCHB + 4);
+    }
+    const uint4 *tya = (const uint4 *)(lds + ta + (idya << 5));
+    const uint4 *tyb = (const uint4 *)(lds + tb + (idyb << 5));
+    const uint4 z4 = make_uint4(0, 0, 0, 0);
+    const uint4 sa03 = tya[0], sa47 = NLEV > 4 ? tya[1] : z4;
+    const uint4 sb03 = tyb[0], sb47 = NLEV > 4 ? tyb[1] : z4;
+    uint2 sxa = make_uint2(0, 0), sxb = make_uint2(0, 0);
+    if (SMAX > 0) {
+        sxa = *(const uint2 *)(lds + ta + RUN_TUPX_OFS + (idxa << 3));
+        sxb = *(const uint2 *)(lds + tb + RUN_TUPX_OFS + (idxb << 3));
+    }
+    // word masks: everything for words before the row's last, `valid` for the last, nothing after
+    const uint32_t wma = k < kw - 1 ? 0xffffffffu : (k == kw - 1 ? valid_last : 0u);
+    const uint32_t wmb = k + 1 < kw - 1 ? 0xffffffffu : (k + 1 == kw - 1 ? valid_last : 0u);
+    const uint32_t Da = merge_word<NLEV, SMAX>(a0, a1, (uint32_t)(A0a >> 10), sa03, sa47, sxa) & wma & lane_ok;
+    const uint32_t Db = merge_word<NLEV, SMAX>(b0, b1, (uint32_t)(A0b >> 10), sb03, sb47, sxb) & wmb & lane_ok;
+    // bit-sliced add of a 1-bit value per column into the 3-plane counters (K is a constant, so the
+    // counters stay in registers)
+    uint32_t t = c0[k] & Da;
+    c2[k] |= c1[k] & t;
+    c1[k] ^= t;
+    c0[k] ^= Da;
+    t = c0[k + 1] & Db;
+    c2[k + 1] |= c1[k + 1] & t;
+    c1[k + 1] ^= t;
+    c0[k + 1] ^= Db;
+    return __popc(Da) + __popc(Db);
+}
+
+// A pair's column lag bound (0, 1 or 2; wave-uniform) picks its specialisation: most words of a
+// candidate need no lag handling even when some word of the block does.
+template <int NLEV, int K>
+__device__ __forceinline__ uint32_t pair_dispatch(const char *lds, const int rx, const int ry, const int kw,
+                                                  const uint32_t valid_last, const uint32_t lane_ok,
+                                                  uint32_t (&c0)[RUN_K], uint32_t (&c1)[RUN_K], uint32_t (&c2)[RUN_K],
+                                                  const int lagbits)
+{
+    // keep the pairs apart: without this fence the scheduler hoists all four pairs' loads and the
+    // kernel needs 180 VGPRs (2 waves per SIMD instead of 4)
+    __builtin_amdgcn_sched_barrier(0);
+    const int lag = (lagbits >> K) & 3;
+    if (lag == 0) return pair_words<NLEV, 0, K>(lds, rx, ry, kw, valid_last, lane_ok, c0, c1, c2);
+    if (lag == 1) return pair_words<NLEV, 1, K>(lds, rx, ry, kw, valid_last, lane_ok, c0, c1, c2);
+    return pair_words<NLEV, 2, K>(lds, rx, ry, kw, valid_last, lane_ok, c0, c1, c2);
+}
+
+// The RUN_K words of one band for one wave.  NLEV is uniform for the whole block (maximum over its
+// words; unused levels have empty masks), so the block dispatches once per band to a straight-line
+// specialisation.
+template <int NLEV>
+__device__ __forceinline__ uint32_t band_words(const char *lds, const int rx, const int ry, const int kw,
+                                               const uint32_t valid_last, const uint32_t lane_ok,
+                                               uint32_t (&c0)[RUN_K], uint32_t (&c1)[RUN_K], uint32_t (&c2)[RUN_K],
+                                               const int lagbits)
+{
+    static_assert(RUN_K == 8, "four pairs");
+    uint32_t cnt = pair_dispatch<NLEV, 0>(lds, rx, ry, kw, valid_last, lane_ok, c0, c1, c2, lagbits);
+    cnt += pair_dispatch<NLEV, 2>(lds, rx, ry, kw, valid_last, lane_ok, c0, c1, c2, lagbits);
+    cnt += pair_dispatch<NLEV, 4>(lds, rx, ry, kw, valid_last, lane_ok, c0, c1, c2, lagbits);
+    cnt += pair_dispatch<NLEV, 6>(lds, rx, ry, kw, valid_last, lane_ok, c0, c1, c2, lagbits);
     return cnt;
 }
 
-template <int SMAX>
 __device__ __forceinline__ uint32_t band_words_s(const char *lds, const int rx, const int ry, const int kw,
                                                  const uint32_t valid_last, const uint32_t lane_ok,
                                                  uint32_t (&c0)[RUN_K], uint32_t (&c1)[RUN_K], uint32_t (&c2)[RUN_K],
-                                                 const int nlev)
+                                                 const int nlev, const int lagbits)
 {
     switch (nlev) {
-    case 1: return band_words<1, SMAX>(lds, rx, ry, kw, valid_last, lane_ok, c0, c1, c2);
-    case 2: return band_words<2, SMAX>(lds, rx, ry, kw, valid_last, lane_ok, c0, c1, c2);
-    case 3: return band_words<3, SMAX>(lds, rx, ry, kw, valid_last, lane_ok, c0, c1, c2);
-    case 4: return band_words<4, SMAX>(lds, rx, ry, kw, valid_last, lane_ok, c0, c1, c2);
-    case 5: return band_words<5, SMAX>(lds, rx, ry, kw, valid_last, lane_ok, c0, c1, c2);
-    case 6: return band_words<6, SMAX>(lds, rx, ry, kw, valid_last, lane_ok, c0, c1, c2);
-    case 7: return band_words<7, SMAX>(lds, rx, ry, kw, valid_last, lane_ok, c0, c1, c2);
-    default: return band_words<8, SMAX>(lds, rx, ry, kw, valid_last, lane_ok, c0, c1, c2);
+    case 1: return band_words<1>(lds, rx, ry, kw, valid_last, lane_ok, c0, c1, c2, lagbits);
+    case 2: return band_words<2>(lds, rx, ry, kw, valid_last, lane_ok, c0, c1, c2, lagbits);
+    case 3: return band_words<3>(lds, rx, ry, kw, valid_last, lane_ok, c0, c1, c2, lagbits);
+    case 4: return band_words<4>(lds, rx, ry, kw, valid_last, lane_ok, c0, c1, c2, lagbits);
+    case 5: return band_words<5>(lds, rx, ry, kw, valid_last, lane_ok, c0, c1, c2, lagbits);
+    case 6: return band_words<6>(lds, rx, ry, kw, valid_last, lane_ok, c0, c1, c2, lagbits);
+    case 7: return band_words<7>(lds, rx, ry, kw, valid_last, lane_ok, c0, c1, c2, lagbits);
+    default: return band_words<8>(lds, rx, ry, kw, valid_last, lane_ok, c0, c1, c2, lagbits);
     }
 }
 
@@ -481,9 +510,9 @@ __global__ __launch_bounds__(RUN_BAND, 4) void runs_kernel(const RunPass p, cons
 
     // block constants: one scalar load (the address is uniform)
     const RunBlk bk = p.blk[(int64_t)a * p.G + g];
-    const int nlev_blk = bk.nlev, smax_blk = bk.smax;
+    const int nlev_blk = bk.nlev, lagbits = bk.lagbits;
     const uint32_t valid_last = bk.valid_last;
-    const int ca_f = bk.ca_f, ca_l = bk.ca_l, cb_f = bk.cb_f, cb_l = bk.cb_l;
+    const int ca_min = bk.ca_min, ca_max = bk.ca_max, cb_min = bk.cb_min, cb_max = bk.cb_max;
     const int2_t *__restrict__ RT = p.RT + (int64_t)a * p.NR;
     const int c_first = w0 * 32;
     uint16_t *__restrict__ out = p.part + ((int64_t)a * p.G + g) * p.NR;
@@ -499,10 +528,10 @@ __global__ __launch_bounds__(RUN_BAND, 4) void runs_kernel(const RunPass p, cons
         RunGeom q;
         const int t0x = __builtin_amdgcn_readfirstlane(t0.x), t0y = __builtin_amdgcn_readfirstlane(t0.y);
         const int t1x = __builtin_amdgcn_readfirstlane(t1.x), t1y = __builtin_amdgcn_readfirstlane(t1.y);
-        const int minbit = min(min(t0x + ca_f, t0x + ca_l), min(t1x + ca_f, t1x + ca_l)) >> 10;
-        const int maxbit = max(max(t0x + ca_f, t0x + ca_l), max(t1x + ca_f, t1x + ca_l)) >> 10;
-        const int minrow = min(min(t0y + cb_f, t0y + cb_l), min(t1y + cb_f, t1y + cb_l)) >> 10;
-        const int maxrow = max(max(t0y + cb_f, t0y + cb_l), max(t1y + cb_f, t1y + cb_l)) >> 10;
+        const int minbit = (min(t0x, t1x) + ca_min) >> 10;  // min over the four corners
+        const int maxbit = (max(t0x, t1x) + ca_max) >> 10;
+        const int minrow = (min(t0y, t1y) + cb_min) >> 10;
+        const int maxrow = (max(t0y, t1y) + cb_max) >> 10;
         q.wxw = (minbit >> 5) & ~3;  // first window word (multiple of 4: 16-byte loads)
         q.wy0 = minrow - 7;          // a word reads up to 7 rows beside its true samples
         q.nrows = maxrow - minrow + 15;
@@ -513,65 +542,64 @@ __global__ __launch_bounds__(RUN_BAND, 4) void runs_kernel(const RunPass p, cons
         return q;
     };
     // The window (nrows x nq aligned 16-byte pieces, zero outside the image) is fetched into
-    // registers one band ahead -- piece i = tid + 512 n, row = i / nq -- so the fetch of band b+1
-    // overlaps the compute of band b and every wave carries the same share.
+    // registers one band ahead, so the fetch of band b+1 overlaps the compute of band b and every
+    // wave carries the same share.  A round of the block covers rpr = 512 / nq whole rows: thread t
+    // owns piece t % nq of row t / nq + n * rpr in round n, so both its global and its LDS address
+    // advance by a wave-uniform stride.  The loads go through a buffer descriptor of the bit image:
+    // rows above / below the image give byte offsets outside [0, num_records) (as unsigned), which
+    // the hardware range check turns into zeros, and a thread whose words lie left / right of the
+    // image (the same in every round) uses an offset that is out of range in every round -- no
+    // compare, no branch and no zero fill per piece.
     constexpr int PIECES = (RUN_WIN_ROWS * RUN_QUADS + RUN_BAND - 1) / RUN_BAND;
-    static_assert(RUN_QUADS == 5 && PIECES * RUN_BAND < 16384, "piece -> row uses 16-bit reciprocals of 3 and 5");
-    // (row, first word) of the thread's n-th piece.  Recomputed where it is used (4 VALU ops) from an
-    // opaque copy of tid: cached or loop-hoisted 64-bit offsets cost more registers than the kernel
-    // has, and every spill reload in the fetch sequence would wait for the loads already in flight.
-    auto piece = [&](auto NQc, int n, int &row, int &w4) {
-        constexpr int NQ = decltype(NQc)::value;
+    static_assert(RUN_QUADS == 5 && RUN_BAND == 512, "piece -> row uses 16-bit reciprocals of 3 and 5");
+    static_assert(PIECES * (RUN_BAND / RUN_QUADS) >= RUN_WIN_ROWS, "rounds cover the window");
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)p.src, /*stride*/ 0, (int)((uint32_t)p.src_rows * (uint32_t)p.src_wpr * 4u), 0x00020000);
+    // (row, first word) of the thread's round-0 piece.  Recomputed where it is used from an opaque
+    // copy of tid: cached or loop-hoisted offsets cost more registers than the kernel has, and a
+    // spill reload inside the fetch sequence would wait for the loads already in flight.
+    auto piece0 = [&](const RunGeom &q, int &row0, int &w4, int &rpr) {
         int t = tid;
         asm volatile("" : "+v"(t));
-        const int i = t + n * RUN_BAND;
-        row = NQ == 4 ? (i >> 2) : (int)(((uint32_t)i * (NQ == 3 ? 21846u : 13108u)) >> 16);
-        w4 = 4 * (i - row * NQ);
+        const uint32_t magic = q.nq == 3 ? 21846u : (q.nq == 4 ? 16384u : 13108u);  // 65536 / nq, rounded up
+        rpr = q.nq == 3 ? 170 : (q.nq == 4 ? 128 : 102);
+        row0 = (int)(((uint32_t)t * magic) >> 16);
+        w4 = 4 * (t - row0 * q.nq);
     };
-    uint4 pre[PIECES];
-    auto prefetch_q = [&](auto NQc, const RunGeom &q) {
-        constexpr int NQ = decltype(NQc)::value;
-        // wave-uniform base + unsigned 32-bit byte offset: one SGPR pair and one VGPR per load
-        const char *base = (const char *)(p.src + ((int64_t)q.wy0 * p.src_wpr + q.wxw));
-        const int row_lo = -q.wy0, row_hi = min(q.nrows, p.src_rows - q.wy0);  // rows inside the image
-        const int w_lo = -q.wxw, w_hi = p.src_wpr - q.wxw - 3;                 // 4-word pieces inside a row
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 pre[PIECES];
+    auto prefetch = [&](const RunGeom &q) {
+        if (!q.fits) return;
+        int row0, w4, rpr;
+        piece0(q, row0, w4, rpr);
+        const int w = q.wxw + w4;
+        const bool in_w = row0 < rpr && w >= 0 && w + 3 < p.src_wpr;
+        // out-of-image threads: 2^31 stays out of range after adding any round's stride (< 2^31)
+        const uint32_t voff = in_w ? (uint32_t)(((q.wy0 + row0) * p.src_wpr + w) * 4) : 0x80000000u;
+        const uint32_t stride = (uint32_t)(rpr * p.src_wpr * 4);
 #pragma unroll
         for (int n = 0; n < PIECES; n++) {
-            if (n * RUN_BAND >= q.nrows * NQ) break;  // wave-uniform: no piece of this round exists
-            int row, w4;
-            piece(NQc, n, row, w4);
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (row >= row_lo && row < row_hi && w4 >= w_lo && w4 < w_hi)
-                v = *(const uint4 *)(base + (uint32_t)((row * p.src_wpr + w4) * 4));
-            pre[n] = v;
+            if (n * rpr >= q.nrows) break;  // wave-uniform: this round has no rows
+            pre[n] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(voff + n * stride), 0, 0);
         }
     };
-    auto commit_q = [&](auto NQc, const RunGeom &q) {
-        constexpr int NQ = decltype(NQc)::value;
+    auto commit = [&](const RunGeom &q) {
+        int row0, w4, rpr;
+        piece0(q, row0, w4, rpr);
+        char *d0 = lds + RUN_WIN_OFS + row0 * RUN_PITCHB + w4 * 4;
+        const int rows_left = row0 < rpr ? q.nrows - row0 : 0;
+        const int dstride = rpr * RUN_PITCHB;
 #pragma unroll
         for (int n = 0; n < PIECES; n++) {
-            if (n * RUN_BAND >= q.nrows * NQ) break;
-            int row, w4;
-            piece(NQc, n, row, w4);
-            if (row < q.nrows) {
-                uint32_t *d = (uint32_t *)(lds + RUN_WIN_OFS + row * RUN_PITCHB + w4 * 4);
+            if (n * rpr >= q.nrows) break;
+            if (n * rpr < rows_left) {
+                uint32_t *d = (uint32_t *)(d0 + n * dstride);
                 d[0] = pre[n].x;
                 d[1] = pre[n].y;
                 d[2] = pre[n].z;
                 d[3] = pre[n].w;
             }
         }
-    };
-    auto prefetch = [&](const RunGeom &q) {
-        if (!q.fits) return;
-        if (q.nq == 3) prefetch_q(std::integral_constant<int, 3>{}, q);
-        else if (q.nq == 4) prefetch_q(std::integral_constant<int, 4>{}, q);
-        else prefetch_q(std::integral_constant<int, 5>{}, q);
-    };
-    auto commit = [&](const RunGeom &q) {
-        if (q.nq == 3) commit_q(std::integral_constant<int, 3>{}, q);
-        else if (q.nq == 4) commit_q(std::integral_constant<int, 4>{}, q);
-        else commit_q(std::integral_constant<int, 5>{}, q);
     };
 
     // ---- prologue: the first band's fetch goes out before the run tables are staged
@@ -641,10 +669,7 @@ __global__ __launch_bounds__(RUN_BAND, 4) void runs_kernel(const RunPass p, cons
             const int rx = rt_now.x - (now.wxw << 15);  // window-local fixed point
             const int ry = rt_now.y - (now.wy0 << 10);
             const uint32_t lane_ok = r < p.NR ? 0xffffffffu : 0u;  // rows past the end count nothing
-            uint32_t cnt = 0;
-            if (smax_blk == 1) cnt = band_words_s<1>(lds, rx, ry, kw, valid_last, lane_ok, c0, c1, c2, nlev_blk);
-            else if (smax_blk == 0) cnt = band_words_s<0>(lds, rx, ry, kw, valid_last, lane_ok, c0, c1, c2, nlev_blk);
-            else cnt = band_words_s<2>(lds, rx, ry, kw, valid_last, lane_ok, c0, c1, c2, nlev_blk);
+            const uint32_t cnt = band_words_s(lds, rx, ry, kw, valid_last, lane_ok, c0, c1, c2, nlev_blk, lagbits);
             if (r < p.NR) out[r] = (uint16_t)cnt;
         }
         RUN_STAMP(3)
