@@ -42,39 +42,44 @@ def make_scans(n, seed0, dev):
     return torch.stack(cards).to(dev), thetas
 
 
-def cpu_baseline(gray, gpu_vs, gpu_hs, sample_angles):
+def cpu_baseline(gray, gpu_vs, gpu_hs, budget_s):
     """The oracle ("port" of the reference CPU path, oracle/oracle.c) timed on this box's host
-    cores on a bounded sample: `sample_angles` evenly spaced candidates of one scan.  Also the
-    run's parity check: the sampled scores must equal the GPU's bit for bit."""
+    cores on a bounded sample of the same workload: whole 400-candidate sweeps of one scan,
+    angle-parallel over all cores, repeated until about 2/3 of `budget_s` seconds are spent; then
+    16-candidate slices on one thread for the rest.  Also the run's parity check: every candidate's
+    scores must equal the GPU's bit for bit."""
     from oracle import oracle as orc
     orc.build()
     b = orc.threshold_binary(gray)
     Ms = orc.rotation_matrices(ROWS, COLS, MAX_ANGLE, STEP)
     A = Ms.shape[0]
     cores = min(os.cpu_count() or 1, 64)
-    sample_angles = min(A, max(sample_angles, 2 * cores))
-    pick = np.linspace(0, A - 1, sample_angles).astype(int)
-    orc.sweep_matrices(b, Ms[pick[:2]], threads=1, want_proj=False, fast=True)  # warm-up
-    t0 = time.perf_counter()
-    _, _, vs1, hs1 = orc.sweep_matrices(b, Ms[pick[: max(4, sample_angles // 8)]], threads=1, want_proj=False, fast=True)
-    t1 = time.perf_counter()
-    _, _, vs, hs = orc.sweep_matrices(b, Ms[pick], threads=cores, want_proj=False, fast=True)
-    t2 = time.perf_counter()
-    n1 = max(4, sample_angles // 8)
-    ok = bool((vs.view(np.uint64) == gpu_vs[pick].view(np.uint64)).all()
-              and (hs.view(np.uint64) == gpu_hs[pick].view(np.uint64)).all())
-    per_angle_1 = (t1 - t0) / n1
-    per_angle_all = (t2 - t1) / sample_angles
+    orc.sweep_matrices(b, Ms[:2], threads=1, want_proj=False, fast=True)  # warm-up
+    sweeps, t_all, ok = 0, 0.0, True
+    while sweeps < 1 or t_all < budget_s * 2.0 / 3.0:
+        t0 = time.perf_counter()
+        _, _, vs, hs = orc.sweep_matrices(b, Ms, threads=cores, want_proj=False, fast=True)
+        t_all += time.perf_counter() - t0
+        sweeps += 1
+        ok = ok and bool((vs.view(np.uint64) == gpu_vs.view(np.uint64)).all()
+                         and (hs.view(np.uint64) == gpu_hs.view(np.uint64)).all())
+    n1, t_1 = 0, 0.0
+    while n1 < 16 or (t_1 < budget_s / 3.0 and n1 + 16 <= A):
+        t0 = time.perf_counter()
+        orc.sweep_matrices(b, Ms[n1:n1 + 16], threads=1, want_proj=False, fast=True)
+        t_1 += time.perf_counter() - t0
+        n1 += 16
     return {
-        "value": 1.0 / (per_angle_all * A),
+        "value": sweeps / t_all,
         "unit": "images/s",
         "cores": cores,
         "kind": "port",
-        "sample": "1 scan, %d of %d candidates evenly spaced, angle-parallel OpenMP over all host cores "
+        "sample": "%d whole sweep(s) of one scan (all %d candidates), angle-parallel OpenMP over all host cores, %.1f s "
                   "(oracle/oracle.c -O3: warp + clone + 2 projection passes + 2 std-devs per candidate)"
-                  % (sample_angles, A),
-        "single_thread_value": 1.0 / (per_angle_1 * A),
-        "single_thread_sample": "%d candidates, 1 thread (threads=1 is what every reference caller passes)" % n1,
+                  % (sweeps, A, t_all),
+        "single_thread_value": n1 / (t_1 * A),
+        "single_thread_sample": "%d candidates, 1 thread, %.1f s (threads=1 is what every reference caller passes)"
+                                % (n1, t_1),
         "parity_vs_gpu": ok,
     }
 
@@ -88,7 +93,7 @@ def main():
     ap.add_argument("--streams", type=int, default=1,
                     help="HIP streams per GPU; the sweep kernel fills the chip by itself, so 1 keeps the "
                          "per-kernel HIP-event / rocprof durations free of cross-stream overlap")
-    ap.add_argument("--cpu-sample-angles", type=int, default=48)
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="wall-clock budget of the CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -196,7 +201,7 @@ def main():
         }
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(scans[0].cpu().numpy(), vs[0].cpu().numpy(), hs[0].cpu().numpy(),
-                                               args.cpu_sample_angles)
+                                               args.cpu_seconds)
     batch.close()
     if world > 1:
         torch.distributed.barrier()
