@@ -249,6 +249,60 @@ int omr_rotate_device(const uint8_t *d_src, int64_t src_step, int32_t rows, int3
                       const uint8_t border_value[4], int32_t clip, uint8_t *d_dst, int64_t dst_step,
                       int32_t dst_rows, int32_t dst_cols, void *stream);
 
+/* ---- Hough-line deskew path ---------------------------------------------
+ * OpenCV 4.6.0 semantics restated on the GPU: Canny is exact (integer stencils + a set-valued
+ * hysteresis); HoughLinesP keeps hough.cpp's point order (cv::RNG seed 2^64-1), float32 votes and
+ * 16.16 line walks, so the segments are the reference's segments, not an approximation. */
+
+/* imgproc::canny(src, &mut edges, low, high, 3, false): call sites hough.rs:27 (50, 150 on the gray
+ * scan), omr.rs:239 (on the 3-channel scan: per pixel the channel with the largest |dx|+|dy|),
+ * omr.rs:323-330.  edges: 1 channel, 0 / 255. */
+int omr_canny(const omr_image *src, double low_thresh, double high_thresh, omr_image_owned *edges);
+
+/* imgproc::hough_lines_p(&edges, &mut lines, rho, theta, threshold, min_line_length, max_line_gap):
+ * hough.rs:31-43, omr.rs:245-253 (rho 1, theta pi/180, threshold 0).  lines: cap x (x0, y0, x1, y1);
+ * *n_lines = segments found (call again with a larger buffer if it exceeds cap).  theta must give
+ * at most 192 accumulator angles (-213 otherwise). */
+int omr_hough_lines_p(const omr_image *edges_u8c1, double rho, double theta, int32_t threshold,
+                      double min_line_length, double max_line_gap, int32_t *lines, int32_t cap,
+                      int32_t *n_lines);
+
+/* oics::hough::get_angle_with_hough(&TransformableMatrix, min_line_length, max_line_gap, file_name,
+ * edge_image_output_dir) -> Result<f64> (hough.rs:17-100; called core/src/main.rs:103-110,
+ * app/src-tauri/src/test.rs:383-390).  The debug picture the reference writes with imwrite
+ * (hough.rs:46-63, :94-99) is host-side codec work and stays with the caller, hence no file
+ * arguments.  No segment found: -215 (the reference panics on angles[0], hough.rs:74). */
+int omr_get_angle_with_hough(const omr_image *gray, double min_line_length, double max_line_gap,
+                             double *angle_out);
+
+/* oics::omr::get_result_from_edges_detection(&Mat, f64, f64) -> Result<OmrResult> (omr.rs:231-302). */
+int omr_get_result_from_edges_detection(const omr_image *src, double edges_min_line_length,
+                                        double edges_max_line_gap, double *angle, int32_t *status,
+                                        double *candidates, int32_t cand_cap, int32_t *cand_len);
+
+/* The same on n device-resident scans of one shape (one workgroup per scan in the sequential Hough
+ * stage): BASELINE config 4.  angles / status / n_lines: host arrays of n; a scan without any
+ * segment reports status NotAResult and angle 0 instead of the reference's panic. */
+int omr_edges_detection_batch_device(const uint8_t *d_scans, int32_t n, int64_t scan_stride_bytes,
+                                     int32_t rows, int32_t cols, int32_t channels, int64_t step_bytes,
+                                     double min_line_length, double max_line_gap, double *angles,
+                                     int32_t *status, int32_t *n_lines, void *stream);
+
+/* The decision of correct_default (omr.rs:351-399): which angle to rotate by and whether the sheet
+ * needs a manual check, from the projection result and the edges result. */
+void omr_correct_default_decision(double proj_angle, int32_t proj_status, const double *proj_candidates,
+                                  int32_t n_cand, double edges_angle, double *rotate_angle,
+                                  int32_t *need_check);
+
+/* oics::omr::correct_default(input_file, output_file, u16, f64, i32, i32, f64, f64) ->
+ * Result<(f64, bool)> (omr.rs:339-448; called app/src-tauri/src/task.rs:38-47) on a decoded BGR
+ * image: imread / imwrite stay on the host side of the shim.  rotated may be NULL. */
+int omr_correct_default(const omr_image *src_bgr, uint16_t projection_max_angle,
+                        double projection_angle_step, int32_t projection_max_width,
+                        int32_t projection_max_height, double hough_min_line_length,
+                        double hough_max_line_gap, double *rotate_angle, int32_t *need_check,
+                        omr_image_owned *rotated);
+
 /* calculate::get_arithmetic_mean / get_standard_deviation (calculate.rs:2-10, :13-23) */
 int omr_get_arithmetic_mean(const double *v, size_t n, double *out);
 int omr_get_standard_deviation(const double *v, size_t n, double *out);

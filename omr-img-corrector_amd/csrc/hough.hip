@@ -1,0 +1,523 @@
+// hough.hip -- Canny + progressive probabilistic Hough (OpenCV 4.6.0 semantics) for gfx950.
+//
+// Canny is data-parallel and exact: Sobel / non-maximum suppression are integer stencils and the
+// hysteresis result is a set (the candidates 8-connected to a strong pixel), so the order of
+// propagation does not matter.  HoughLinesP is a *sequential* randomised algorithm (hough.cpp
+// HoughLinesProbabilistic: every drawn point sees the accumulator and the mask left by all points
+// before it), so the kernel keeps the sequence and parallelises inside a step -- one workgroup per
+// scan, lane = accumulator angle for the 180 votes, lane = position for the line walks -- and
+// across scans (one workgroup each; a batch fills the chip).  Same RNG (cv::RNG seed 2^64-1), same
+// float32 vote arithmetic (no contraction), same 16.16 walk: the segments are bit-identical to the
+// CPU restatement.
+//
+// Reference call sites: packages/lib/src/hough.rs:27-43, packages/lib/src/omr.rs:236-253, :323-330.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "hough.hpp"
+
+namespace omr {
+
+// ------------------------------------------------------------------------------------------
+// Canny: Sobel 3x3 (BORDER_REPLICATE) -> L1 magnitude -> sector test -> map {0, 1, 2}
+#define CN_TW 64
+#define CN_TH 16
+#define CN_THREADS 256
+
+template <int CN>
+__global__ __launch_bounds__(CN_THREADS) void canny_nms_kernel(const uint8_t *__restrict__ src, int64_t scan_stride,
+                                                               int64_t step, int rows, int cols, int low, int high,
+                                                               uint8_t *__restrict__ map)
+{
+    constexpr int SW = CN_TW + 4, SH = CN_TH + 4;  // source tile, 2 px halo
+    constexpr int MW = CN_TW + 2, MH = CN_TH + 2;  // gradient tile, 1 px halo
+    __shared__ uint8_t s_src[SH][SW * CN];
+    __shared__ uint16_t s_mag[MH][MW];
+    __shared__ short2 s_g[MH][MW];
+    const int x0 = blockIdx.x * CN_TW, y0 = blockIdx.y * CN_TH;
+    src += (int64_t)blockIdx.z * scan_stride;
+    map += (int64_t)blockIdx.z * rows * cols;
+    for (int i = threadIdx.x; i < SH * SW; i += CN_THREADS) {
+        const int ty = i / SW, tx = i - ty * SW;
+        const int gy = min(max(y0 + ty - 2, 0), rows - 1), gx = min(max(x0 + tx - 2, 0), cols - 1);
+        const uint8_t *p = src + (int64_t)gy * step + (int64_t)gx * CN;
+#pragma unroll
+        for (int c = 0; c < CN; c++) s_src[ty][tx * CN + c] = p[c];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < MH * MW; i += CN_THREADS) {
+        const int my = i / MW, mx = i - my * MW;
+        const int y = y0 + my - 1, x = x0 + mx - 1;
+        int bm = 0, bx = 0, by = 0;
+        if (y >= 0 && y < rows && x >= 0 && x < cols) {
+            const int ty = my + 1, tx = mx + 1;
+#pragma unroll
+            for (int c = 0; c < CN; c++) {
+                const int a00 = s_src[ty - 1][(tx - 1) * CN + c], a01 = s_src[ty - 1][tx * CN + c];
+                const int a02 = s_src[ty - 1][(tx + 1) * CN + c], a10 = s_src[ty][(tx - 1) * CN + c];
+                const int a12 = s_src[ty][(tx + 1) * CN + c], a20 = s_src[ty + 1][(tx - 1) * CN + c];
+                const int a21 = s_src[ty + 1][tx * CN + c], a22 = s_src[ty + 1][(tx + 1) * CN + c];
+                const int dx = (a02 + 2 * a12 + a22) - (a00 + 2 * a10 + a20);
+                const int dy = (a20 + 2 * a21 + a22) - (a00 + 2 * a01 + a02);
+                const int m = abs(dx) + abs(dy);
+                if (c == 0 || m > bm) bm = m, bx = dx, by = dy;  // first channel with the largest magnitude
+            }
+        }
+        s_mag[my][mx] = (uint16_t)bm;  // <= 2040
+        s_g[my][mx] = make_short2((short)bx, (short)by);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < CN_TH * CN_TW; i += CN_THREADS) {
+        const int py = i / CN_TW, px = i - py * CN_TW;
+        const int y = y0 + py, x = x0 + px;
+        if (y >= rows || x >= cols) continue;
+        const int my = py + 1, mx = px + 1;
+        const int m = s_mag[my][mx];
+        bool edge = false;
+        if (m > low) {
+            const int xs = s_g[my][mx].x, ys = s_g[my][mx].y;
+            const int ax = abs(xs), ay = abs(ys) << 15;
+            const int tg22x = ax * 13573;
+            if (ay < tg22x) {
+                edge = m > s_mag[my][mx - 1] && m >= s_mag[my][mx + 1];
+            } else {
+                const int tg67x = tg22x + (ax << 16);
+                if (ay > tg67x) {
+                    edge = m > s_mag[my - 1][mx] && m >= s_mag[my + 1][mx];
+                } else {
+                    const int sgn = (xs ^ ys) < 0 ? -1 : 1;
+                    edge = m > s_mag[my - 1][mx - sgn] && m > s_mag[my + 1][mx + sgn];
+                }
+            }
+        }
+        map[(int64_t)y * cols + x] = edge ? (m > high ? 2 : 0) : 1;
+    }
+}
+
+hipError_t launch_canny_nms(const uint8_t *d_src, int64_t scan_stride, int64_t row_step, int rows, int cols, int cn,
+                            int n, int low, int high, uint8_t *d_map, hipStream_t s)
+{
+    const dim3 grid((cols + CN_TW - 1) / CN_TW, (rows + CN_TH - 1) / CN_TH, n);
+    if (cn == 1)
+        hipLaunchKernelGGL(canny_nms_kernel<1>, grid, dim3(CN_THREADS), 0, s, d_src, scan_stride, row_step, rows, cols,
+                           low, high, d_map);
+    else if (cn == 3)
+        hipLaunchKernelGGL(canny_nms_kernel<3>, grid, dim3(CN_THREADS), 0, s, d_src, scan_stride, row_step, rows, cols,
+                           low, high, d_map);
+    else if (cn == 4)
+        hipLaunchKernelGGL(canny_nms_kernel<4>, grid, dim3(CN_THREADS), 0, s, d_src, scan_stride, row_step, rows, cols,
+                           low, high, d_map);
+    else
+        return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+// Hysteresis: every tile runs to its local fixed point in LDS; tiles exchange through the map
+// between launches, the host relaunches until no tile changed.
+#define HY_TW 64
+#define HY_TH 32
+#define HY_THREADS 256
+
+__global__ __launch_bounds__(HY_THREADS) void canny_hyst_kernel(uint8_t *__restrict__ map, int rows, int cols,
+                                                                int *__restrict__ changed)
+{
+    __shared__ uint8_t t[HY_TH + 2][HY_TW + 2 + 2];  // +2: keep rows 4-byte friendly
+    const int x0 = blockIdx.x * HY_TW, y0 = blockIdx.y * HY_TH;
+    map += (int64_t)blockIdx.z * rows * cols;
+    for (int i = threadIdx.x; i < (HY_TH + 2) * (HY_TW + 2); i += HY_THREADS) {
+        const int ty = i / (HY_TW + 2), tx = i - ty * (HY_TW + 2);
+        const int y = y0 + ty - 1, x = x0 + tx - 1;
+        t[ty][tx] = (y >= 0 && y < rows && x >= 0 && x < cols) ? map[(int64_t)y * cols + x] : 1;
+    }
+    __syncthreads();
+    bool any = false;
+    for (;;) {
+        bool ch = false;
+        for (int i = threadIdx.x; i < HY_TH * HY_TW; i += HY_THREADS) {
+            const int py = i / HY_TW + 1, px = i % HY_TW + 1;
+            if (t[py][px] == 0) {
+                const bool near = t[py - 1][px - 1] == 2 || t[py - 1][px] == 2 || t[py - 1][px + 1] == 2 ||
+                                  t[py][px - 1] == 2 || t[py][px + 1] == 2 || t[py + 1][px - 1] == 2 ||
+                                  t[py + 1][px] == 2 || t[py + 1][px + 1] == 2;
+                if (near) {
+                    t[py][px] = 2;  // monotone 0 -> 2: a neighbour reading the old value just waits a round
+                    ch = true;
+                }
+            }
+        }
+        if (!__syncthreads_or(ch)) break;
+        any = true;
+    }
+    if (!any) return;
+    for (int i = threadIdx.x; i < HY_TH * HY_TW; i += HY_THREADS) {
+        const int py = i / HY_TW, px = i % HY_TW;
+        const int y = y0 + py, x = x0 + px;
+        if (y < rows && x < cols) map[(int64_t)y * cols + x] = t[py + 1][px + 1];
+    }
+    if (threadIdx.x == 0) atomicOr(changed, 1);
+}
+
+hipError_t launch_canny_hysteresis(uint8_t *d_map, int rows, int cols, int n, int *d_changed, hipStream_t s)
+{
+    const dim3 grid((cols + HY_TW - 1) / HY_TW, (rows + HY_TH - 1) / HY_TH, n);
+    hipLaunchKernelGGL(canny_hyst_kernel, grid, dim3(HY_THREADS), 0, s, d_map, rows, cols, d_changed);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// raster-order point list (hough.cpp stage 1)
+__device__ __forceinline__ int block_sum_256(int v, int *sh)
+{
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+__global__ __launch_bounds__(256) void edges_rowcount_kernel(uint8_t *__restrict__ img, int rows, int cols,
+                                                             int from_map, int32_t *__restrict__ rowcnt)
+{
+    __shared__ int sh[4];
+    const int y = blockIdx.x, scan = blockIdx.y;
+    uint8_t *p = img + ((int64_t)scan * rows + y) * cols;
+    int c = 0;
+    for (int x = threadIdx.x; x < cols; x += 256) {
+        uint8_t v = p[x];
+        if (from_map) {
+            v = v == 2 ? 255 : 0;
+            p[x] = v;
+        }
+        c += v != 0;
+    }
+    c = block_sum_256(c, sh);
+    if (threadIdx.x == 0) rowcnt[(int64_t)scan * rows + y] = c;
+}
+
+hipError_t launch_edges_rowcount(uint8_t *d_map, int rows, int cols, int n, int from_map, int32_t *d_rowcnt,
+                                 hipStream_t s)
+{
+    hipLaunchKernelGGL(edges_rowcount_kernel, dim3(rows, n), dim3(256), 0, s, d_map, rows, cols, from_map, d_rowcnt);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(1024) void edges_rowscan_kernel(const int32_t *__restrict__ rowcnt, int rows,
+                                                             int32_t *__restrict__ rowoff, int32_t *__restrict__ total)
+{
+    __shared__ int sh[1024];
+    const int scan = blockIdx.x, tid = threadIdx.x;
+    rowcnt += (int64_t)scan * rows;
+    rowoff += (int64_t)scan * rows;
+    const int per = (rows + 1023) / 1024;
+    const int r0 = min(tid * per, rows), r1 = min(r0 + per, rows);
+    int s = 0;
+    for (int r = r0; r < r1; r++) s += rowcnt[r];
+    sh[tid] = s;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {  // inclusive Hillis-Steele scan of the 1024 partials
+        const int v = tid >= off ? sh[tid - off] : 0;
+        __syncthreads();
+        sh[tid] += v;
+        __syncthreads();
+    }
+    int run = sh[tid] - s;  // exclusive
+    for (int r = r0; r < r1; r++) {
+        rowoff[r] = run;
+        run += rowcnt[r];
+    }
+    if (tid == 1023) total[scan] = sh[1023];
+}
+
+hipError_t launch_edges_rowscan(const int32_t *d_rowcnt, int rows, int n, int32_t *d_rowoff, int32_t *d_total,
+                                hipStream_t s)
+{
+    hipLaunchKernelGGL(edges_rowscan_kernel, dim3(n), dim3(1024), 0, s, d_rowcnt, rows, d_rowoff, d_total);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void edges_compact_kernel(const uint8_t *__restrict__ img, int rows, int cols,
+                                                            const int32_t *__restrict__ rowoff,
+                                                            const int64_t *__restrict__ scan_off,
+                                                            uint32_t *__restrict__ nz)
+{
+    __shared__ int sh[4];
+    const int y = blockIdx.x, scan = blockIdx.y;
+    const uint8_t *p = img + ((int64_t)scan * rows + y) * cols;
+    uint32_t *out = nz + scan_off[scan] + rowoff[(int64_t)scan * rows + y];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int base = 0;
+    for (int xb = 0; xb < cols; xb += 256) {
+        const int x = xb + threadIdx.x;
+        const bool f = x < cols && p[x] != 0;
+        const unsigned long long m = __ballot(f);
+        __syncthreads();
+        if (lane == 0) sh[wave] = __popcll(m);
+        __syncthreads();
+        int before = __popcll(m & ((1ull << lane) - 1ull));
+        for (int w = 0; w < wave; w++) before += sh[w];
+        if (f) out[base + before] = ((uint32_t)y << 16) | (uint32_t)x;
+        base += sh[0] + sh[1] + sh[2] + sh[3];
+    }
+}
+
+hipError_t launch_edges_compact(const uint8_t *d_edges, int rows, int cols, int n, const int32_t *d_rowoff,
+                                const int64_t *d_scan_off, uint32_t *d_nz, hipStream_t s)
+{
+    hipLaunchKernelGGL(edges_compact_kernel, dim3(rows, n), dim3(256), 0, s, d_edges, rows, cols, d_rowoff, d_scan_off,
+                       d_nz);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// HoughLinesProbabilistic, one workgroup per scan.
+//   thread 0     : RNG, swap-remove from the point list, skipping of points already erased
+//   lane = angle : the 180 accumulator increments of a drawn point and their arg-max; the
+//                  decrements ("un-votes") of an accepted segment's points (fire-and-forget atomics)
+//   lane = step  : the two walks along the chosen line, 192 positions per round; the sequential
+//                  gap rule is applied by thread 0 to the rounds' ballots
+// Row n of the accumulator is only ever touched by lane n, so its updates are ordered; mask bytes
+// are read and written with device-scope (L1-bypassing) accesses between barriers.
+struct PphtShared {
+    int i, j;                      // drawn point (i = row, j = column), i < 0: list exhausted
+    unsigned long long key[3];     // per-wave (value, angle) maxima
+    unsigned long long nzb[3];     // walk round: non-zero ballots
+    unsigned long long oob[3];     // walk round: out-of-image ballots
+    int stop, gap, end_t;          // walk state of the current direction
+    int end[2];                    // last non-zero step of both directions
+    int good;
+    int npts;                      // points to un-vote in this round
+    int pts[OMR_PPHT_THREADS];     // their (y << 16 | x)
+};
+
+// device-scope accesses: served by L2, so a wave sees what other waves stored before the last barrier
+__device__ __forceinline__ uint8_t mask_load(const uint8_t *p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void mask_clear(uint8_t *p)
+{
+    __hip_atomic_store(p, (uint8_t)0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__global__ __launch_bounds__(OMR_PPHT_THREADS) void ppht_kernel(const PphtArgs a)
+{
+    __shared__ PphtShared sh;
+    const int scan = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int W = a.width, H = a.height;
+    uint8_t *mask = a.mask + (int64_t)scan * W * H;
+    uint32_t *nz = a.nz + a.scan_off[scan];
+    int32_t *accum = a.accum + (int64_t)scan * a.numangle * a.numrho;
+    int32_t *lines = a.lines + (int64_t)scan * a.cap * 4;
+    const bool voter = tid < a.numangle;
+    float tc = 0.f, ts = 0.f;
+    if (voter) {
+        tc = a.ttab[2 * tid];
+        ts = a.ttab[2 * tid + 1];
+    }
+    int32_t *row = accum + (int64_t)(voter ? tid : 0) * a.numrho + (a.numrho - 1) / 2;
+    // thread 0 state
+    unsigned long long rng = ~0ull;  // cv::RNG((uint64)-1)
+    int count = a.count[scan];
+    int nl = 0;
+
+    for (;;) {
+        if (tid == 0) {
+            int pi = -1, pj = -1;
+            while (count > 0) {
+                rng = (unsigned long long)(uint32_t)rng * 4164903690u + (uint32_t)(rng >> 32);
+                const int idx = (int)((uint32_t)rng % (uint32_t)count);
+                const uint32_t p = nz[idx];
+                nz[idx] = nz[count - 1];
+                count--;
+                const int j = (int)(p & 0xffffu), i = (int)(p >> 16);
+                if (mask_load(mask + (int64_t)i * W + j)) {
+                    pi = i;
+                    pj = j;
+                    break;
+                }
+            }
+            sh.i = pi;
+            sh.j = pj;
+        }
+        __syncthreads();
+        const int pi = sh.i, pj = sh.j;
+        if (pi < 0) break;
+        // ---- vote: r = cvRound(j * cos/rho + i * sin/rho) in float32, no contraction
+        long long key = (long long)0x8000000000000000ull;
+        if (voter) {
+            const float fr = __fadd_rn(__fmul_rn((float)pj, tc), __fmul_rn((float)pi, ts));
+            const int r = __float2int_rn(fr);
+            const int val = atomicAdd(row + r, 1) + 1;
+            // larger value first, then the LOWER angle ("if (max_val < val)" keeps the first maximum)
+            key = ((long long)val << 32) | (long long)(uint32_t)(0x7fffffff - tid);
+        }
+        for (int off = 32; off > 0; off >>= 1) {
+            const long long o = __shfl_down(key, off);
+            key = o > key ? o : key;
+        }
+        if (lane == 0) sh.key[wave] = (unsigned long long)key;
+        __syncthreads();
+        long long best = (long long)sh.key[0];
+        if ((long long)sh.key[1] > best) best = (long long)sh.key[1];
+        if ((long long)sh.key[2] > best) best = (long long)sh.key[2];
+        const int max_val = (int)(best >> 32);
+        const int max_n = 0x7fffffff - (int)(uint32_t)(best & 0xffffffffll);
+        if (max_val < a.threshold) {  // with threshold 0 only when un-votes drove the bins negative
+            __syncthreads();
+            continue;
+        }
+        const PphtWalk wk = a.walk[max_n];
+        int x0 = pj, y0 = pi;
+        if (wk.xflag) y0 = (y0 << 16) + (1 << 15);
+        else x0 = (x0 << 16) + (1 << 15);
+
+        // ---- first pass: the segment's two ends
+        for (int k = 0; k < 2; k++) {
+            const int dx = k ? -wk.dx0 : wk.dx0, dy = k ? -wk.dy0 : wk.dy0;
+            if (tid == 0) {
+                sh.stop = 0;
+                sh.gap = 0;
+                sh.end_t = 0;  // step 0 is the drawn point itself: non-zero
+            }
+            for (int base = 0;; base += OMR_PPHT_THREADS) {
+                const int t = base + tid;
+                const int x = x0 + t * dx, y = y0 + t * dy;
+                const int j1 = wk.xflag ? x : x >> 16, i1 = wk.xflag ? y >> 16 : y;
+                const bool out = j1 < 0 || j1 >= W || i1 < 0 || i1 >= H;
+                const bool on = !out && mask_load(mask + (int64_t)i1 * W + j1) != 0;
+                const unsigned long long bn = __ballot(on), bo = __ballot(out);
+                if (lane == 0) {
+                    sh.nzb[wave] = bn;
+                    sh.oob[wave] = bo;
+                }
+                __syncthreads();
+                if (tid == 0) {
+                    int gap = sh.gap, end_t = sh.end_t, stop = 0;
+                    for (int w = 0; w < 3 && !stop; w++) {
+                        unsigned long long n = sh.nzb[w];
+                        const unsigned long long o = sh.oob[w];
+                        const int valid = o ? __ffsll((long long)o) - 1 : 64;  // steps before the border
+                        if (valid < 64) n &= (1ull << valid) - 1ull;
+                        int prev = -1;
+                        while (n) {
+                            const int q = __ffsll((long long)n) - 1;
+                            n &= n - 1;
+                            if (gap + (q - prev - 1) > a.line_gap) {
+                                stop = 1;
+                                break;
+                            }
+                            gap = 0;
+                            end_t = base + w * 64 + q;
+                            prev = q;
+                        }
+                        if (!stop) {
+                            gap += valid - prev - 1;
+                            if (gap > a.line_gap || valid < 64) stop = 1;
+                        }
+                    }
+                    sh.gap = gap;
+                    sh.end_t = end_t;
+                    sh.stop = stop;
+                }
+                __syncthreads();
+                if (sh.stop) break;
+            }
+            if (tid == 0) sh.end[k] = sh.end_t;
+            __syncthreads();
+        }
+        // line ends and the length test
+        int ex[2], ey[2];
+        for (int k = 0; k < 2; k++) {
+            const int t = sh.end[k];
+            const int dx = k ? -wk.dx0 : wk.dx0, dy = k ? -wk.dy0 : wk.dy0;
+            const int x = x0 + t * dx, y = y0 + t * dy;
+            ex[k] = wk.xflag ? x : x >> 16;
+            ey[k] = wk.xflag ? y >> 16 : y;
+        }
+        const bool good = abs(ex[1] - ex[0]) >= a.line_length || abs(ey[1] - ey[0]) >= a.line_length;
+
+        // ---- second pass: erase the segment's points; un-vote them when the segment is accepted
+        for (int k = 0; k < 2; k++) {
+            const int dx = k ? -wk.dx0 : wk.dx0, dy = k ? -wk.dy0 : wk.dy0;
+            const int last = sh.end[k];
+            for (int base = k; base <= last; base += OMR_PPHT_THREADS) {  // k = 1 skips step 0 (erased by k = 0)
+                const int t = base + tid;
+                bool on = false;
+                uint32_t pt = 0;
+                if (t <= last) {
+                    const int x = x0 + t * dx, y = y0 + t * dy;
+                    const int j1 = wk.xflag ? x : x >> 16, i1 = wk.xflag ? y >> 16 : y;
+                    uint8_t *m = mask + (int64_t)i1 * W + j1;
+                    if (mask_load(m)) {
+                        on = true;
+                        pt = ((uint32_t)i1 << 16) | (uint32_t)j1;
+                        mask_clear(m);
+                    }
+                }
+                if (good) {  // block-uniform
+                    const unsigned long long bn = __ballot(on);
+                    if (lane == 0) sh.nzb[wave] = bn;
+                    __syncthreads();
+                    int before = __popcll(bn & ((1ull << lane) - 1ull));
+                    for (int w = 0; w < wave; w++) before += __popcll(sh.nzb[w]);
+                    if (on) sh.pts[before] = (int)pt;
+                    const int np = __popcll(sh.nzb[0]) + __popcll(sh.nzb[1]) + __popcll(sh.nzb[2]);
+                    __syncthreads();
+                    if (voter) {
+                        for (int q = 0; q < np; q++) {
+                            const uint32_t p = (uint32_t)sh.pts[q];
+                            const float fr = __fadd_rn(__fmul_rn((float)(p & 0xffffu), tc), __fmul_rn((float)(p >> 16), ts));
+                            atomicAdd(row + __float2int_rn(fr), -1);  // no return value: fire and forget
+                        }
+                    }
+                    __syncthreads();
+                }
+            }
+        }
+        if (tid == 0 && good) {
+            if (nl < a.cap) {
+                lines[4 * nl] = ex[0];
+                lines[4 * nl + 1] = ey[0];
+                lines[4 * nl + 2] = ex[1];
+                lines[4 * nl + 3] = ey[1];
+            }
+            nl++;
+        }
+        __syncthreads();  // erasures are complete before thread 0 tests the next points
+    }
+    if (tid == 0) a.n_lines[scan] = nl;
+}
+
+hipError_t launch_ppht(const PphtArgs &a, int n, hipStream_t s)
+{
+    if (n <= 0) return hipSuccess;
+    if (a.numangle > OMR_PPHT_THREADS) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(ppht_kernel, dim3(n), dim3(OMR_PPHT_THREADS), 0, s, a);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void angle_votes_kernel(const float *__restrict__ ang, int n, int as_f64,
+                                                          int32_t *__restrict__ counts)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float ai = ang[i];
+    int c = 0;
+    if (as_f64) {
+        const double di = (double)ai;
+        for (int j = 0; j < n; j++) c += fabs(di - (double)ang[j]) < 0.1;
+    } else {
+        for (int j = 0; j < n; j++) c += fabsf(__fsub_rn(ai, ang[j])) < 0.1f;
+    }
+    counts[i] = c;
+}
+
+hipError_t launch_angle_votes(const float *d_angles, int n, int as_f64, int32_t *d_counts, hipStream_t s)
+{
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(angle_votes_kernel, dim3((n + 255) / 256), dim3(256), 0, s, d_angles, n, as_f64, d_counts);
+    return hipGetLastError();
+}
+
+}  // namespace omr

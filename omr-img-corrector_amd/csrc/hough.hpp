@@ -1,0 +1,53 @@
+// hough.hpp -- device kernels of the Hough-line deskew path:
+// Canny(50, 150, 3) -> HoughLinesP(rho 1, theta pi/180, threshold, minLineLength, maxLineGap) as
+// OpenCV 4.6.0 defines them (call sites packages/lib/src/hough.rs:27-43, omr.rs:236-253).
+// All kernels take a batch: blockIdx.z (or .x for the per-scan kernels) = scan.
+#pragma once
+#include <hip/hip_runtime_api.h>
+#include <stdint.h>
+
+namespace omr {
+
+// map values of the Canny stages (canny.cpp): 0 = may become an edge, 1 = no edge, 2 = edge
+// Non-maximum suppression of the L1 Sobel gradient; cn = 1, 3 or 4 (per pixel the channel with the
+// largest |dx| + |dy|).  src: n scans, scan_stride bytes apart.  map: n x rows x cols, packed.
+hipError_t launch_canny_nms(const uint8_t *d_src, int64_t scan_stride, int64_t row_step, int rows, int cols, int cn,
+                            int n, int low, int high, uint8_t *d_map, hipStream_t s);
+// One hysteresis pass (tile-local fixed point); *d_changed |= 1 when any tile changed.
+hipError_t launch_canny_hysteresis(uint8_t *d_map, int rows, int cols, int n, int *d_changed, hipStream_t s);
+// map -> edges (0 / 255, in place) and the number of edge pixels of every row.
+hipError_t launch_edges_rowcount(uint8_t *d_map, int rows, int cols, int n, int from_map, int32_t *d_rowcnt,
+                                 hipStream_t s);
+// exclusive scan of the row counts of every scan; d_total[scan] = number of edge pixels
+hipError_t launch_edges_rowscan(const int32_t *d_rowcnt, int rows, int n, int32_t *d_rowoff, int32_t *d_total,
+                                hipStream_t s);
+// raster-order list of the non-zero pixels: nz[scan_off[scan] + k] = y << 16 | x
+hipError_t launch_edges_compact(const uint8_t *d_edges, int rows, int cols, int n, const int32_t *d_rowoff,
+                                const int64_t *d_scan_off, uint32_t *d_nz, hipStream_t s);
+
+struct PphtWalk {  // per accumulator angle: the line walk of hough.cpp (16.16 fixed point)
+    int32_t xflag, dx0, dy0, pad;
+};
+struct PphtArgs {
+    uint8_t *mask;            // n x height x width, non-zero = point still available (destroyed)
+    int32_t width, height;
+    uint32_t *nz;             // point lists (destroyed)
+    const int64_t *scan_off;  // [n] offset of a scan's list in nz
+    const int32_t *count;     // [n] points per scan
+    int32_t *accum;           // n x numangle x numrho, zeroed
+    int32_t numangle, numrho;
+    const float *ttab;        // numangle x (cos / rho, sin / rho) as float
+    const PphtWalk *walk;     // numangle
+    int32_t threshold, line_length, line_gap;
+    int32_t *lines;           // n x cap x 4
+    int32_t cap;
+    int32_t *n_lines;         // [n]
+};
+#define OMR_PPHT_THREADS 192  // lane = accumulator angle; numangle <= 192
+hipError_t launch_ppht(const PphtArgs &a, int n, hipStream_t s);
+
+// counts[i] = #{ j : |a[i] - a[j]| < 0.1 } in f32 (hough.rs:77-83) or in f64 on widened values
+// (omr.rs:278-284)
+hipError_t launch_angle_votes(const float *d_angles, int n, int as_f64, int32_t *d_counts, hipStream_t s);
+
+}  // namespace omr

@@ -3,7 +3,7 @@ import ctypes as C
 
 import numpy as np
 
-from ._lib import check, f64p, lib
+from ._lib import OmrImageOwned, check, f64p, i32p, lib
 from .transfer import _mat, as_image
 from .types import ResultStatus
 
@@ -49,3 +49,51 @@ def select_projection_result(v_sd, h_sd, N, step):
                                              C.byref(angle), C.byref(status), cand.ctypes.data_as(f64p), cand.size,
                                              C.byref(clen)))
     return OmrResult(angle.value, ResultStatus(status.value), cand[: clen.value].copy())
+
+
+def get_result_from_edges_detection(src_mat, edges_min_line_length, edges_max_line_gap):
+    """omr.rs:231-302"""
+    a, im = as_image(_mat(src_mat))
+    cap = 1 << 16
+    cand = np.zeros(cap, np.float64)
+    angle, status, clen = C.c_double(), C.c_int32(), C.c_int32()
+    check(lib().omr_get_result_from_edges_detection(C.byref(im), float(edges_min_line_length), float(edges_max_line_gap),
+                                                    C.byref(angle), C.byref(status), cand.ctypes.data_as(f64p), cap,
+                                                    C.byref(clen)))
+    return OmrResult(angle.value, ResultStatus(status.value), cand[: min(clen.value, cap)].copy())
+
+
+def edges_detection_batch_device(d_scans_ptr, n, scan_stride, rows, cols, channels, step, min_line_length, max_line_gap,
+                                 stream=None):
+    """get_result_from_edges_detection on n device-resident scans -> (angles, status, n_lines)"""
+    angles = np.zeros(n, np.float64)
+    status = np.zeros(n, np.int32)
+    nl = np.zeros(n, np.int32)
+    check(lib().omr_edges_detection_batch_device(d_scans_ptr, n, scan_stride, rows, cols, channels, step,
+                                                 float(min_line_length), float(max_line_gap), angles.ctypes.data_as(f64p),
+                                                 status.ctypes.data_as(i32p), nl.ctypes.data_as(i32p), stream))
+    return angles, status, nl
+
+
+def correct_default_decision(projection_result, edges_angle):
+    """omr.rs:351-399 -> (rotate_angle, need_check)"""
+    c = np.ascontiguousarray(projection_result.candidates, np.float64)
+    ang, chk = C.c_double(), C.c_int32()
+    lib().omr_correct_default_decision(float(projection_result.angle), int(projection_result.status),
+                                       c.ctypes.data_as(f64p), c.size, float(edges_angle), C.byref(ang), C.byref(chk))
+    return ang.value, bool(chk.value)
+
+
+def correct_default(src_mat, projection_max_angle, projection_angle_step, projection_max_width, projection_max_height,
+                    hough_min_line_length, hough_max_line_gap, want_image=True):
+    """omr.rs:339-448 on a decoded BGR image (imread / imwrite are the caller's) ->
+    (rotate_angle, need_check, rotated image or None)"""
+    from .hough import _take
+    a, im = as_image(_mat(src_mat))
+    ang, chk = C.c_double(), C.c_int32()
+    owned = OmrImageOwned()
+    check(lib().omr_correct_default(C.byref(im), int(projection_max_angle), float(projection_angle_step),
+                                    int(projection_max_width), int(projection_max_height), float(hough_min_line_length),
+                                    float(hough_max_line_gap), C.byref(ang), C.byref(chk),
+                                    C.byref(owned) if want_image else None))
+    return ang.value, bool(chk.value), (_take(owned) if want_image else None)

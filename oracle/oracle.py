@@ -20,8 +20,7 @@ f64p = C.POINTER(C.c_double)
 
 def build(force=False):
     """Compile liboracle.so / liboracle_fast.so with gcc (building the checker is not using it)."""
-    if force or not all(os.path.exists(os.path.join(_HERE, n)) for n in ("liboracle.so", "liboracle_fast.so")):
-        subprocess.check_call(["make", "-s", "-C", _HERE] + (["-B"] if force else []))
+    subprocess.check_call(["make", "-s", "-C", _HERE] + (["-B"] if force else []))  # no-op when up to date
 
 
 def lib(fast=False):
@@ -85,6 +84,31 @@ def lib(fast=False):
                                                      C.c_int, C.c_int, f64p, C.POINTER(C.c_int), f64p, C.c_int,
                                                      C.POINTER(C.c_int)]
         L.orc_get_result_from_projection.restype = C.c_int
+        # ---- Hough-line path (oracle_hough.c)
+        i16p = C.POINTER(C.c_int16)
+        ip = C.POINTER(C.c_int)
+        L.orc_sobel3_16s.argtypes = [u8p, C.c_int, C.c_int, C.c_int, C.c_int64, i16p, i16p]
+        L.orc_sobel3_16s.restype = None
+        L.orc_canny.argtypes = [u8p, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_double, C.c_double, u8p, C.c_int64]
+        L.orc_canny.restype = C.c_int
+        L.orc_hough_trigtab.argtypes = [C.c_double, C.c_double, ip, C.POINTER(C.c_float)]
+        L.orc_hough_trigtab.restype = None
+        L.orc_hough_lines_p.argtypes = [u8p, C.c_int, C.c_int, C.c_int64, C.c_double, C.c_double, C.c_int, C.c_double,
+                                        C.c_double, i32p, C.c_int, ip]
+        L.orc_hough_lines_p.restype = C.c_int
+        L.orc_line_angle_f32.argtypes = [i32p]
+        L.orc_line_angle_f32.restype = C.c_float
+        L.orc_vote_hough_rs.argtypes = [C.POINTER(C.c_float), C.c_int, f64p]
+        L.orc_vote_hough_rs.restype = C.c_int
+        L.orc_vote_omr_rs.argtypes = [C.POINTER(C.c_float), C.c_int, f64p, ip, f64p, C.c_int, ip]
+        L.orc_vote_omr_rs.restype = C.c_int
+        L.orc_get_angle_with_hough.argtypes = [u8p, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_double, C.c_double, f64p, ip]
+        L.orc_get_angle_with_hough.restype = C.c_int
+        L.orc_get_result_from_edges_detection.argtypes = [u8p, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_double,
+                                                          C.c_double, f64p, ip, f64p, C.c_int, ip, ip]
+        L.orc_get_result_from_edges_detection.restype = C.c_int
+        L.orc_correct_default_decision.argtypes = [C.c_double, C.c_int, f64p, C.c_int, C.c_double, f64p, ip]
+        L.orc_correct_default_decision.restype = None
         _LIBS[name] = L
     return _LIBS[name]
 
@@ -293,3 +317,88 @@ def get_result_from_projection(img, max_angle, step, max_w, max_h):
     _check(lib().orc_get_result_from_projection(_u8(a), r, c, cn, st, max_angle, step, max_w, max_h, C.byref(ang),
                                                 C.byref(status), _f64(cand), cand.size, C.byref(n)))
     return ang.value, status.value, cand[: n.value].copy()
+
+
+# ---- Hough-line path (oracle_hough.c) -----------------------------------
+def sobel3_16s(img):
+    a, rows, cols, cn, step = _img(img)
+    dx = np.zeros((rows, cols, cn), np.int16)
+    dy = np.zeros((rows, cols, cn), np.int16)
+    i16p = C.POINTER(C.c_int16)
+    lib().orc_sobel3_16s(_u8(a), rows, cols, cn, step, dx.ctypes.data_as(i16p), dy.ctypes.data_as(i16p))
+    return dx, dy
+
+
+def canny(img, low=50.0, high=150.0, fast=False):
+    a, rows, cols, cn, step = _img(img)
+    out = np.zeros((rows, cols), np.uint8)
+    _check(lib(fast).orc_canny(_u8(a), rows, cols, cn, step, low, high, _u8(out), out.strides[0]))
+    return out
+
+
+def hough_trigtab(theta=np.pi / 180.0, rho=1.0):
+    n = C.c_int(0)
+    lib().orc_hough_trigtab(theta, rho, C.byref(n), None)
+    t = np.zeros(2 * n.value, np.float32)
+    lib().orc_hough_trigtab(theta, rho, C.byref(n), t.ctypes.data_as(C.POINTER(C.c_float)))
+    return n.value, t
+
+
+def hough_lines_p(edges, min_line_length, max_line_gap, rho=1.0, theta=np.pi / 180.0, threshold=0, fast=False):
+    a, rows, cols, cn, step = _img(edges)
+    assert cn == 1
+    n = C.c_int(0)
+    L = lib(fast)
+    _check(L.orc_hough_lines_p(_u8(a), rows, cols, step, rho, theta, threshold, min_line_length, max_line_gap, None, 0,
+                               C.byref(n)))
+    lines = np.zeros((max(n.value, 1), 4), np.int32)
+    _check(L.orc_hough_lines_p(_u8(a), rows, cols, step, rho, theta, threshold, min_line_length, max_line_gap,
+                               lines.ctypes.data_as(i32p), n.value, C.byref(n)))
+    return lines[: n.value]
+
+
+def line_angles_f32(lines):
+    lines = np.ascontiguousarray(lines, np.int32)
+    return np.array([lib().orc_line_angle_f32(lines[i].ctypes.data_as(i32p)) for i in range(len(lines))], np.float32)
+
+
+def vote_hough_rs(angles):
+    angles = np.ascontiguousarray(angles, np.float32)
+    out = C.c_double(0)
+    _check(lib().orc_vote_hough_rs(angles.ctypes.data_as(C.POINTER(C.c_float)), len(angles), C.byref(out)))
+    return out.value
+
+
+def vote_omr_rs(angles):
+    angles = np.ascontiguousarray(angles, np.float32)
+    out, st, nc = C.c_double(0), C.c_int(0), C.c_int(0)
+    cand = np.zeros(max(len(angles), 1), np.float64)
+    _check(lib().orc_vote_omr_rs(angles.ctypes.data_as(C.POINTER(C.c_float)), len(angles), C.byref(out), C.byref(st),
+                                 _f64(cand), len(cand), C.byref(nc)))
+    return out.value, st.value, cand[: nc.value]
+
+
+def get_angle_with_hough(gray, min_line_length, max_line_gap, fast=False):
+    a, rows, cols, cn, step = _img(gray)
+    out, n = C.c_double(0), C.c_int(0)
+    _check(lib(fast).orc_get_angle_with_hough(_u8(a), rows, cols, cn, step, min_line_length, max_line_gap, C.byref(out),
+                                              C.byref(n)))
+    return out.value, n.value
+
+
+def get_result_from_edges_detection(src, min_line_length, max_line_gap, fast=False):
+    a, rows, cols, cn, step = _img(src)
+    out, st, nc, nl = C.c_double(0), C.c_int(0), C.c_int(0), C.c_int(0)
+    cap = 1 << 16
+    cand = np.zeros(cap, np.float64)
+    _check(lib(fast).orc_get_result_from_edges_detection(_u8(a), rows, cols, cn, step, min_line_length, max_line_gap,
+                                                         C.byref(out), C.byref(st), _f64(cand), cap, C.byref(nc),
+                                                         C.byref(nl)))
+    return out.value, st.value, cand[: min(nc.value, cap)], nl.value
+
+
+def correct_default_decision(proj_angle, proj_status, proj_candidates, edges_angle):
+    c = np.ascontiguousarray(proj_candidates, np.float64)
+    ang, chk = C.c_double(0), C.c_int(0)
+    lib().orc_correct_default_decision(proj_angle, proj_status, _f64(c), len(c), edges_angle, C.byref(ang), C.byref(chk))
+    return ang.value, bool(chk.value)
