@@ -126,3 +126,24 @@ def test_correct_default_decision_rule(oracle):
     for pa, st, cand, ea in cases:
         r = omr.OmrResult(pa, ResultStatus(st), np.array(cand, np.float64))
         assert omr.correct_default_decision(r, ea) == oracle.correct_default_decision(pa, st, cand, ea)
+
+
+def test_golden_vectors(golden_dir):
+    import glob
+    import os
+    files = sorted(glob.glob(os.path.join(golden_dir, "hough_*.npz")))
+    assert len(files) >= 5
+    for f in files:
+        d = np.load(f)
+        img = d["img"]
+        edges = hough.canny(img)
+        assert (np.packbits(edges != 0, axis=1, bitorder="little") == d["edges_bits"]).all(), f
+        mll, mlg = float(d["min_line_length"]), float(d["max_line_gap"])
+        lines = hough.hough_lines_p(edges, 1.0, np.pi / 180.0, 0, mll, mlg)
+        assert lines.shape == d["lines"].shape and (lines == d["lines"]).all(), f
+        if len(lines):
+            a1 = hough.get_angle_with_hough(img, mll, mlg)
+            assert np.float64(a1).view(np.uint64) == d["hough_rs_angle_bits"], f
+            r = omr.get_result_from_edges_detection(img, mll, mlg)
+            assert np.float64(r.angle).view(np.uint64) == d["omr_rs_angle_bits"] and int(r.status) == int(d["omr_rs_status"])
+            assert (r.candidates.view(np.uint64) == d["omr_rs_candidate_bits"]).all(), f
