@@ -262,7 +262,7 @@ int omr_canny(const omr_image *src, double low_thresh, double high_thresh, omr_i
 /* imgproc::hough_lines_p(&edges, &mut lines, rho, theta, threshold, min_line_length, max_line_gap):
  * hough.rs:31-43, omr.rs:245-253 (rho 1, theta pi/180, threshold 0).  lines: cap x (x0, y0, x1, y1);
  * *n_lines = segments found (call again with a larger buffer if it exceeds cap).  theta must give
- * at most 192 accumulator angles (-213 otherwise). */
+ * at most 256 accumulator angles (-213 otherwise). */
 int omr_hough_lines_p(const omr_image *edges_u8c1, double rho, double theta, int32_t threshold,
                       double min_line_length, double max_line_gap, int32_t *lines, int32_t cap,
                       int32_t *n_lines);

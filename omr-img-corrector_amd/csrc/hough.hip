@@ -165,7 +165,12 @@ hipError_t launch_canny_hysteresis(uint8_t *d_map, int rows, int cols, int n, in
 }
 
 // ------------------------------------------------------------------------------------------
-// raster-order point list (hough.cpp stage 1)
+// raster-order point list (hough.cpp stage 1) and the tiled mask
+__host__ __device__ __forceinline__ int64_t mask_offset(int y, int x, int tiles_x)
+{
+    return ((int64_t)(y >> 3) * tiles_x + (x >> 3)) * 64 + (y & 7) * 8 + (x & 7);
+}
+
 __device__ __forceinline__ int block_sum_256(int v, int *sh)
 {
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
@@ -238,7 +243,7 @@ hipError_t launch_edges_rowscan(const int32_t *d_rowcnt, int rows, int n, int32_
 __global__ __launch_bounds__(256) void edges_compact_kernel(const uint8_t *__restrict__ img, int rows, int cols,
                                                             const int32_t *__restrict__ rowoff,
                                                             const int64_t *__restrict__ scan_off,
-                                                            uint32_t *__restrict__ nz)
+                                                            uint32_t *__restrict__ nz, uint8_t *__restrict__ tiled)
 {
     __shared__ int sh[4];
     const int y = blockIdx.x, scan = blockIdx.y;
@@ -249,6 +254,7 @@ __global__ __launch_bounds__(256) void edges_compact_kernel(const uint8_t *__res
     for (int xb = 0; xb < cols; xb += 256) {
         const int x = xb + threadIdx.x;
         const bool f = x < cols && p[x] != 0;
+        if (x < cols) tiled[ppht_mask_bytes(rows, cols) * scan + mask_offset(y, x, ppht_tiles_x(cols))] = f ? 1 : 0;
         const unsigned long long m = __ballot(f);
         __syncthreads();
         if (lane == 0) sh[wave] = __popcll(m);
@@ -261,32 +267,37 @@ __global__ __launch_bounds__(256) void edges_compact_kernel(const uint8_t *__res
 }
 
 hipError_t launch_edges_compact(const uint8_t *d_edges, int rows, int cols, int n, const int32_t *d_rowoff,
-                                const int64_t *d_scan_off, uint32_t *d_nz, hipStream_t s)
+                                const int64_t *d_scan_off, uint32_t *d_nz, uint8_t *d_mask_tiled, hipStream_t s)
 {
     hipLaunchKernelGGL(edges_compact_kernel, dim3(rows, n), dim3(256), 0, s, d_edges, rows, cols, d_rowoff, d_scan_off,
-                       d_nz);
+                       d_nz, d_mask_tiled);
     return hipGetLastError();
 }
 
 // ------------------------------------------------------------------------------------------
-// HoughLinesProbabilistic, one workgroup per scan.
-//   thread 0     : RNG, swap-remove from the point list, skipping of points already erased
-//   lane = angle : the 180 accumulator increments of a drawn point and their arg-max; the
+// HoughLinesProbabilistic, one workgroup (4 waves) per scan.
+//   wave 0       : the draw stage.  The draw order does not depend on the image (RNG + swap-remove
+//                  on the point list), so 64 draws are made per round: lane 0 steps the RNG 64 times,
+//                  every lane takes one draw (index, the point, the element swapped in), the swaps
+//                  are committed together when no two draws of the round touch the same list slot
+//                  (else lane 0 replays the round one by one), and the 64 mask tests are one memory
+//                  round trip.  Points still set are then served lowest lane first; after every
+//                  walk the remaining ones are re-tested (the walk may have erased them).
+//   lane = angle : the 180 accumulator increments of a served point and their arg-max; the
 //                  decrements ("un-votes") of an accepted segment's points (fire-and-forget atomics)
-//   lane = step  : the two walks along the chosen line, 192 positions per round; the sequential
-//                  gap rule is applied by thread 0 to the rounds' ballots
+//   lane = step  : the two walks along the chosen line run side by side (threads 0-127 one way,
+//                  128-255 the other, 128 positions per round); the sequential gap rule is applied
+//                  to the rounds' ballots by threads 0 and 128
 // Row n of the accumulator is only ever touched by lane n, so its updates are ordered; mask bytes
-// are read and written with device-scope (L1-bypassing) accesses between barriers.
+// and list slots are read and written with device-scope (L2) accesses between barriers.
 struct PphtShared {
-    int i, j;                      // drawn point (i = row, j = column), i < 0: list exhausted
-    unsigned long long key[3];     // per-wave (value, angle) maxima
-    unsigned long long nzb[3];     // walk round: non-zero ballots
-    unsigned long long oob[3];     // walk round: out-of-image ballots
-    int stop, gap, end_t;          // walk state of the current direction
-    int end[2];                    // last non-zero step of both directions
-    int good;
-    int npts;                      // points to un-vote in this round
-    int pts[OMR_PPHT_THREADS];     // their (y << 16 | x)
+    int i, j;                      // served point (i = row, j = column), i < 0: list exhausted
+    unsigned long long key[4];     // per-wave (value, angle) maxima
+    unsigned long long nzb[4];     // walk round: non-zero ballots
+    unsigned long long oob[4];     // walk round: out-of-image ballots
+    int stop[2], gap[2], end_t[2]; // walk state of both directions
+    uint32_t r[64];                // draw round: raw RNG outputs (replay: the drawn points)
+    int pts[OMR_PPHT_THREADS];     // points to un-vote in this round (y << 16 | x)
 };
 
 // device-scope accesses: served by L2, so a wave sees what other waves stored before the last barrier
@@ -298,13 +309,22 @@ __device__ __forceinline__ void mask_clear(uint8_t *p)
 {
     __hip_atomic_store(p, (uint8_t)0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+__device__ __forceinline__ uint32_t list_load(const uint32_t *p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void list_store(uint32_t *p, uint32_t v)
+{
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 
 __global__ __launch_bounds__(OMR_PPHT_THREADS) void ppht_kernel(const PphtArgs a)
 {
     __shared__ PphtShared sh;
     const int scan = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int W = a.width, H = a.height;
-    uint8_t *mask = a.mask + (int64_t)scan * W * H;
+    uint8_t *mask = a.mask + (int64_t)scan * ppht_mask_bytes(H, W);
+    const int TX = ppht_tiles_x(W);
     uint32_t *nz = a.nz + a.scan_off[scan];
     int32_t *accum = a.accum + (int64_t)scan * a.numangle * a.numrho;
     int32_t *lines = a.lines + (int64_t)scan * a.cap * 4;
@@ -315,29 +335,76 @@ __global__ __launch_bounds__(OMR_PPHT_THREADS) void ppht_kernel(const PphtArgs a
         ts = a.ttab[2 * tid + 1];
     }
     int32_t *row = accum + (int64_t)(voter ? tid : 0) * a.numrho + (a.numrho - 1) / 2;
-    // thread 0 state
-    unsigned long long rng = ~0ull;  // cv::RNG((uint64)-1)
+    const int dir = tid >> 7, slot = tid & 127;  // walk role
+    // wave 0 state
+    unsigned long long rng = ~0ull;  // cv::RNG((uint64)-1), stepped by lane 0
     int count = a.count[scan];
+    uint32_t pt = 0;                 // this lane's drawn point of the current round
+    unsigned long long pend = 0;     // lanes whose point is still set and not served yet
     int nl = 0;
+    volatile uint32_t *shr = sh.r;
 
     for (;;) {
-        if (tid == 0) {
-            int pi = -1, pj = -1;
-            while (count > 0) {
-                rng = (unsigned long long)(uint32_t)rng * 4164903690u + (uint32_t)(rng >> 32);
-                const int idx = (int)((uint32_t)rng % (uint32_t)count);
-                const uint32_t p = nz[idx];
-                nz[idx] = nz[count - 1];
-                count--;
-                const int j = (int)(p & 0xffffu), i = (int)(p >> 16);
-                if (mask_load(mask + (int64_t)i * W + j)) {
-                    pi = i;
-                    pj = j;
-                    break;
+        if (wave == 0) {
+            while (pend == 0 && count > 0) {  // ---- a draw round
+                const int nd = min(64, count);
+                if (lane == 0) {
+                    for (int t = 0; t < nd; t++) {
+                        rng = (unsigned long long)(uint32_t)rng * 4164903690u + (uint32_t)(rng >> 32);
+                        shr[t] = (uint32_t)rng;
+                    }
                 }
+                __builtin_amdgcn_wave_barrier();  // same wave: LDS operations complete in order
+                const bool act = lane < nd;
+                const int c = count - lane;  // list length at this lane's draw
+                uint32_t idx = 0xffffffffu, p = 0, q = 0;
+                if (act) {
+                    idx = shr[lane] % (uint32_t)c;
+                    p = list_load(nz + idx);
+                    q = list_load(nz + (c - 1));
+                }
+                // draw s writes slot idx_s; a later draw t reads slots idx_t and c_t - 1
+                bool conf = false;
+                for (int s = 0; s + 1 < nd; s++) {
+                    const uint32_t is = (uint32_t)__builtin_amdgcn_readlane((int)idx, s);
+                    conf |= act && lane > s && (idx == is || (uint32_t)(c - 1) == is);
+                }
+                if (__ballot(conf)) {  // rare: replay the round in order
+                    if (lane == 0) {
+                        int cc = count;
+                        for (int t = 0; t < nd; t++) {
+                            const uint32_t ix = shr[t] % (uint32_t)cc;
+                            const uint32_t pp = list_load(nz + ix);
+                            list_store(nz + ix, list_load(nz + (cc - 1)));
+                            cc--;
+                            shr[t] = pp;
+                        }
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    p = act ? shr[lane] : 0;
+                } else if (act) {
+                    list_store(nz + idx, q);
+                }
+                count -= nd;
+                pt = p;
+                const bool on = act && mask_load(mask + mask_offset((int)(p >> 16), (int)(p & 0xffffu), TX)) != 0;
+                pend = __ballot(on);
             }
-            sh.i = pi;
-            sh.j = pj;
+            int pi = -1, pj = -1;
+            if (pend) {
+                const int t = __ffsll((long long)pend) - 1;
+                pend &= pend - 1;
+                const uint32_t p = (uint32_t)__builtin_amdgcn_readlane((int)pt, t);
+                pi = (int)(p >> 16);
+                pj = (int)(p & 0xffffu);
+            }
+            if (lane == 0) {
+                sh.i = pi;
+                sh.j = pj;
+                sh.stop[0] = sh.stop[1] = 0;
+                sh.gap[0] = sh.gap[1] = 0;
+                sh.end_t[0] = sh.end_t[1] = 0;  // step 0 is the served point itself: non-zero
+            }
         }
         __syncthreads();
         const int pi = sh.i, pj = sh.j;
@@ -346,8 +413,11 @@ __global__ __launch_bounds__(OMR_PPHT_THREADS) void ppht_kernel(const PphtArgs a
         long long key = (long long)0x8000000000000000ull;
         if (voter) {
             const float fr = __fadd_rn(__fmul_rn((float)pj, tc), __fmul_rn((float)pi, ts));
-            const int r = __float2int_rn(fr);
-            const int val = atomicAdd(row + r, 1) + 1;
+            // a plain load + store pair, not an RMW atomic: the row belongs to this lane alone, and L2
+            // keeps far more load misses in flight than atomic misses
+            int32_t *bin = row + __float2int_rn(fr);
+            const int val = __hip_atomic_load(bin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
+            __hip_atomic_store(bin, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             // larger value first, then the LOWER angle ("if (max_val < val)" keeps the first maximum)
             key = ((long long)val << 32) | (long long)(uint32_t)(0x7fffffff - tid);
         }
@@ -358,44 +428,41 @@ __global__ __launch_bounds__(OMR_PPHT_THREADS) void ppht_kernel(const PphtArgs a
         if (lane == 0) sh.key[wave] = (unsigned long long)key;
         __syncthreads();
         long long best = (long long)sh.key[0];
-        if ((long long)sh.key[1] > best) best = (long long)sh.key[1];
-        if ((long long)sh.key[2] > best) best = (long long)sh.key[2];
+        for (int w = 1; w < 4; w++)
+            if ((long long)sh.key[w] > best) best = (long long)sh.key[w];
         const int max_val = (int)(best >> 32);
         const int max_n = 0x7fffffff - (int)(uint32_t)(best & 0xffffffffll);
-        if (max_val < a.threshold) {  // with threshold 0 only when un-votes drove the bins negative
-            __syncthreads();
-            continue;
-        }
-        const PphtWalk wk = a.walk[max_n];
-        int x0 = pj, y0 = pi;
-        if (wk.xflag) y0 = (y0 << 16) + (1 << 15);
-        else x0 = (x0 << 16) + (1 << 15);
+        if (max_val >= a.threshold) {  // with threshold 0 false only when un-votes drove the bins negative
+            const PphtWalk wk = a.walk[max_n];
+            int x0 = pj, y0 = pi;
+            if (wk.xflag) y0 = (y0 << 16) + (1 << 15);
+            else x0 = (x0 << 16) + (1 << 15);
+            const int dx = dir ? -wk.dx0 : wk.dx0, dy = dir ? -wk.dy0 : wk.dy0;
 
-        // ---- first pass: the segment's two ends
-        for (int k = 0; k < 2; k++) {
-            const int dx = k ? -wk.dx0 : wk.dx0, dy = k ? -wk.dy0 : wk.dy0;
-            if (tid == 0) {
-                sh.stop = 0;
-                sh.gap = 0;
-                sh.end_t = 0;  // step 0 is the drawn point itself: non-zero
-            }
-            for (int base = 0;; base += OMR_PPHT_THREADS) {
-                const int t = base + tid;
-                const int x = x0 + t * dx, y = y0 + t * dy;
-                const int j1 = wk.xflag ? x : x >> 16, i1 = wk.xflag ? y >> 16 : y;
-                const bool out = j1 < 0 || j1 >= W || i1 < 0 || i1 >= H;
-                const bool on = !out && mask_load(mask + (int64_t)i1 * W + j1) != 0;
+            // ---- first pass: the segment's two ends, both directions side by side
+            bool on0 = false;  // this thread's position of round 0 holds a point
+            for (int base = 0;; base += 128) {
+                const bool live = !sh.stop[dir];
+                bool out = false, on = false;
+                if (live) {
+                    const int t = base + slot;
+                    const int x = x0 + t * dx, y = y0 + t * dy;
+                    const int j1 = wk.xflag ? x : x >> 16, i1 = wk.xflag ? y >> 16 : y;
+                    out = j1 < 0 || j1 >= W || i1 < 0 || i1 >= H;
+                    on = !out && mask_load(mask + mask_offset(i1, j1, TX)) != 0;
+                }
+                if (base == 0) on0 = on;
                 const unsigned long long bn = __ballot(on), bo = __ballot(out);
                 if (lane == 0) {
                     sh.nzb[wave] = bn;
                     sh.oob[wave] = bo;
                 }
                 __syncthreads();
-                if (tid == 0) {
-                    int gap = sh.gap, end_t = sh.end_t, stop = 0;
-                    for (int w = 0; w < 3 && !stop; w++) {
-                        unsigned long long n = sh.nzb[w];
-                        const unsigned long long o = sh.oob[w];
+                if (slot == 0 && live) {  // threads 0 and 128: the sequential gap rule over this round
+                    int gap = sh.gap[dir], end_t = sh.end_t[dir], stop = 0;
+                    for (int w = 0; w < 2 && !stop; w++) {
+                        unsigned long long n = sh.nzb[2 * dir + w];
+                        const unsigned long long o = sh.oob[2 * dir + w];
                         const int valid = o ? __ffsll((long long)o) - 1 : 64;  // steps before the border
                         if (valid < 64) n &= (1ull << valid) - 1ull;
                         int prev = -1;
@@ -415,42 +482,38 @@ __global__ __launch_bounds__(OMR_PPHT_THREADS) void ppht_kernel(const PphtArgs a
                             if (gap > a.line_gap || valid < 64) stop = 1;
                         }
                     }
-                    sh.gap = gap;
-                    sh.end_t = end_t;
-                    sh.stop = stop;
+                    sh.gap[dir] = gap;
+                    sh.end_t[dir] = end_t;
+                    sh.stop[dir] = stop;
                 }
                 __syncthreads();
-                if (sh.stop) break;
+                if (sh.stop[0] && sh.stop[1]) break;
             }
-            if (tid == 0) sh.end[k] = sh.end_t;
-            __syncthreads();
-        }
-        // line ends and the length test
-        int ex[2], ey[2];
-        for (int k = 0; k < 2; k++) {
-            const int t = sh.end[k];
-            const int dx = k ? -wk.dx0 : wk.dx0, dy = k ? -wk.dy0 : wk.dy0;
-            const int x = x0 + t * dx, y = y0 + t * dy;
-            ex[k] = wk.xflag ? x : x >> 16;
-            ey[k] = wk.xflag ? y >> 16 : y;
-        }
-        const bool good = abs(ex[1] - ex[0]) >= a.line_length || abs(ey[1] - ey[0]) >= a.line_length;
+            // line ends and the length test
+            int ex[2], ey[2];
+            for (int k = 0; k < 2; k++) {
+                const int t = sh.end_t[k];
+                const int kx = k ? -wk.dx0 : wk.dx0, ky = k ? -wk.dy0 : wk.dy0;
+                const int x = x0 + t * kx, y = y0 + t * ky;
+                ex[k] = wk.xflag ? x : x >> 16;
+                ey[k] = wk.xflag ? y >> 16 : y;
+            }
+            const bool good = abs(ex[1] - ex[0]) >= a.line_length || abs(ey[1] - ey[0]) >= a.line_length;
 
-        // ---- second pass: erase the segment's points; un-vote them when the segment is accepted
-        for (int k = 0; k < 2; k++) {
-            const int dx = k ? -wk.dx0 : wk.dx0, dy = k ? -wk.dy0 : wk.dy0;
-            const int last = sh.end[k];
-            for (int base = k; base <= last; base += OMR_PPHT_THREADS) {  // k = 1 skips step 0 (erased by k = 0)
-                const int t = base + tid;
+            // ---- second pass: erase the segment's points; un-vote them when the segment is accepted.
+            // Round 0 reuses the first pass's flags (the mask has not changed since).
+            const int last = sh.end_t[dir], last_max = max(sh.end_t[0], sh.end_t[1]);
+            for (int base = 0; base <= last_max; base += 128) {
+                const int t = base + slot;
                 bool on = false;
-                uint32_t pt = 0;
-                if (t <= last) {
+                uint32_t ptw = 0;
+                if (t <= last && !(dir == 1 && t == 0)) {  // step 0 belongs to direction 0
                     const int x = x0 + t * dx, y = y0 + t * dy;
                     const int j1 = wk.xflag ? x : x >> 16, i1 = wk.xflag ? y >> 16 : y;
-                    uint8_t *m = mask + (int64_t)i1 * W + j1;
-                    if (mask_load(m)) {
-                        on = true;
-                        pt = ((uint32_t)i1 << 16) | (uint32_t)j1;
+                    uint8_t *m = mask + mask_offset(i1, j1, TX);
+                    on = base == 0 ? on0 : mask_load(m) != 0;
+                    if (on) {
+                        ptw = ((uint32_t)i1 << 16) | (uint32_t)j1;
                         mask_clear(m);
                     }
                 }
@@ -458,32 +521,70 @@ __global__ __launch_bounds__(OMR_PPHT_THREADS) void ppht_kernel(const PphtArgs a
                     const unsigned long long bn = __ballot(on);
                     if (lane == 0) sh.nzb[wave] = bn;
                     __syncthreads();
-                    int before = __popcll(bn & ((1ull << lane) - 1ull));
-                    for (int w = 0; w < wave; w++) before += __popcll(sh.nzb[w]);
-                    if (on) sh.pts[before] = (int)pt;
-                    const int np = __popcll(sh.nzb[0]) + __popcll(sh.nzb[1]) + __popcll(sh.nzb[2]);
+                    int before = __popcll(bn & ((1ull << lane) - 1ull)), np = 0;
+                    for (int w = 0; w < 4; w++) {
+                        const int c = __popcll(sh.nzb[w]);
+                        if (w < wave) before += c;
+                        np += c;
+                    }
+                    if (on) sh.pts[before] = (int)ptw;
                     __syncthreads();
                     if (voter) {
-                        for (int q = 0; q < np; q++) {
-                            const uint32_t p = (uint32_t)sh.pts[q];
-                            const float fr = __fadd_rn(__fmul_rn((float)(p & 0xffffu), tc), __fmul_rn((float)(p >> 16), ts));
-                            atomicAdd(row + __float2int_rn(fr), -1);  // no return value: fire and forget
+                        // Un-vote as load / store pairs (the row is this lane's alone), eight points at
+                        // a time with all loads in flight together; points of a chunk that share a bin
+                        // are merged first (the last one carries the sum), chunks follow each other in
+                        // program order (same lane, same address: L2 keeps the order).
+                        {
+                            const int q1 = np;
+                            for (int qb = 0; qb < q1; qb += 8) {
+                                int bin[8], c[8], v[8];
+#pragma unroll
+                                for (int i = 0; i < 8; i++) {
+                                    const int q = qb + i;
+                                    bin[i] = -0x40000000 + i;  // distinct sentinels
+                                    c[i] = 0;
+                                    if (q < q1) {
+                                        const uint32_t p = (uint32_t)sh.pts[q];
+                                        bin[i] = __float2int_rn(__fadd_rn(__fmul_rn((float)(p & 0xffffu), tc),
+                                                                          __fmul_rn((float)(p >> 16), ts)));
+                                        c[i] = 1;
+                                    }
+                                }
+#pragma unroll
+                                for (int i = 1; i < 8; i++)
+#pragma unroll
+                                    for (int j = 0; j < i; j++)
+                                        if (bin[i] == bin[j]) {
+                                            c[i] += c[j];
+                                            c[j] = 0;
+                                        }
+#pragma unroll
+                                for (int i = 0; i < 8; i++)
+                                    if (c[i]) v[i] = __hip_atomic_load(row + bin[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                                for (int i = 0; i < 8; i++)
+                                    if (c[i])
+                                        __hip_atomic_store(row + bin[i], v[i] - c[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            }
                         }
                     }
-                    __syncthreads();
                 }
             }
-        }
-        if (tid == 0 && good) {
-            if (nl < a.cap) {
-                lines[4 * nl] = ex[0];
-                lines[4 * nl + 1] = ey[0];
-                lines[4 * nl + 2] = ex[1];
-                lines[4 * nl + 3] = ey[1];
+            if (tid == 0 && good) {
+                if (nl < a.cap) {
+                    lines[4 * nl] = ex[0];
+                    lines[4 * nl + 1] = ey[0];
+                    lines[4 * nl + 2] = ex[1];
+                    lines[4 * nl + 3] = ey[1];
+                }
+                nl++;
             }
-            nl++;
         }
-        __syncthreads();  // erasures are complete before thread 0 tests the next points
+        __syncthreads();  // erasures are complete: wave 0 re-tests the points it still holds
+        if (wave == 0 && pend) {
+            const bool on = ((pend >> lane) & 1ull) && mask_load(mask + mask_offset((int)(pt >> 16), (int)(pt & 0xffffu), TX)) != 0;
+            pend = __ballot(on);
+        }
     }
     if (tid == 0) a.n_lines[scan] = nl;
 }
@@ -511,6 +612,35 @@ __global__ __launch_bounds__(256) void angle_votes_kernel(const float *__restric
         for (int j = 0; j < n; j++) c += fabsf(__fsub_rn(ai, ang[j])) < 0.1f;
     }
     counts[i] = c;
+}
+
+__global__ __launch_bounds__(256) void angle_votes_batch_kernel(const float *__restrict__ ang,
+                                                                const int64_t *__restrict__ off, int as_f64,
+                                                                int32_t *__restrict__ counts)
+{
+    const int64_t o = off[blockIdx.y];
+    const int n = (int)(off[blockIdx.y + 1] - o);
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float *a = ang + o;
+    const float ai = a[i];
+    int c = 0;
+    if (as_f64) {
+        const double di = (double)ai;
+        for (int j = 0; j < n; j++) c += fabs(di - (double)a[j]) < 0.1;
+    } else {
+        for (int j = 0; j < n; j++) c += fabsf(__fsub_rn(ai, a[j])) < 0.1f;
+    }
+    counts[o + i] = c;
+}
+
+hipError_t launch_angle_votes_batch(const float *d_angles, const int64_t *d_off, int n_scans, int max_n, int as_f64,
+                                    int32_t *d_counts, hipStream_t s)
+{
+    if (n_scans <= 0 || max_n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(angle_votes_batch_kernel, dim3((max_n + 255) / 256, n_scans), dim3(256), 0, s, d_angles, d_off,
+                       as_f64, d_counts);
+    return hipGetLastError();
 }
 
 hipError_t launch_angle_votes(const float *d_angles, int n, int as_f64, int32_t *d_counts, hipStream_t s)

@@ -21,15 +21,19 @@ hipError_t launch_edges_rowcount(uint8_t *d_map, int rows, int cols, int n, int 
 // exclusive scan of the row counts of every scan; d_total[scan] = number of edge pixels
 hipError_t launch_edges_rowscan(const int32_t *d_rowcnt, int rows, int n, int32_t *d_rowoff, int32_t *d_total,
                                 hipStream_t s);
-// raster-order list of the non-zero pixels: nz[scan_off[scan] + k] = y << 16 | x
+// raster-order list of the non-zero pixels: nz[scan_off[scan] + k] = y << 16 | x, and the mask of the
+// Hough stage in 8x8-pixel tiles (one 64-byte line per tile: a line walk of 128 steps touches ~16
+// lines instead of up to 128): byte of (y, x) = ((y >> 3) * tiles_x + (x >> 3)) * 64 + (y & 7) * 8 + (x & 7)
 hipError_t launch_edges_compact(const uint8_t *d_edges, int rows, int cols, int n, const int32_t *d_rowoff,
-                                const int64_t *d_scan_off, uint32_t *d_nz, hipStream_t s);
+                                const int64_t *d_scan_off, uint32_t *d_nz, uint8_t *d_mask_tiled, hipStream_t s);
+__host__ __device__ inline int ppht_tiles_x(int cols) { return (cols + 7) / 8; }
+__host__ __device__ inline int64_t ppht_mask_bytes(int rows, int cols) { return (int64_t)((rows + 7) / 8) * ppht_tiles_x(cols) * 64; }
 
 struct PphtWalk {  // per accumulator angle: the line walk of hough.cpp (16.16 fixed point)
     int32_t xflag, dx0, dy0, pad;
 };
 struct PphtArgs {
-    uint8_t *mask;            // n x height x width, non-zero = point still available (destroyed)
+    uint8_t *mask;            // n x ppht_mask_bytes(), 8x8 tiles, non-zero = point still available (destroyed)
     int32_t width, height;
     uint32_t *nz;             // point lists (destroyed)
     const int64_t *scan_off;  // [n] offset of a scan's list in nz
@@ -43,11 +47,14 @@ struct PphtArgs {
     int32_t cap;
     int32_t *n_lines;         // [n]
 };
-#define OMR_PPHT_THREADS 192  // lane = accumulator angle; numangle <= 192
+#define OMR_PPHT_THREADS 256  // lane = accumulator angle; numangle <= 256
 hipError_t launch_ppht(const PphtArgs &a, int n, hipStream_t s);
 
 // counts[i] = #{ j : |a[i] - a[j]| < 0.1 } in f32 (hough.rs:77-83) or in f64 on widened values
 // (omr.rs:278-284)
 hipError_t launch_angle_votes(const float *d_angles, int n, int as_f64, int32_t *d_counts, hipStream_t s);
+// the same for a batch: scan k owns angles / counts [off[k], off[k + 1]); max_n = the longest list
+hipError_t launch_angle_votes_batch(const float *d_angles, const int64_t *d_off, int n_scans, int max_n, int as_f64,
+                                    int32_t *d_counts, hipStream_t s);
 
 }  // namespace omr

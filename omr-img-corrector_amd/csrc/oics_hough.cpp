@@ -15,6 +15,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <thread>
 #include <vector>
 
 #include "../../include/omrdeskew.h"
@@ -86,7 +87,7 @@ int canny_device(const uint8_t *d_src, int64_t scan_stride, int64_t step, int ro
     return OMR_OK;
 }
 
-// HoughLinesP on n device-resident edge images (d_edges: packed, destroyed; d_rowcnt filled).
+// HoughLinesP on n device-resident edge images (d_edges: packed, kept; d_rowcnt filled).
 int ppht_device(uint8_t *d_edges, int32_t *d_rowcnt, int rows, int cols, int n, const HoughParams &hp, hipStream_t s,
                 std::vector<std::vector<int32_t>> *lines_out)
 {
@@ -115,7 +116,7 @@ int ppht_device(uint8_t *d_edges, int32_t *d_rowcnt, int rows, int cols, int n, 
         }
         walk[k] = w;
     }
-    DevBuf rowoff, total, scanoff, nz, d_ttab, d_walk, accum, lines, nlines;
+    DevBuf rowoff, total, scanoff, nz, d_ttab, d_walk, accum, lines, nlines, tiled;
     OMR_HIP(rowoff.alloc(sizeof(int32_t) * (size_t)n * rows));
     OMR_HIP(total.alloc(sizeof(int32_t) * (size_t)n));
     OMR_HIP(launch_edges_rowscan(d_rowcnt, rows, n, rowoff.as<int32_t>(), total.as<int32_t>(), s));
@@ -134,7 +135,9 @@ int ppht_device(uint8_t *d_edges, int32_t *d_rowcnt, int rows, int cols, int n, 
     OMR_HIP(scanoff.alloc(sizeof(int64_t) * (size_t)n));
     OMR_HIP(nz.alloc(sizeof(uint32_t) * (size_t)std::max<int64_t>(sum, 1)));
     OMR_HIP(hipMemcpyAsync(scanoff.p, off.data(), sizeof(int64_t) * (size_t)n, hipMemcpyHostToDevice, s));
-    OMR_HIP(launch_edges_compact(d_edges, rows, cols, n, rowoff.as<int32_t>(), scanoff.as<int64_t>(), nz.as<uint32_t>(), s));
+    OMR_HIP(tiled.alloc((size_t)n * (size_t)ppht_mask_bytes(rows, cols)));
+    OMR_HIP(launch_edges_compact(d_edges, rows, cols, n, rowoff.as<int32_t>(), scanoff.as<int64_t>(), nz.as<uint32_t>(),
+                                 tiled.as<uint8_t>(), s));
     OMR_HIP(d_ttab.alloc(sizeof(float) * ttab.size()));
     OMR_HIP(d_walk.alloc(sizeof(PphtWalk) * walk.size()));
     OMR_HIP(hipMemcpyAsync(d_ttab.p, ttab.data(), sizeof(float) * ttab.size(), hipMemcpyHostToDevice, s));
@@ -144,7 +147,7 @@ int ppht_device(uint8_t *d_edges, int32_t *d_rowcnt, int rows, int cols, int n, 
     OMR_HIP(lines.alloc(sizeof(int32_t) * 4 * (size_t)n * cap));
     OMR_HIP(nlines.alloc(sizeof(int32_t) * (size_t)n));
     PphtArgs a{};
-    a.mask = d_edges;
+    a.mask = tiled.as<uint8_t>();
     a.width = cols;
     a.height = rows;
     a.nz = nz.as<uint32_t>();
@@ -413,19 +416,47 @@ int omr_edges_detection_batch_device(const uint8_t *d_scans, int32_t n, int64_t 
     std::vector<std::vector<int32_t>> lines;
     hipStream_t s = (hipStream_t)stream;
     if ((rc = edges_lines_device(d_scans, scan_stride_bytes, step_bytes, rows, cols, channels, n, hp, s, &lines))) return rc;
+    // angles on host threads (libm atan2f, as the reference), one vote launch for the whole batch
+    std::vector<std::vector<float>> ang((size_t)n);
+    {
+        const int nt = (int)std::max(1u, std::min<unsigned>((unsigned)n, std::min(std::thread::hardware_concurrency(), 32u)));
+        std::vector<std::thread> pool;
+        for (int t = 0; t < nt; t++)
+            pool.emplace_back([&, t]() {
+                for (int i = t; i < n; i += nt) line_angles(lines[i], &ang[i]);
+            });
+        for (auto &th : pool) th.join();
+    }
+    std::vector<int64_t> off((size_t)n + 1, 0);
+    int max_n = 0;
     for (int i = 0; i < n; i++) {
-        std::vector<float> ang;
-        std::vector<int32_t> cnt;
-        line_angles(lines[i], &ang);
-        if (n_lines) n_lines[i] = (int32_t)ang.size();
-        if (ang.empty()) {  // the reference would panic (quirk B11): report "not a result"
+        off[i + 1] = off[i] + (int64_t)ang[i].size();
+        max_n = std::max(max_n, (int)ang[i].size());
+    }
+    std::vector<int32_t> cnt_all((size_t)off[n]);
+    if (off[n] > 0) {
+        std::vector<float> flat((size_t)off[n]);
+        for (int i = 0; i < n; i++) std::copy(ang[i].begin(), ang[i].end(), flat.begin() + off[i]);
+        DevBuf da, dc, doff;
+        OMR_HIP(da.alloc(sizeof(float) * flat.size()));
+        OMR_HIP(dc.alloc(sizeof(int32_t) * flat.size()));
+        OMR_HIP(doff.alloc(sizeof(int64_t) * off.size()));
+        OMR_HIP(hipMemcpyAsync(da.p, flat.data(), sizeof(float) * flat.size(), hipMemcpyHostToDevice, s));
+        OMR_HIP(hipMemcpyAsync(doff.p, off.data(), sizeof(int64_t) * off.size(), hipMemcpyHostToDevice, s));
+        OMR_HIP(launch_angle_votes_batch(da.as<float>(), doff.as<int64_t>(), n, max_n, 1, dc.as<int32_t>(), s));
+        OMR_HIP(hipMemcpyAsync(cnt_all.data(), dc.p, sizeof(int32_t) * flat.size(), hipMemcpyDeviceToHost, s));
+        OMR_HIP(hipStreamSynchronize(s));
+    }
+    for (int i = 0; i < n; i++) {
+        if (n_lines) n_lines[i] = (int32_t)ang[i].size();
+        if (ang[i].empty()) {  // the reference would panic (quirk B11): report "not a result"
             angles[i] = 0.0;
             if (status) status[i] = OMR_STATUS_NOT_A_RESULT;
             continue;
         }
-        if ((rc = vote_counts(ang, true, s, &cnt))) return rc;
+        std::vector<int32_t> cnt(cnt_all.begin() + off[i], cnt_all.begin() + off[i + 1]);
         int32_t st = 0, nc = 0;
-        if ((rc = select_omr_rs(ang, cnt, &angles[i], &st, nullptr, 0, &nc))) return rc;
+        if ((rc = select_omr_rs(ang[i], cnt, &angles[i], &st, nullptr, 0, &nc))) return rc;
         if (status) status[i] = st;
     }
     return OMR_OK;
