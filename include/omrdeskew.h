@@ -303,6 +303,37 @@ int omr_correct_default(const omr_image *src_bgr, uint16_t projection_max_angle,
                         double hough_max_line_gap, double *rotate_angle, int32_t *need_check,
                         omr_image_owned *rotated);
 
+/* ---- FFT deskew path ------------------------------------------------------
+ * The 2-D DFT is float32 like the reference's (dft on CV_32F); it is a different factorisation than
+ * OpenCV's (radix-2 Stockham / Bluestein chirp-z in LDS), so the 8-bit spectrum pictures agree with
+ * the CPU restatement to about one grey level, not bit for bit.  Everything after the picture
+ * (Canny, HoughLinesP, votes) is the exact chain of the Hough-line path.  Each axis length must be a
+ * power of two <= 8192 or any length <= 4096 (-213 otherwise). */
+
+/* oics::fft::get_fft_image(&TransformableMatrix) -> Result<(Mat, Mat)> (fft.rs:124-141):
+ * (magnitude_image, magnitude_log_image), both 8-bit single channel.  Either output may be NULL. */
+int omr_get_fft_image(const omr_image *gray_u8c1, omr_image_owned *magnitude_image,
+                      omr_image_owned *magnitude_log_image);
+
+/* The magnitude_log pictures of n device-resident scans of one shape (BASELINE config 5):
+ * d_magnitude_log: n x rows x cols bytes, packed. */
+int omr_fft_image_batch_device(const uint8_t *d_scans, int32_t n, int64_t scan_stride_bytes, int32_t rows,
+                               int32_t cols, int64_t step_bytes, uint8_t *d_magnitude_log, void *stream);
+
+/* oics::fft::get_angle_with_fft(&TransformableMatrix, canny_threshold_1, canny_threshold_2,
+ * min_line_length, max_line_gap, file_name, edge_image_output_dir) -> Result<f64> (fft.rs:145-256;
+ * called core/src/main.rs:141-150, app/src-tauri/src/test.rs:450-459).  The debug picture stays with
+ * the caller (as for omr_get_angle_with_hough).  Keeps the vote's quirk (fft.rs:231 re-reads line i). */
+int omr_get_angle_with_fft(const omr_image *gray_u8c1, double canny_threshold_1, double canny_threshold_2,
+                           double min_line_length, double max_line_gap, double *angle_out);
+
+/* oics::omr::get_result_from_fourier_transform(&Mat, weak, strong, min_line_length, max_line_gap) ->
+ * Result<OmrResult> (omr.rs:304-337) on the 3/4-channel scan. */
+int omr_get_result_from_fourier_transform(const omr_image *src, double canny_threshold_weak,
+                                          double canny_threshold_strong, double fourier_min_line_length,
+                                          double fourier_max_line_gap, double *angle, int32_t *status,
+                                          double *candidates, int32_t cand_cap, int32_t *cand_len);
+
 /* calculate::get_arithmetic_mean / get_standard_deviation (calculate.rs:2-10, :13-23) */
 int omr_get_arithmetic_mean(const double *v, size_t n, double *out);
 int omr_get_standard_deviation(const double *v, size_t n, double *out);

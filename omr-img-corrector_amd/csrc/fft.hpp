@@ -1,0 +1,48 @@
+// fft.hpp -- device kernels of the FFT deskew path: the spectrum pictures of
+// packages/lib/src/fft.rs:42-141 (2-D complex float32 DFT with DFT_SCALE, fft_shift, magnitude,
+// min-max "correction", log, 8-bit conversion).
+#pragma once
+#include <hip/hip_runtime_api.h>
+#include <stdint.h>
+
+namespace omr {
+
+struct cfloat {
+    float x, y;
+};
+
+// One pass of 1-D transforms over `lines` lines of length n, a whole line per workgroup in LDS:
+// a radix-2 Stockham FFT when n is a power of two (m = n), else Bluestein's chirp-z through two
+// FFTs of length m = the power of two >= 2n - 1.  m <= 8192 (2 x 64 KiB of LDS).
+struct FftPass {
+    const uint8_t *src_u8;  // real 8-bit input (im = 0), x = (float)v * in_scale; or NULL
+    int64_t src_step;       // bytes between lines of src_u8
+    float in_scale;
+    const cfloat *src_c;    // complex input, lines of n elements, packed; used when src_u8 == NULL
+    cfloat *dst;            // [lines][n]
+    int32_t n, m, log2m, lines;
+    const cfloat *W;        // m / 2 twiddles exp(-2 pi i t / m)
+    const cfloat *chirp;    // n: exp(-i pi k^2 / n); NULL for the direct transform
+    const cfloat *Bf;       // m: FFT_m of the padded conjugate chirp (Bluestein)
+    float out_scale;
+};
+#define OMR_FFT_MAX_M 8192
+hipError_t launch_fft_pass(const FftPass &p, hipStream_t s);
+
+// [rows][cols] -> [cols][rows]
+hipError_t launch_transpose_c(const cfloat *d_src, int rows, int cols, cfloat *d_dst, hipStream_t s);
+
+// d_minmax: 4 ordered-uint words {min |F|, max |F|, min log, max log}; launch_spec_reset initialises them
+hipError_t launch_spec_reset(uint32_t *d_minmax, hipStream_t s);
+// |F| of the quadrant-swapped spectrum (fft.rs:68-88, :108-110) and its min / max
+hipError_t launch_spec_magnitude(const cfloat *d_F, int rows, int cols, float *d_mag, uint32_t *d_minmax,
+                                 hipStream_t s);
+// correction(|F|) * 255 -> 8-bit "magnitude_image" (x 255 again, fft.rs:134) and log(. + 1/255) with its
+// min / max (fft.rs:113-119)
+hipError_t launch_spec_normalise(const float *d_mag, int rows, int cols, const uint32_t *d_minmax_in,
+                                 uint8_t *d_mag_u8, float *d_log, uint32_t *d_minmax_out, hipStream_t s);
+// correction(log) -> 8-bit "magnitude_log_image" (fft.rs:136-138)
+hipError_t launch_spec_log_u8(const float *d_log, int rows, int cols, const uint32_t *d_minmax, uint8_t *d_log_u8,
+                              hipStream_t s);
+
+}  // namespace omr

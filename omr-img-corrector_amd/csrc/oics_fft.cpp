@@ -1,0 +1,344 @@
+// oics_fft.cpp -- host side of the FFT deskew path, exported through the C ABI
+// with the reference's names and argument meaning:
+//
+//   oics::fft::get_fft_image                       packages/lib/src/fft.rs:124-141
+//   oics::fft::get_angle_with_fft                  packages/lib/src/fft.rs:145-256
+//   oics::omr::get_result_from_fourier_transform   packages/lib/src/omr.rs:304-337
+//
+// The DFT, the spectrum pictures, Canny and HoughLinesP run on the GPU (fft.hip, hough.hip); the host
+// tabulates twiddles and Bluestein chirps in double precision (once per call -- a few thousand
+// cos / sin and one length-m double FFT per axis), turns segments into angles with libm atan2 and
+// applies the reference's vote.  No CPU fallback: without a HIP device every entry point returns -217.
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <complex>
+#include <vector>
+
+#include "../../include/omrdeskew.h"
+#include "engine.hpp"
+#include "fft.hpp"
+#include "hough.hpp"
+#include "hough_host.hpp"
+#include "kernels.hpp"
+
+using namespace omr;
+using namespace omr::hh;
+
+namespace {
+
+typedef std::complex<double> cd;
+const double kPi = 3.14159265358979323846;
+
+void fft_host(std::vector<cd> &a)  // iterative radix-2, in place, forward
+{
+    const size_t n = a.size();
+    for (size_t i = 1, j = 0; i < n; i++) {
+        size_t bit = n >> 1;
+        for (; j & bit; bit >>= 1) j ^= bit;
+        j ^= bit;
+        if (i < j) std::swap(a[i], a[j]);
+    }
+    for (size_t len = 2; len <= n; len <<= 1) {
+        for (size_t i = 0; i < n; i += len)
+            for (size_t k = 0; k < len / 2; k++) {
+                const double ang = -2.0 * kPi * (double)k / (double)len;
+                const cd w(cos(ang), sin(ang));
+                const cd u = a[i + k], v = a[i + k + len / 2] * w;
+                a[i + k] = u + v;
+                a[i + k + len / 2] = u - v;
+            }
+    }
+}
+
+// device tables of one axis length
+struct AxisTables {
+    int n = 0, m = 0, log2m = 0;
+    bool blue = false;
+    DevBuf W, chirp, Bf;
+    int build(int len, hipStream_t s)
+    {
+        n = len;
+        blue = (n & (n - 1)) != 0;
+        m = 1;
+        log2m = 0;
+        const int need = blue ? 2 * n - 1 : n;
+        while (m < need) {
+            m <<= 1;
+            log2m++;
+        }
+        if (m > OMR_FFT_MAX_M)
+            return fail(OMR_ERR_NOTIMPL, "DFT length %d needs a transform of %d points; the kernel holds at most %d in LDS", n,
+                        m, OMR_FFT_MAX_M);
+        std::vector<cfloat> w((size_t)std::max(m / 2, 1));
+        for (int t = 0; t < m / 2; t++) {
+            const double ang = -2.0 * kPi * (double)t / (double)m;
+            w[t] = cfloat{(float)cos(ang), (float)sin(ang)};
+        }
+        OMR_HIP(W.alloc(sizeof(cfloat) * w.size()));
+        OMR_HIP(hipMemcpyAsync(W.p, w.data(), sizeof(cfloat) * w.size(), hipMemcpyHostToDevice, s));
+        if (blue) {
+            std::vector<cd> c((size_t)n);
+            for (int k = 0; k < n; k++) {
+                const long long k2 = ((long long)k * k) % (2LL * n);  // exp(-i pi k^2 / n) has period 2n in k^2
+                const double ang = -kPi * (double)k2 / (double)n;
+                c[k] = cd(cos(ang), sin(ang));
+            }
+            std::vector<cd> b((size_t)m, cd(0, 0));
+            b[0] = std::conj(c[0]);
+            for (int k = 1; k < n; k++) b[k] = b[m - k] = std::conj(c[k]);
+            fft_host(b);
+            std::vector<cfloat> cf((size_t)n), bf((size_t)m);
+            for (int k = 0; k < n; k++) cf[k] = cfloat{(float)c[k].real(), (float)c[k].imag()};
+            for (int k = 0; k < m; k++) bf[k] = cfloat{(float)b[k].real(), (float)b[k].imag()};
+            OMR_HIP(chirp.alloc(sizeof(cfloat) * cf.size()));
+            OMR_HIP(Bf.alloc(sizeof(cfloat) * bf.size()));
+            OMR_HIP(hipMemcpyAsync(chirp.p, cf.data(), sizeof(cfloat) * cf.size(), hipMemcpyHostToDevice, s));
+            OMR_HIP(hipMemcpyAsync(Bf.p, bf.data(), sizeof(cfloat) * bf.size(), hipMemcpyHostToDevice, s));
+            OMR_HIP(hipStreamSynchronize(s));  // the host vectors go out of scope
+        } else {
+            OMR_HIP(hipStreamSynchronize(s));
+        }
+        return OMR_OK;
+    }
+};
+
+// workspace + tables for scans of one shape
+struct FftWork {
+    int rows = 0, cols = 0;
+    AxisTables ax_cols, ax_rows;  // transforms along a row (length cols) / along a column (length rows)
+    DevBuf c0, c1, mag, lg, mm;
+    int create(int r, int c, hipStream_t s)
+    {
+        rows = r;
+        cols = c;
+        int rc;
+        if ((rc = ax_cols.build(c, s))) return rc;
+        if ((rc = ax_rows.build(r, s))) return rc;
+        const size_t px = (size_t)r * c;
+        OMR_HIP(c0.alloc(sizeof(cfloat) * px));
+        OMR_HIP(c1.alloc(sizeof(cfloat) * px));
+        OMR_HIP(mag.alloc(sizeof(float) * px));
+        OMR_HIP(lg.alloc(sizeof(float) * px));
+        OMR_HIP(mm.alloc(sizeof(uint32_t) * 4));
+        return OMR_OK;
+    }
+    // fft.rs:124-141 for one device-resident 8-bit scan -> the two 8-bit pictures (device, packed)
+    int run(const uint8_t *d_gray, int64_t step, uint8_t *d_mag_u8, uint8_t *d_log_u8, hipStream_t s)
+    {
+        FftPass p{};
+        // along rows: u8 * (1 / 255) -> complex spectrum lines
+        p.src_u8 = d_gray;
+        p.src_step = step;
+        p.in_scale = (float)(1.0 / 255.0);  // convert_to(CV_32F, 1.0 / 255.0): alpha cast to float
+        p.dst = c0.as<cfloat>();
+        p.n = cols;
+        p.m = ax_cols.m;
+        p.log2m = ax_cols.log2m;
+        p.lines = rows;
+        p.W = ax_cols.W.as<cfloat>();
+        p.chirp = ax_cols.blue ? ax_cols.chirp.as<cfloat>() : nullptr;
+        p.Bf = ax_cols.blue ? ax_cols.Bf.as<cfloat>() : nullptr;
+        p.out_scale = 1.0f;
+        OMR_HIP(launch_fft_pass(p, s));
+        OMR_HIP(launch_transpose_c(c0.as<cfloat>(), rows, cols, c1.as<cfloat>(), s));
+        // along columns (now lines of the transposed array), with DFT_SCALE
+        FftPass q{};
+        q.src_c = c1.as<cfloat>();
+        q.dst = c0.as<cfloat>();
+        q.n = rows;
+        q.m = ax_rows.m;
+        q.log2m = ax_rows.log2m;
+        q.lines = cols;
+        q.W = ax_rows.W.as<cfloat>();
+        q.chirp = ax_rows.blue ? ax_rows.chirp.as<cfloat>() : nullptr;
+        q.Bf = ax_rows.blue ? ax_rows.Bf.as<cfloat>() : nullptr;
+        q.out_scale = (float)(1.0 / ((double)rows * (double)cols));
+        OMR_HIP(launch_fft_pass(q, s));
+        OMR_HIP(launch_transpose_c(c0.as<cfloat>(), cols, rows, c1.as<cfloat>(), s));  // back to [rows][cols]
+        OMR_HIP(launch_spec_reset(mm.as<uint32_t>(), s));
+        OMR_HIP(launch_spec_magnitude(c1.as<cfloat>(), rows, cols, mag.as<float>(), mm.as<uint32_t>(), s));
+        OMR_HIP(launch_spec_normalise(mag.as<float>(), rows, cols, mm.as<uint32_t>(), d_mag_u8, lg.as<float>(),
+                                      mm.as<uint32_t>() + 2, s));
+        OMR_HIP(launch_spec_log_u8(lg.as<float>(), rows, cols, mm.as<uint32_t>() + 2, d_log_u8, s));
+        return OMR_OK;
+    }
+};
+
+int check_gray(const omr_image *im)
+{
+    int rc = check_img(im);
+    if (rc) return rc;
+    if (im->channels != 1) return fail(OMR_ERR_ASSERT, "the FFT path takes an 8-bit single-channel image");
+    return OMR_OK;
+}
+
+int download_owned(const uint8_t *d, int rows, int cols, omr_image_owned *out, hipStream_t s)
+{
+    out->rows = rows;
+    out->cols = cols;
+    out->channels = 1;
+    out->step_bytes = cols;
+    out->data = (uint8_t *)malloc((size_t)rows * cols);
+    if (!out->data) return fail(OMR_ERR_NOMEM, "out of host memory");
+    hipError_t e = hipMemcpyAsync(out->data, d, (size_t)rows * cols, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e != hipSuccess) {
+        omr_image_free(out);
+        return fail_gpu("download picture", e);
+    }
+    return OMR_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int omr_get_fft_image(const omr_image *gray, omr_image_owned *magnitude_image, omr_image_owned *magnitude_log_image)
+{
+    clear_error();
+    int rc = check_gray(gray);
+    if (rc) return rc;
+    if (!magnitude_image && !magnitude_log_image) return fail(OMR_ERR_BADARG, "null output");
+    if ((rc = have_device())) return rc;
+    HStream st;
+    if ((rc = st.create())) return rc;
+    DevBuf in, m8, l8;
+    if ((rc = upload(gray, &in, st.s))) return rc;
+    FftWork w;
+    if ((rc = w.create(gray->rows, gray->cols, st.s))) return rc;
+    const size_t px = (size_t)gray->rows * gray->cols;
+    OMR_HIP(m8.alloc(px));
+    OMR_HIP(l8.alloc(px));
+    if ((rc = w.run(in.as<uint8_t>(), gray->cols, m8.as<uint8_t>(), l8.as<uint8_t>(), st.s))) return rc;
+    if (magnitude_image && (rc = download_owned(m8.as<uint8_t>(), gray->rows, gray->cols, magnitude_image, st.s))) return rc;
+    if (magnitude_log_image &&
+        (rc = download_owned(l8.as<uint8_t>(), gray->rows, gray->cols, magnitude_log_image, st.s))) {
+        if (magnitude_image) omr_image_free(magnitude_image);
+        return rc;
+    }
+    return OMR_OK;
+}
+
+// n device-resident scans of one shape -> their magnitude_log pictures (device, packed n x rows x cols)
+int omr_fft_image_batch_device(const uint8_t *d_scans, int32_t n, int64_t scan_stride_bytes, int32_t rows, int32_t cols,
+                               int64_t step_bytes, uint8_t *d_magnitude_log, void *stream)
+{
+    clear_error();
+    if (!d_scans || !d_magnitude_log || n <= 0) return fail(OMR_ERR_BADARG, "null pointer or empty batch");
+    if (rows <= 0 || cols <= 0 || rows >= 32767 || cols >= 32767) return fail(OMR_ERR_ASSERT, "bad image shape");
+    if (step_bytes < cols) return fail(OMR_ERR_BADARG, "step_bytes too small");
+    int rc = have_device();
+    if (rc) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    FftWork w;
+    if ((rc = w.create(rows, cols, s))) return rc;
+    DevBuf m8;
+    const size_t px = (size_t)rows * cols;
+    OMR_HIP(m8.alloc(px));
+    for (int i = 0; i < n; i++)
+        if ((rc = w.run(d_scans + (int64_t)i * scan_stride_bytes, step_bytes, m8.as<uint8_t>(), d_magnitude_log + (size_t)i * px,
+                        s)))
+            return rc;
+    OMR_HIP(hipStreamSynchronize(s));  // the workspace is released on return
+    return OMR_OK;
+}
+
+int omr_get_angle_with_fft(const omr_image *gray, double canny_threshold_1, double canny_threshold_2,
+                           double min_line_length, double max_line_gap, double *angle_out)
+{
+    clear_error();
+    int rc = check_gray(gray);
+    if (rc) return rc;
+    if (!angle_out) return fail(OMR_ERR_BADARG, "null output");
+    if ((rc = have_device())) return rc;
+    HStream st;
+    if ((rc = st.create())) return rc;
+    const int rows = gray->rows, cols = gray->cols;
+    DevBuf in, m8, l8;
+    if ((rc = upload(gray, &in, st.s))) return rc;
+    FftWork w;
+    if ((rc = w.create(rows, cols, st.s))) return rc;
+    OMR_HIP(m8.alloc((size_t)rows * cols));
+    OMR_HIP(l8.alloc((size_t)rows * cols));
+    if ((rc = w.run(in.as<uint8_t>(), cols, m8.as<uint8_t>(), l8.as<uint8_t>(), st.s))) return rc;
+    HoughParams hp;
+    hp.low = canny_threshold_1;
+    hp.high = canny_threshold_2;
+    hp.threshold = 100;  // fft.rs:184
+    hp.min_line_length = min_line_length;
+    hp.max_line_gap = max_line_gap;
+    std::vector<std::vector<int32_t>> lines;
+    if ((rc = edges_lines_device(l8.as<uint8_t>(), 0, cols, rows, cols, 1, 1, hp, st.s, &lines))) return rc;
+    // fft.rs:197-247: f64 angles folded into [-45, 45]; the inner loop re-reads line i (quirk B10), so
+    // line i collects n - 1 votes iff its raw angle is within 0.1 of its folded angle, else none
+    const std::vector<int32_t> &l = lines[0];
+    const int n = (int)(l.size() / 4);
+    double average_angle = 0.0;
+    int max_votes = 0;
+    for (int i = 0; i < n; i++) {
+        const double x1 = l[4 * i], y1 = l[4 * i + 1], x2 = l[4 * i + 2], y2 = l[4 * i + 3];
+        const double raw = (atan2(y2 - y1, x2 - x1) * 180.0) / kPi;
+        const double angle = raw < -45.0 ? raw + 90.0 : (raw > 45.0 ? raw - 90.0 : raw);
+        int votes = 0;
+        for (int j = 0; j < n; j++) {
+            if (i == j) continue;
+            if (fabs(raw - angle) < 0.1) votes++;
+        }
+        if (votes > max_votes) {
+            max_votes = votes;
+            average_angle = angle;
+        }
+        if (max_votes == n - 1 && n > 1) break;  // nothing can beat n - 1 with a strict '>'
+    }
+    *angle_out = average_angle;
+    return OMR_OK;
+}
+
+int omr_get_result_from_fourier_transform(const omr_image *src, double canny_threshold_weak,
+                                          double canny_threshold_strong, double fourier_min_line_length,
+                                          double fourier_max_line_gap, double *angle, int32_t *status,
+                                          double *candidates, int32_t cand_cap, int32_t *cand_len)
+{
+    clear_error();
+    int rc = check_img(src);
+    if (rc) return rc;
+    if (src->channels != 3 && src->channels != 4)
+        return fail(OMR_ERR_ASSERT, "cvtColor(RGB2GRAY) needs 3 or 4 channels (omr.rs:314)");
+    if (!angle) return fail(OMR_ERR_BADARG, "null output");
+    if ((rc = have_device())) return rc;
+    HStream st;
+    if ((rc = st.create())) return rc;
+    const int rows = src->rows, cols = src->cols;
+    DevBuf in, gray, m8, l8, edges, flag, rowcnt;
+    if ((rc = upload(src, &in, st.s))) return rc;
+    OMR_HIP(gray.alloc((size_t)rows * cols));
+    OMR_HIP(launch_rgb2gray(in.as<uint8_t>(), (int64_t)cols * src->channels, rows, cols, src->channels, gray.as<uint8_t>(),
+                            cols, st.s));
+    FftWork w;
+    if ((rc = w.create(rows, cols, st.s))) return rc;
+    OMR_HIP(m8.alloc((size_t)rows * cols));
+    OMR_HIP(l8.alloc((size_t)rows * cols));
+    if ((rc = w.run(gray.as<uint8_t>(), cols, m8.as<uint8_t>(), l8.as<uint8_t>(), st.s))) return rc;
+    // omr.rs:323-330 Canny(weak, strong) on the log picture, then get_result_from_edges_detection on the
+    // EDGE picture: Canny(50, 150) once more (omr.rs:236-240), HoughLinesP threshold 0, the omr.rs vote
+    OMR_HIP(edges.alloc((size_t)rows * cols));
+    OMR_HIP(flag.alloc(sizeof(int)));
+    OMR_HIP(rowcnt.alloc(sizeof(int32_t) * (size_t)rows));
+    if ((rc = canny_device(l8.as<uint8_t>(), 0, cols, rows, cols, 1, 1, canny_threshold_weak, canny_threshold_strong,
+                           edges.as<uint8_t>(), flag.as<int>(), st.s, rowcnt.as<int32_t>())))
+        return rc;
+    HoughParams hp;
+    hp.min_line_length = fourier_min_line_length;
+    hp.max_line_gap = fourier_max_line_gap;
+    std::vector<std::vector<int32_t>> lines;
+    if ((rc = edges_lines_device(edges.as<uint8_t>(), 0, cols, rows, cols, 1, 1, hp, st.s, &lines))) return rc;
+    std::vector<float> ang;
+    std::vector<int32_t> cnt;
+    line_angles(lines[0], &ang);
+    if ((rc = vote_counts(ang, true, st.s, &cnt))) return rc;
+    return select_omr_rs(ang, cnt, angle, status, candidates, cand_cap, cand_len);
+}
+
+}  // extern "C"

@@ -21,23 +21,23 @@
 #include "../../include/omrdeskew.h"
 #include "engine.hpp"
 #include "hough.hpp"
+#include "hough_host.hpp"
 
 using namespace omr;
+using namespace omr::hh;
 
-namespace {
+namespace omr {
+namespace hh {
 
-struct HStream {
-    hipStream_t s = nullptr;
-    ~HStream()
-    {
-        if (s) (void)hipStreamDestroy(s);
-    }
-    int create()
-    {
-        OMR_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
-        return OMR_OK;
-    }
-};
+int HStream::create()
+{
+    OMR_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    return OMR_OK;
+}
+HStream::~HStream()
+{
+    if (s) (void)hipStreamDestroy(s);
+}
 
 int have_device()
 {
@@ -60,13 +60,6 @@ int check_img(const omr_image *im)
 
 inline int cv_round(double v) { return (int)lrint(v); }
 inline int cv_round(float v) { return (int)lrintf(v); }
-
-struct HoughParams {
-    double low = 50.0, high = 150.0;  // hough.rs:27, omr.rs:239
-    double rho = 1.0, theta = 3.14159265358979323846 / 180.0;
-    int threshold = 0;
-    double min_line_length = 0, max_line_gap = 0;
-};
 
 // Canny on n device-resident scans of one shape -> d_map holds the edges (0 / 255), packed.
 int canny_device(const uint8_t *d_src, int64_t scan_stride, int64_t step, int rows, int cols, int cn, int n, double low_t,
@@ -282,7 +275,8 @@ int edges_lines_device(const uint8_t *d_src, int64_t scan_stride, int64_t step, 
     return ppht_device(map.as<uint8_t>(), rowcnt.as<int32_t>(), rows, cols, n, hp, s, lines);
 }
 
-}  // namespace
+}  // namespace hh
+}  // namespace omr
 
 extern "C" {
 

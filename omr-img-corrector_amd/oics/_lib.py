@@ -105,6 +105,12 @@ SYMBOLS = {
     "omr_correct_default_decision": (None, [C.c_double, C.c_int32, f64p, C.c_int32, C.c_double, f64p, i32p]),
     "omr_correct_default": (C.c_int, [C.POINTER(OmrImage), C.c_uint16, C.c_double, C.c_int32, C.c_int32, C.c_double,
                                       C.c_double, f64p, i32p, C.POINTER(OmrImageOwned)]),
+    "omr_get_fft_image": (C.c_int, [C.POINTER(OmrImage), C.POINTER(OmrImageOwned), C.POINTER(OmrImageOwned)]),
+    "omr_fft_image_batch_device": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.c_int64,
+                                             C.c_void_p, C.c_void_p]),
+    "omr_get_angle_with_fft": (C.c_int, [C.POINTER(OmrImage), C.c_double, C.c_double, C.c_double, C.c_double, f64p]),
+    "omr_get_result_from_fourier_transform": (C.c_int, [C.POINTER(OmrImage), C.c_double, C.c_double, C.c_double,
+                                                        C.c_double, f64p, i32p, f64p, C.c_int32, i32p]),
     "omr_get_arithmetic_mean": (C.c_int, [f64p, C.c_size_t, f64p]),
     "omr_get_standard_deviation": (C.c_int, [f64p, C.c_size_t, f64p]),
 }

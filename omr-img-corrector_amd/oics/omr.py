@@ -97,3 +97,17 @@ def correct_default(src_mat, projection_max_angle, projection_angle_step, projec
                                     float(hough_max_line_gap), C.byref(ang), C.byref(chk),
                                     C.byref(owned) if want_image else None))
     return ang.value, bool(chk.value), (_take(owned) if want_image else None)
+
+
+def get_result_from_fourier_transform(src_mat, canny_threshold_weak, canny_threshold_strong, fourier_min_line_length,
+                                      fourier_max_line_gap):
+    """omr.rs:304-337"""
+    a, im = as_image(_mat(src_mat))
+    cap = 1 << 16
+    cand = np.zeros(cap, np.float64)
+    angle, status, clen = C.c_double(), C.c_int32(), C.c_int32()
+    check(lib().omr_get_result_from_fourier_transform(C.byref(im), float(canny_threshold_weak),
+                                                      float(canny_threshold_strong), float(fourier_min_line_length),
+                                                      float(fourier_max_line_gap), C.byref(angle), C.byref(status),
+                                                      cand.ctypes.data_as(f64p), cap, C.byref(clen)))
+    return OmrResult(angle.value, ResultStatus(status.value), cand[: min(clen.value, cap)].copy())

@@ -45,6 +45,11 @@ def main():
     case("hough_120x97_s5_bgr", bgr.astype(np.uint8), 20.0, 5.0)
     d = np.load(os.path.join(OUT, "dataset_image001.npz"))
     case("hough_dataset_image001", d["gray_small"], 40.0, 8.0)
+    # FFT path (row f4): the two spectrum pictures of one card (oracle/oracle_fft.py, tolerance parity)
+    from oracle import oracle_fft as offt
+    g, _ = synth.make_card(230, 248, 4)
+    m, lg = offt.get_fft_image(g)
+    np.savez_compressed(os.path.join(OUT, "fft_248x230_s4.npz"), img=g, magnitude=m, magnitude_log=lg)
 
 
 if __name__ == "__main__":

@@ -1,0 +1,103 @@
+"""FFT deskew path through the C ABI against the numpy restatement
+(oracle/oracle_fft.py).  The float32 DFT is a different factorisation than OpenCV's and than numpy's
+double-precision one, so the bar for the 8-bit spectrum pictures is a tolerance, written here:
+every pixel within 1 grey level, at least 99 % identical.  Everything downstream of the picture
+(Canny, HoughLinesP, votes) must equal the oracle's chain run on the SAME picture exactly."""
+import numpy as np
+import pytest
+
+import oics
+from oics import fft, omr, synth
+from oracle import oracle_fft as offt
+
+pytestmark = pytest.mark.gpu
+
+PICTURE_TOL = 1          # grey levels
+PICTURE_EQUAL_MIN = 0.99  # fraction of identical pixels
+
+
+def close(got, exp):
+    d = np.abs(got.astype(np.int16) - exp.astype(np.int16))
+    return int(d.max()), float((d == 0).mean())
+
+
+@pytest.mark.parametrize("rows,cols,seed", [(64, 64, 1), (128, 256, 2), (512, 512, 1), (75, 100, 3), (230, 248, 4),
+                                           (877, 620, 2), (333, 512, 5), (1024, 77, 6)])
+def test_fft_pictures_match_oracle(rows, cols, seed):
+    g, _ = synth.make_card(rows, cols, seed)
+    m, lg = fft.get_fft_image(g)
+    em, elg = offt.get_fft_image(g)
+    assert m.shape == em.shape == (rows, cols) and lg.shape == elg.shape
+    dmax, same = close(lg, elg)
+    assert dmax <= PICTURE_TOL and same >= PICTURE_EQUAL_MIN, ("log picture", dmax, same)
+    dmax, same = close(m, em)
+    assert dmax <= PICTURE_TOL and same >= PICTURE_EQUAL_MIN, ("magnitude picture", dmax, same)
+
+
+def test_fft_picture_properties():
+    # a pure horizontal cosine: the spectrum has its DC peak and two symmetric peaks on the centre row
+    rows, cols = 128, 128
+    x = np.arange(cols)
+    g = np.tile((127.5 + 100.0 * np.cos(2 * np.pi * 8 * x / cols)).astype(np.uint8), (rows, 1))
+    m, lg = fft.get_fft_image(g)
+    cy, cx = rows // 2, cols // 2
+    assert lg[cy, cx] == 255                                    # DC is the maximum after the quadrant swap
+    assert lg[cy, cx + 8] > 200 and lg[cy, cx - 8] > 200 and lg[cy, cx + 8] == lg[cy, cx - 8]
+    assert np.median(lg) < 128
+    # odd sizes: the last row / column stays where the DFT put it (fft.rs:69-74)
+    g, _ = synth.make_card(65, 81, 7)
+    _, lg = fft.get_fft_image(g)
+    _, elg = offt.get_fft_image(g)
+    assert close(lg, elg)[0] <= PICTURE_TOL
+
+
+def test_fft_size_limits():
+    with pytest.raises(oics.OmrError) as e:
+        fft.get_fft_image(np.zeros((16, 5000), np.uint8))       # 5000 is not a power of two and > 4096
+    assert e.value.code == -213
+    with pytest.raises(oics.OmrError) as e:
+        fft.get_fft_image(np.zeros((16, 16, 3), np.uint8))
+    assert e.value.code == -215
+
+
+@pytest.mark.parametrize("rows,cols,seed", [(512, 512, 1), (300, 420, 9)])
+def test_angle_drivers_follow_the_oracle_chain(oracle, rows, cols, seed):
+    g, _ = synth.make_card(rows, cols, seed)
+    _, lg = fft.get_fft_image(g)
+    for c1, c2, mll, mlg in ((50.0, 150.0, 100.0, 15.0), (30.0, 90.0, 40.0, 5.0)):
+        got = fft.get_angle_with_fft(g, c1, c2, mll, mlg)
+        edges = oracle.canny(lg, c1, c2)                        # the oracle's chain on the GPU's picture
+        lines = oracle.hough_lines_p(edges, mll, mlg, threshold=100)
+        assert got == offt.vote_fft_rs(lines)
+    bgr = np.stack([g, g, g], axis=2)
+    r = omr.get_result_from_fourier_transform(bgr, 50.0, 150.0, 100.0, 15.0)
+    edges = oracle.canny(lg, 50.0, 150.0)
+    try:
+        ea, es, ec, _ = oracle.get_result_from_edges_detection(edges, 100.0, 15.0)
+    except RuntimeError:
+        pytest.skip("no segment in this spectrum")
+    assert np.float64(r.angle).view(np.uint64) == np.float64(ea).view(np.uint64) and int(r.status) == es
+    assert r.candidates.size == ec.size and (r.candidates.view(np.uint64) == ec.view(np.uint64)).all()
+
+
+def test_fft_batch_device():
+    import torch
+    rows, cols, n = 256, 320, 4
+    imgs = [synth.make_card(rows, cols, 40 + i)[0] for i in range(n)]
+    d = torch.from_numpy(np.stack(imgs)).to("cuda:0")
+    out = torch.zeros((n, rows, cols), dtype=torch.uint8, device="cuda:0")
+    fft.fft_image_batch_device(d.data_ptr(), n, rows * cols, rows, cols, cols, out.data_ptr())
+    got = out.cpu().numpy()
+    for i in range(n):
+        assert (got[i] == fft.get_fft_image(imgs[i])[1]).all()
+        assert close(got[i], offt.get_fft_image(imgs[i])[1])[0] <= PICTURE_TOL
+
+
+def test_golden_picture(golden_dir):
+    import os
+    d = np.load(os.path.join(golden_dir, "fft_248x230_s4.npz"))
+    m, lg = fft.get_fft_image(d["img"])
+    dmax, same = close(lg, d["magnitude_log"])
+    assert dmax <= PICTURE_TOL and same >= PICTURE_EQUAL_MIN
+    dmax, same = close(m, d["magnitude"])
+    assert dmax <= PICTURE_TOL and same >= PICTURE_EQUAL_MIN

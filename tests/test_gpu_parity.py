@@ -38,7 +38,7 @@ def test_device_present():
 
 @pytest.mark.parametrize("kernel", [GENERIC, LDS, RUNS])
 def test_golden_vectors(golden_dir, kernel):
-    files = sorted(f for f in glob.glob(os.path.join(golden_dir, "*.npz")) if "frontend" not in f and "hough" not in f)
+    files = sorted(f for f in glob.glob(os.path.join(golden_dir, "*.npz")) if "frontend" not in f and "hough" not in f and "fft_" not in f)
     assert len(files) >= 9
     for f in files:
         d, b = load(f)

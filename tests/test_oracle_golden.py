@@ -18,7 +18,7 @@ def load(path):
 
 
 def sweep_files(golden_dir):
-    return sorted(f for f in glob.glob(os.path.join(golden_dir, "*.npz")) if "frontend" not in f and "hough" not in f)
+    return sorted(f for f in glob.glob(os.path.join(golden_dir, "*.npz")) if "frontend" not in f and "hough" not in f and "fft_" not in f)
 
 
 def test_golden_present(golden_dir):

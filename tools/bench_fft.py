@@ -1,0 +1,49 @@
+"""FFT path (BASELINE config 5) measurement: magnitude_log pictures of a batch of 4096x4096 (and
+2480x3508) scans resident in HBM through omr_fft_image_batch_device, beside the numpy oracle on the host
+(double-precision pocketfft + the float32 picture chain); agreement of the pictures is reported.
+Usage: python tools/bench_fft.py [batch] [reps]"""
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "omr-img-corrector_amd"))
+import numpy as np
+import torch
+
+from oics import fft, synth
+from oracle import oracle_fft as offt
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+REPS = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+dev = torch.device("cuda:0")
+out = {}
+for name, rows, cols in (("C5 4096x4096", 4096, 4096), ("A4 2480x3508", 3508, 2480)):
+    cards = [synth.make_card(rows, cols, 3 + i)[0] for i in range(2)]
+    d = torch.from_numpy(np.stack([cards[i % 2] for i in range(B)])).to(dev)
+    o = torch.zeros((B, rows, cols), dtype=torch.uint8, device=dev)
+    fft.fft_image_batch_device(d.data_ptr(), 2, rows * cols, rows, cols, cols, o.data_ptr())  # warm-up
+    ts = []
+    for _ in range(REPS):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        fft.fft_image_batch_device(d.data_ptr(), B, rows * cols, rows, cols, cols, o.data_ptr())
+        torch.cuda.synchronize()
+        ts.append(time.perf_counter() - t0)
+    t0 = time.perf_counter()
+    exp = offt.get_fft_image(cards[0])[1]
+    t_cpu = time.perf_counter() - t0
+    got = o[0].cpu().numpy()
+    dlt = np.abs(got.astype(np.int16) - exp.astype(np.int16))
+    px = rows * cols
+    # algorithmic bytes per scan: u8 in, complex f32 spectrum written and read by each of the two 1-D
+    # passes, |F| float32 out and in, two 8-bit pictures out (transposes and the log plane are overhead)
+    alg = px * (1 + 8 * 4 + 4 * 2 + 2)
+    out[name] = {"batch": B, "scans_per_s": B / min(ts), "ms_per_scan": min(ts) / B * 1e3,
+                 "algorithmic_bytes_per_scan": alg, "algorithmic_GBps": alg * B / min(ts) / 1e9,
+                 "cpu_oracle_scans_per_s_numpy": 1.0 / t_cpu,
+                 "picture_max_abs_diff": int(dlt.max()), "picture_identical_fraction": float((dlt == 0).mean())}
+    del d, o
+print(json.dumps(out))
