@@ -3,7 +3,7 @@
 //
 // The reference transforms the scan at its own size (no padding to a fast size), so lengths like
 // 2480 = 2^4 * 5 * 31 or 3508 = 2^2 * 877 must work: a line is transformed entirely inside LDS, by a
-// radix-2 Stockham FFT when its length is a power of two and by Bluestein's chirp-z (two power-of-two
+// radix-4 Stockham FFT when its length is a power of two and by Bluestein's chirp-z (two power-of-two
 // FFTs of length m >= 2n - 1 and three pointwise products) otherwise.  Twiddles and chirps are
 // tabulated by the host in double precision.  The 2-D transform is rows -> transpose -> rows ->
 // transpose; float32 throughout (the reference's dft is CV_32F), built without FMA contraction.
@@ -21,22 +21,44 @@ __device__ __forceinline__ cfloat cmul(const cfloat a, const cfloat b)
 
 #define FFT_THREADS 512
 
-// forward FFT of length m = 2^log2m, Stockham autosort, radix 2: ping-pong between `in` and `out`;
-// returns the buffer that holds the result (natural order)
+// forward FFT of length m = 2^log2m, Stockham autosort: one radix-2 stage when log2m is odd, then
+// radix-4 stages (half the barriers and LDS round trips of radix 2); ping-pong between `in` and
+// `out`, returns the buffer that holds the result (natural order).  W: m twiddles exp(-2 pi i t / m).
 __device__ cfloat *fft_forward_lds(cfloat *in, cfloat *out, const int m, const int log2m,
                                    const cfloat *__restrict__ W, const int tid)
 {
-    const int half = m >> 1;
-    for (int s = 0; s < log2m; s++) {
-        const int Ns = 1 << s;
+    int s = 0;
+    if (log2m & 1) {  // Ns = 1: no twiddles
+        const int half = m >> 1;
         __syncthreads();
         for (int j = tid; j < half; j += FFT_THREADS) {
+            const cfloat u0 = in[j], u1 = in[j + half];
+            out[2 * j] = cfloat{u0.x + u1.x, u0.y + u1.y};
+            out[2 * j + 1] = cfloat{u0.x - u1.x, u0.y - u1.y};
+        }
+        cfloat *t = in;
+        in = out;
+        out = t;
+        s = 1;
+    }
+    const int quarter = m >> 2;
+    for (; s < log2m; s += 2) {
+        const int Ns = 1 << s;
+        __syncthreads();
+        for (int j = tid; j < quarter; j += FFT_THREADS) {
             const int k = j & (Ns - 1);
+            const int tw = k << (log2m - 2 - s);  // exp(-2 pi i k / (4 Ns)) = W[tw]
             const cfloat u0 = in[j];
-            const cfloat u1 = cmul(in[j + half], W[k << (log2m - 1 - s)]);  // exp(-2 pi i k / (2 Ns))
-            const int j0 = ((j - k) << 1) + k;
-            out[j0] = cfloat{u0.x + u1.x, u0.y + u1.y};
-            out[j0 + Ns] = cfloat{u0.x - u1.x, u0.y - u1.y};
+            const cfloat u1 = cmul(in[j + quarter], W[tw]);
+            const cfloat u2 = cmul(in[j + 2 * quarter], W[2 * tw]);
+            const cfloat u3 = cmul(in[j + 3 * quarter], W[3 * tw]);
+            const cfloat a{u0.x + u2.x, u0.y + u2.y}, b{u0.x - u2.x, u0.y - u2.y};
+            const cfloat c{u1.x + u3.x, u1.y + u3.y}, d{u1.x - u3.x, u1.y - u3.y};
+            const int j0 = ((j - k) << 2) + k;
+            out[j0] = cfloat{a.x + c.x, a.y + c.y};
+            out[j0 + Ns] = cfloat{b.x + d.y, b.y - d.x};      // b - i d
+            out[j0 + 2 * Ns] = cfloat{a.x - c.x, a.y - c.y};
+            out[j0 + 3 * Ns] = cfloat{b.x - d.y, b.y + d.x};  // b + i d
         }
         cfloat *t = in;
         in = out;
@@ -129,19 +151,9 @@ __device__ __forceinline__ float key2f(uint32_t k)
     return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
 }
 
-__global__ void spec_reset_kernel(uint32_t *mm)
-{
-    mm[0] = mm[2] = 0xffffffffu;
-    mm[1] = mm[3] = 0u;
-}
-
-hipError_t launch_spec_reset(uint32_t *d_minmax, hipStream_t s)
-{
-    hipLaunchKernelGGL(spec_reset_kernel, dim3(1), dim3(1), 0, s, d_minmax);
-    return hipGetLastError();
-}
-
-__device__ __forceinline__ void block_minmax(float lo, float hi, uint32_t *mm)
+// per-block extrema go to part[2 * block .. +1]; minmax_final_kernel folds them (thousands of atomics
+// on one address would serialise in L2 and cost more than the pass itself)
+__device__ __forceinline__ void block_minmax(float lo, float hi, float *part, int block)
 {
     __shared__ float s_lo[4], s_hi[4];
     for (int off = 32; off > 0; off >>= 1) {
@@ -158,39 +170,69 @@ __device__ __forceinline__ void block_minmax(float lo, float hi, uint32_t *mm)
             lo = fminf(lo, s_lo[w]);
             hi = fmaxf(hi, s_hi[w]);
         }
-        atomicMin(mm, f2key(lo));
-        atomicMax(mm + 1, f2key(hi));
+        part[2 * block] = lo;
+        part[2 * block + 1] = hi;
     }
 }
 
-// out(r, c) = |F(sr, sc)|: quadrants of cx x cy swapped diagonally, an odd last row / column untouched
+__global__ __launch_bounds__(1024) void minmax_final_kernel(const float *__restrict__ part, int n, uint32_t *mm)
+{
+    __shared__ float s_lo[16], s_hi[16];
+    float lo = __builtin_inff(), hi = -__builtin_inff();
+    for (int i = threadIdx.x; i < n; i += 1024) {
+        lo = fminf(lo, part[2 * i]);
+        hi = fmaxf(hi, part[2 * i + 1]);
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        lo = fminf(lo, __shfl_down(lo, off));
+        hi = fmaxf(hi, __shfl_down(hi, off));
+    }
+    if ((threadIdx.x & 63) == 0) {
+        s_lo[threadIdx.x >> 6] = lo;
+        s_hi[threadIdx.x >> 6] = hi;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 16; w++) {
+            lo = fminf(lo, s_lo[w]);
+            hi = fmaxf(hi, s_hi[w]);
+        }
+        mm[0] = f2key(lo);
+        mm[1] = f2key(hi);
+    }
+}
+
+// out(r, c) = |F(sr, sc)|: quadrants of cx x cy swapped diagonally, an odd last row / column untouched.
+// Block = 1024 consecutive pixels of one row (4 per thread), so source and destination are both runs.
 __global__ __launch_bounds__(256) void spec_magnitude_kernel(const cfloat *__restrict__ F, int rows, int cols,
-                                                             float *__restrict__ mag, uint32_t *__restrict__ mm)
+                                                             float *__restrict__ mag, float *__restrict__ part)
 {
     const int cx = cols / 2, cy = rows / 2;
-    const int64_t total = (int64_t)rows * cols;
+    const int r = blockIdx.y;
+    const int sr = r < 2 * cy ? (r < cy ? r + cy : r - cy) : r;
     float lo = __builtin_inff(), hi = -__builtin_inff();
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-        const int r = (int)(i / cols), c = (int)(i - (int64_t)r * cols);
-        int sr = r, sc = c;
-        if (r < 2 * cy && c < 2 * cx) {
-            sr = r < cy ? r + cy : r - cy;
-            sc = c < cx ? c + cx : c - cx;
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        const int c = blockIdx.x * 1024 + u * 256 + threadIdx.x;
+        if (c < cols) {
+            const int sc = (r < 2 * cy && c < 2 * cx) ? (c < cx ? c + cx : c - cx) : c;
+            const int srr = (c < 2 * cx) ? sr : r;  // the odd last column is outside every quadrant
+            const cfloat v = F[(int64_t)srr * cols + sc];
+            const float m = sqrtf(v.x * v.x + v.y * v.y);
+            mag[(int64_t)r * cols + c] = m;
+            lo = fminf(lo, m);
+            hi = fmaxf(hi, m);
         }
-        const cfloat v = F[(int64_t)sr * cols + sc];
-        const float m = sqrtf(v.x * v.x + v.y * v.y);
-        mag[i] = m;
-        lo = fminf(lo, m);
-        hi = fmaxf(hi, m);
     }
-    block_minmax(lo, hi, mm);
+    block_minmax(lo, hi, part, blockIdx.y * gridDim.x + blockIdx.x);
 }
 
-hipError_t launch_spec_magnitude(const cfloat *d_F, int rows, int cols, float *d_mag, uint32_t *d_minmax, hipStream_t s)
+hipError_t launch_spec_magnitude(const cfloat *d_F, int rows, int cols, float *d_mag, float *d_part, uint32_t *d_minmax,
+                                 hipStream_t s)
 {
-    const int64_t total = (int64_t)rows * cols;
-    const int blocks = (int)((total + 1023) / 1024 < 8192 ? (total + 1023) / 1024 : 8192);
-    hipLaunchKernelGGL(spec_magnitude_kernel, dim3(blocks > 0 ? blocks : 1), dim3(256), 0, s, d_F, rows, cols, d_mag, d_minmax);
+    const dim3 grid((cols + 1023) / 1024, rows);
+    hipLaunchKernelGGL(spec_magnitude_kernel, grid, dim3(256), 0, s, d_F, rows, cols, d_mag, d_part);
+    hipLaunchKernelGGL(minmax_final_kernel, dim3(1), dim3(1024), 0, s, d_part, (int)(grid.x * grid.y), d_minmax);
     return hipGetLastError();
 }
 
@@ -198,7 +240,7 @@ hipError_t launch_spec_magnitude(const cfloat *d_F, int rows, int cols, float *d
 __global__ __launch_bounds__(256) void spec_normalise_kernel(const float *__restrict__ mag, int64_t total,
                                                              const uint32_t *__restrict__ mm_in,
                                                              uint8_t *__restrict__ mag_u8, float *__restrict__ lg,
-                                                             uint32_t *__restrict__ mm_out)
+                                                             float *__restrict__ part)
 {
     const double mn = (double)key2f(mm_in[0]), mx = (double)key2f(mm_in[1]);
     const float beta = (float)(-mn), alpha = (float)(1.0 / (mx - mn));
@@ -214,16 +256,18 @@ __global__ __launch_bounds__(256) void spec_normalise_kernel(const float *__rest
         lo = fminf(lo, l);
         hi = fmaxf(hi, l);
     }
-    block_minmax(lo, hi, mm_out);
+    block_minmax(lo, hi, part, blockIdx.x);
 }
 
 hipError_t launch_spec_normalise(const float *d_mag, int rows, int cols, const uint32_t *d_minmax_in, uint8_t *d_mag_u8,
-                                 float *d_log, uint32_t *d_minmax_out, hipStream_t s)
+                                 float *d_log, float *d_part, uint32_t *d_minmax_out, hipStream_t s)
 {
     const int64_t total = (int64_t)rows * cols;
-    const int blocks = (int)((total + 1023) / 1024 < 8192 ? (total + 1023) / 1024 : 8192);
-    hipLaunchKernelGGL(spec_normalise_kernel, dim3(blocks > 0 ? blocks : 1), dim3(256), 0, s, d_mag, total, d_minmax_in,
-                       d_mag_u8, d_log, d_minmax_out);
+    int blocks = (int)((total + 1023) / 1024 < 8192 ? (total + 1023) / 1024 : 8192);
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(spec_normalise_kernel, dim3(blocks), dim3(256), 0, s, d_mag, total, d_minmax_in, d_mag_u8, d_log,
+                       d_part);
+    hipLaunchKernelGGL(minmax_final_kernel, dim3(1), dim3(1024), 0, s, d_part, blocks, d_minmax_out);
     return hipGetLastError();
 }
 

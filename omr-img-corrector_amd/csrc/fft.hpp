@@ -12,7 +12,7 @@ struct cfloat {
 };
 
 // One pass of 1-D transforms over `lines` lines of length n, a whole line per workgroup in LDS:
-// a radix-2 Stockham FFT when n is a power of two (m = n), else Bluestein's chirp-z through two
+// a radix-4 / radix-2 Stockham FFT when n is a power of two (m = n), else Bluestein's chirp-z through two
 // FFTs of length m = the power of two >= 2n - 1.  m <= 8192 (2 x 64 KiB of LDS).
 struct FftPass {
     const uint8_t *src_u8;  // real 8-bit input (im = 0), x = (float)v * in_scale; or NULL
@@ -21,7 +21,7 @@ struct FftPass {
     const cfloat *src_c;    // complex input, lines of n elements, packed; used when src_u8 == NULL
     cfloat *dst;            // [lines][n]
     int32_t n, m, log2m, lines;
-    const cfloat *W;        // m / 2 twiddles exp(-2 pi i t / m)
+    const cfloat *W;        // m twiddles exp(-2 pi i t / m)
     const cfloat *chirp;    // n: exp(-i pi k^2 / n); NULL for the direct transform
     const cfloat *Bf;       // m: FFT_m of the padded conjugate chirp (Bluestein)
     float out_scale;
@@ -32,15 +32,20 @@ hipError_t launch_fft_pass(const FftPass &p, hipStream_t s);
 // [rows][cols] -> [cols][rows]
 hipError_t launch_transpose_c(const cfloat *d_src, int rows, int cols, cfloat *d_dst, hipStream_t s);
 
-// d_minmax: 4 ordered-uint words {min |F|, max |F|, min log, max log}; launch_spec_reset initialises them
-hipError_t launch_spec_reset(uint32_t *d_minmax, hipStream_t s);
+// d_minmax: 4 ordered-uint words {min |F|, max |F|, min log, max log}; d_part: scratch for per-block
+// extrema, spec_part_floats(rows, cols) floats
+inline size_t spec_part_floats(int rows, int cols)
+{
+    const size_t a = (size_t)((cols + 1023) / 1024) * (size_t)rows, b = 8192;
+    return 2 * (a > b ? a : b);
+}
 // |F| of the quadrant-swapped spectrum (fft.rs:68-88, :108-110) and its min / max
-hipError_t launch_spec_magnitude(const cfloat *d_F, int rows, int cols, float *d_mag, uint32_t *d_minmax,
+hipError_t launch_spec_magnitude(const cfloat *d_F, int rows, int cols, float *d_mag, float *d_part, uint32_t *d_minmax,
                                  hipStream_t s);
 // correction(|F|) * 255 -> 8-bit "magnitude_image" (x 255 again, fft.rs:134) and log(. + 1/255) with its
 // min / max (fft.rs:113-119)
 hipError_t launch_spec_normalise(const float *d_mag, int rows, int cols, const uint32_t *d_minmax_in,
-                                 uint8_t *d_mag_u8, float *d_log, uint32_t *d_minmax_out, hipStream_t s);
+                                 uint8_t *d_mag_u8, float *d_log, float *d_part, uint32_t *d_minmax_out, hipStream_t s);
 // correction(log) -> 8-bit "magnitude_log_image" (fft.rs:136-138)
 hipError_t launch_spec_log_u8(const float *d_log, int rows, int cols, const uint32_t *d_minmax, uint8_t *d_log_u8,
                               hipStream_t s);

@@ -71,8 +71,8 @@ struct AxisTables {
         if (m > OMR_FFT_MAX_M)
             return fail(OMR_ERR_NOTIMPL, "DFT length %d needs a transform of %d points; the kernel holds at most %d in LDS", n,
                         m, OMR_FFT_MAX_M);
-        std::vector<cfloat> w((size_t)std::max(m / 2, 1));
-        for (int t = 0; t < m / 2; t++) {
+        std::vector<cfloat> w((size_t)m);
+        for (int t = 0; t < m; t++) {
             const double ang = -2.0 * kPi * (double)t / (double)m;
             w[t] = cfloat{(float)cos(ang), (float)sin(ang)};
         }
@@ -108,7 +108,7 @@ struct AxisTables {
 struct FftWork {
     int rows = 0, cols = 0;
     AxisTables ax_cols, ax_rows;  // transforms along a row (length cols) / along a column (length rows)
-    DevBuf c0, c1, mag, lg, mm;
+    DevBuf c0, c1, mag, lg, mm, part;
     int create(int r, int c, hipStream_t s)
     {
         rows = r;
@@ -122,6 +122,7 @@ struct FftWork {
         OMR_HIP(mag.alloc(sizeof(float) * px));
         OMR_HIP(lg.alloc(sizeof(float) * px));
         OMR_HIP(mm.alloc(sizeof(uint32_t) * 4));
+        OMR_HIP(part.alloc(sizeof(float) * spec_part_floats(r, c)));
         return OMR_OK;
     }
     // fft.rs:124-141 for one device-resident 8-bit scan -> the two 8-bit pictures (device, packed)
@@ -157,10 +158,9 @@ struct FftWork {
         q.out_scale = (float)(1.0 / ((double)rows * (double)cols));
         OMR_HIP(launch_fft_pass(q, s));
         OMR_HIP(launch_transpose_c(c0.as<cfloat>(), cols, rows, c1.as<cfloat>(), s));  // back to [rows][cols]
-        OMR_HIP(launch_spec_reset(mm.as<uint32_t>(), s));
-        OMR_HIP(launch_spec_magnitude(c1.as<cfloat>(), rows, cols, mag.as<float>(), mm.as<uint32_t>(), s));
+        OMR_HIP(launch_spec_magnitude(c1.as<cfloat>(), rows, cols, mag.as<float>(), part.as<float>(), mm.as<uint32_t>(), s));
         OMR_HIP(launch_spec_normalise(mag.as<float>(), rows, cols, mm.as<uint32_t>(), d_mag_u8, lg.as<float>(),
-                                      mm.as<uint32_t>() + 2, s));
+                                      part.as<float>(), mm.as<uint32_t>() + 2, s));
         OMR_HIP(launch_spec_log_u8(lg.as<float>(), rows, cols, mm.as<uint32_t>() + 2, d_log_u8, s));
         return OMR_OK;
     }

@@ -1,7 +1,7 @@
 """FFT path (BASELINE config 5) measurement: magnitude_log pictures of a batch of 4096x4096 (and
 2480x3508) scans resident in HBM through omr_fft_image_batch_device, beside the numpy oracle on the host
 (double-precision pocketfft + the float32 picture chain); agreement of the pictures is reported.
-Usage: python tools/bench_fft.py [batch] [reps]"""
+Usage: python tools/bench_fft.py [batch] [reps] [c5|a4|both]"""
 import json
 import os
 import sys
@@ -18,9 +18,12 @@ from oracle import oracle_fft as offt
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 REPS = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+WHICH = sys.argv[3] if len(sys.argv) > 3 else "both"  # c5 | a4 | both
 dev = torch.device("cuda:0")
 out = {}
 for name, rows, cols in (("C5 4096x4096", 4096, 4096), ("A4 2480x3508", 3508, 2480)):
+    if WHICH != "both" and not name.lower().startswith(WHICH):
+        continue
     cards = [synth.make_card(rows, cols, 3 + i)[0] for i in range(2)]
     d = torch.from_numpy(np.stack([cards[i % 2] for i in range(B)])).to(dev)
     o = torch.zeros((B, rows, cols), dtype=torch.uint8, device=dev)
