@@ -147,3 +147,32 @@ def test_golden_vectors(golden_dir):
             r = omr.get_result_from_edges_detection(img, mll, mlg)
             assert np.float64(r.angle).view(np.uint64) == d["omr_rs_angle_bits"] and int(r.status) == int(d["omr_rs_status"])
             assert (r.candidates.view(np.uint64) == d["omr_rs_candidate_bits"]).all(), f
+
+
+def test_entry_points_are_reentrant(oracle):
+    """The Tauri host runs correct_default on a pool of OS threads (thread_pool.rs:41-54): concurrent
+    calls into the Hough and FFT entry points must not disturb each other."""
+    import threading
+    from oics import fft
+    cards = [card(200 + 10 * k, 260 + 7 * k, 60 + k)[0] for k in range(4)]
+    exp = [(oracle.get_result_from_edges_detection(c, 40.0, 8.0)[:2], oracle.canny(c)) for c in cards]
+    pics = [fft.get_fft_image(c)[1] for c in cards]
+    errs = []
+
+    def work(k):
+        try:
+            for _ in range(3):
+                r = omr.get_result_from_edges_detection(cards[k], 40.0, 8.0)
+                assert (np.float64(r.angle).view(np.uint64) == np.float64(exp[k][0][0]).view(np.uint64)
+                        and int(r.status) == exp[k][0][1])
+                assert (hough.canny(cards[k]) == exp[k][1]).all()
+                assert (fft.get_fft_image(cards[k])[1] == pics[k]).all()
+        except Exception as e:  # noqa: BLE001
+            errs.append((k, repr(e)))
+
+    ts = [threading.Thread(target=work, args=(k,)) for k in range(4)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errs, errs
