@@ -89,10 +89,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--scans", type=int, default=4, help="scans per GPU per step")
+    ap.add_argument("--scans", type=int, default=8, help="scans per GPU per step")
     ap.add_argument("--streams", type=int, default=1,
                     help="HIP streams per GPU; the sweep kernel fills the chip by itself, so 1 keeps the "
                          "per-kernel HIP-event / rocprof durations free of cross-stream overlap")
+    ap.add_argument("--group", type=int, default=8, help="scans carried by one launch of each kernel")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="wall-clock budget of the CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -116,6 +117,8 @@ def main():
     vs = torch.zeros((B, A), dtype=torch.float64, device=dev)
     hs = torch.zeros((B, A), dtype=torch.float64, device=dev)
     batch = projection.Batch(ROWS, COLS, MAX_ANGLE, STEP, device=local_rank, n_streams=args.streams)
+    G = max(1, min(args.group, B))
+    batch.set_group(G)  # scans per kernel launch
 
     def step():
         # black_max = 127 fuses transfer_gray_image_to_thresh_binary into the bit-pack
@@ -140,13 +143,13 @@ def main():
     # a real batch job where it happens once)
     all_best = odist.gather_results(best, B * world, rank, world)
 
-    # roofline leg: duration of a scan's sweep stage from HIP events recorded on the stream the
-    # kernels are launched on, over the same K steps.  The stage is `launches` kernel launches: the
-    # run-merging kernel (both projections in one launch) plus the gather kernel when
-    # some candidates do not qualify for run-merging; the dominant kernel's mean launch time is
-    # stage / launches and one launch carries 1/launches of the scan's algorithmic bytes.
+    # roofline leg: duration of the sweep stage of a launch group (G scans) from HIP events recorded on
+    # the stream the kernels are launched on, over the same K steps.  The stage is `launches` kernel
+    # launches: the run-merging kernel (G scans, both projections, one launch) plus one gather launch
+    # per scan when some candidates do not qualify for run-merging; the dominant kernel's mean launch
+    # time is stage / launches and one launch carries G / launches scans' algorithmic bytes.
     n_runs, n_gather = batch.info()
-    launches = (1 if n_runs > 0 else 0) + (1 if n_gather > 0 else 0)
+    launches = (1 if n_runs > 0 else 0) + (G if n_gather > 0 else 0)
     batch.set_timing(True)
     for _ in range(args.steps):
         step()
@@ -155,7 +158,7 @@ def main():
     stage_ms = k_sum_ms / max(1, k_n)
     kernel_ms = stage_ms / launches
     algo_bytes_scan = float(A) * ROWS * COLS  # binarised image streamed once per candidate
-    algo_bytes = algo_bytes_scan / launches
+    algo_bytes = G * algo_bytes_scan / launches
     achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
 
     total_scans = B * world * args.steps
@@ -188,14 +191,16 @@ def main():
                                    "(reference half-open range), %d scans/GPU/step resident in HBM, "
                                    "projection-std-dev sweep (threshold fused)" % (A, B),
                        "scans_per_gpu_per_step": B, "candidates": A, "global_batch": B * world,
-                       "parallelism": "scan-sharded x%d, host-side gather" % world, "streams_per_gpu": args.streams},
+                       "parallelism": "scan-sharded x%d, host-side gather" % world, "streams_per_gpu": args.streams,
+                       "scans_per_kernel_launch": G},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          "kernel": "omr::runs_kernel (run-merging rotate+project, both projections per launch)"
                                    if n_runs > 0 else "omr::sweep_lds_kernel (gather rotate+project)",
-                         "kernel_ms": kernel_ms, "launches_per_scan": launches, "sweep_stage_ms_per_scan": stage_ms,
+                         "kernel_ms": kernel_ms, "scans_per_launch": G, "launches_per_group": launches,
+                         "sweep_stage_ms_per_scan": stage_ms / G,
                          "algorithmic_bytes_per_launch": algo_bytes, "algorithmic_bytes_per_scan": algo_bytes_scan,
-                         "scans_timed": k_n, "candidates_run_merged": n_runs, "candidates_gathered": n_gather},
+                         "launch_groups_timed": k_n, "candidates_run_merged": n_runs, "candidates_gathered": n_gather},
             "accuracy_ok": acc_ok,
             "gathered_results": int(all_best.numel()),
         }

@@ -160,6 +160,10 @@ int omr_batch_run_device(omr_batch_ctx *ctx, const uint8_t *d_scans, int64_t sca
                          int64_t step_bytes, int32_t n, int32_t black_max, int32_t *d_best_idx,
                          double *d_v_sd, double *d_h_sd);
 int omr_batch_sync(omr_batch_ctx *ctx);
+/* Scans carried by one launch of each kernel (default 1; 1..64).  Larger groups amortise the fixed
+ * cost between dependent launches (about 30 us per sweep at 2480x3508) over more work; the scratch
+ * grows accordingly (about 40 MB per scan of the group at 2480x3508).  Results do not change. */
+int omr_batch_set_group(omr_batch_ctx *ctx, int32_t scans_per_launch);
 /* Sum over scans of the sweep-stage duration (ms; HIP events on the launch stream around the
  * sweep kernels of a scan: one run-merging launch (row pass and column pass) plus one gather
  * launch when some candidates do not qualify) and the number of scans timed since the last call

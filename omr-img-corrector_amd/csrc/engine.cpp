@@ -215,7 +215,7 @@ int SweepTables::build_runs()
     for (int a = 0; a < A; a++) idx[a] = a;
     OMR_HIP(hipMemcpy(all.p, idx.data(), sizeof(int32_t) * (size_t)A, hipMemcpyHostToDevice));
     RunPass ph{z0.as<uint32_t>(), rows, dims.wpr, xy0.as<int2_t>(), adelta.as<int32_t>(), bdelta.as<int32_t>(),
-               rows, cols, NWh, tabsH.as<RunTab>(), metaH.as<RunMeta>(), blkH.as<RunBlk>(), hp.as<uint16_t>(), Gh, 0};
+               rows, cols, NWh, tabsH.as<RunTab>(), metaH.as<RunMeta>(), blkH.as<RunBlk>(), hp.as<uint16_t>(), Gh, 0, 1, A};
     OMR_HIP(launch_runs(ph, all.as<int32_t>(), A, gd.as<int32_t>(), vp.as<uint32_t>(), nullptr));
     std::vector<int32_t> g((size_t)A);
     std::vector<RunMeta> mh((size_t)A * NWh);
@@ -248,29 +248,33 @@ int SweepTables::build_runs()
     return OMR_OK;
 }
 
-int SweepScratch::create(const SweepTables &t)
+int SweepScratch::create(const SweepTables &t, int scans_per_launch)
 {
     const SweepDims &d = t.dims;
+    const size_t Z = (size_t)(scans_per_launch > 0 ? scans_per_launch : 1);
+    zmax = (int)Z;
     if (t.runs_built && t.n_runs > 0) {
-        OMR_HIP(hpart.alloc(sizeof(uint16_t) * (size_t)d.A * t.Gh * d.rows));
+        OMR_HIP(hpart.alloc(sizeof(uint16_t) * Z * (size_t)d.A * t.Gh * d.rows));
         OMR_HIP(guard.alloc(sizeof(int32_t) * (size_t)d.A));
     }
-    OMR_HIP(bits.alloc(sizeof(uint32_t) * (size_t)d.rows * d.wpr));
-    OMR_HIP(vproj.alloc(sizeof(uint32_t) * (size_t)d.A * d.cols));
-    OMR_HIP(hproj.alloc(sizeof(uint32_t) * (size_t)d.A * d.rows));
-    OMR_HIP(vsd.alloc(sizeof(double) * (size_t)d.A));
-    OMR_HIP(hsd.alloc(sizeof(double) * (size_t)d.A));
-    OMR_HIP(best.alloc(sizeof(int32_t)));
+    OMR_HIP(bits.alloc(sizeof(uint32_t) * Z * (size_t)d.rows * d.wpr));
+    OMR_HIP(vproj.alloc(sizeof(uint32_t) * Z * (size_t)d.A * d.cols));
+    OMR_HIP(hproj.alloc(sizeof(uint32_t) * Z * (size_t)d.A * d.rows));
+    OMR_HIP(vsd.alloc(sizeof(double) * Z * (size_t)d.A));
+    OMR_HIP(hsd.alloc(sizeof(double) * Z * (size_t)d.A));
+    OMR_HIP(best.alloc(sizeof(int32_t) * Z));
     return OMR_OK;
 }
 
 int enqueue_sweep(const SweepTables &t, SweepScratch &s, int kernel_sel, const uint8_t *d_img, int64_t step,
                   int black_max, hipStream_t stream, uint32_t *d_vproj, uint32_t *d_hproj, double *d_v_sd,
                   double *d_h_sd, int32_t *d_best, hipEvent_t ev0, hipEvent_t ev1, bool want_proj,
-                  hipStream_t post_stream, hipEvent_t ev_mid)
+                  hipStream_t post_stream, hipEvent_t ev_mid, int scans, int64_t img_stride)
 {
     const SweepDims &d = t.dims;
     if (!d_img) return fail(OMR_ERR_BADARG, "null image");
+    if (scans < 1 || scans > s.zmax) return fail(OMR_ERR_BADARG, "%d scans per launch, scratch holds %d", scans, s.zmax);
+    if (scans > 1 && (d_vproj || d_hproj)) return fail(OMR_ERR_BADARG, "projections are returned for single-scan launches");
     if (step < d.cols) return fail(OMR_ERR_BADARG, "step_bytes %lld < cols %d", (long long)step, d.cols);
     // which kernels sweep which candidates
     bool use_runs = false, gather_lds = t.lds_ok;
@@ -298,24 +302,27 @@ int enqueue_sweep(const SweepTables &t, SweepScratch &s, int kernel_sel, const u
     // The gather kernels accumulate with integer atomics -> vproj / hproj start at 0 when any
     // candidate is gathered; the run-merging kernel overwrites its candidates' rows.
     if (n_g > 0) {
-        OMR_HIP(hipMemsetAsync(vp, 0, sizeof(uint32_t) * (size_t)d.A * d.cols, stream));
-        OMR_HIP(hipMemsetAsync(hp, 0, sizeof(uint32_t) * (size_t)d.A * d.rows, stream));
+        OMR_HIP(hipMemsetAsync(vp, 0, sizeof(uint32_t) * (size_t)scans * d.A * d.cols, stream));
+        OMR_HIP(hipMemsetAsync(hp, 0, sizeof(uint32_t) * (size_t)scans * d.A * d.rows, stream));
     }
-    OMR_HIP(launch_pack_bits(d_img, step, d.rows, d.cols, black_max, s.bits.as<uint32_t>(), d.wpr, stream));
+    OMR_HIP(launch_pack_bits(d_img, step, d.rows, d.cols, black_max, s.bits.as<uint32_t>(), d.wpr, stream, scans,
+                             img_stride));
     if (ev0) OMR_HIP(hipEventRecord(ev0, stream));
     if (use_runs) {
         RunPass ph{s.bits.as<uint32_t>(), d.rows, d.wpr, t.xy0.as<int2_t>(), t.adelta.as<int32_t>(),
                    t.bdelta.as<int32_t>(), d.rows, d.cols, t.NWh, t.tabsH.as<RunTab>(), t.metaH.as<RunMeta>(),
-                   t.blkH.as<RunBlk>(), s.hpart.as<uint16_t>(), t.Gh, 0};
+                   t.blkH.as<RunBlk>(), s.hpart.as<uint16_t>(), t.Gh, 0, scans, d.A};
         OMR_HIP(launch_runs(ph, t.list_runs.as<int32_t>(), t.n_runs, s.guard.as<int32_t>(), vp, stream));
     }
-    if (n_g > 0) {
+    for (int z = 0; z < scans && n_g > 0; z++) {  // the gather kernels take one scan per launch
+        const uint32_t *bz = s.bits.as<uint32_t>() + (size_t)z * d.rows * d.wpr;
+        uint32_t *vz = vp + (size_t)z * d.A * d.cols, *hz = hp + (size_t)z * d.A * d.rows;
         if (gather_lds)
-            OMR_HIP(launch_sweep_lds(s.bits.as<uint32_t>(), d, t.adelta.as<int32_t>(), t.bdelta.as<int32_t>(),
-                                     t.xy0.as<int2_t>(), t.tiles.as<LdsTile>(), glist, n_g, vp, hp, stream));
+            OMR_HIP(launch_sweep_lds(bz, d, t.adelta.as<int32_t>(), t.bdelta.as<int32_t>(), t.xy0.as<int2_t>(),
+                                     t.tiles.as<LdsTile>(), glist, n_g, vz, hz, stream));
         else
-            OMR_HIP(launch_sweep_generic(s.bits.as<uint32_t>(), d, t.adelta.as<int32_t>(), t.bdelta.as<int32_t>(),
-                                         t.xy0.as<int2_t>(), glist, n_g, vp, hp, stream));
+            OMR_HIP(launch_sweep_generic(bz, d, t.adelta.as<int32_t>(), t.bdelta.as<int32_t>(), t.xy0.as<int2_t>(), glist,
+                                         n_g, vz, hz, stream));
     }
     if (ev1) OMR_HIP(hipEventRecord(ev1, stream));
     if (post_stream && ev_mid) {
@@ -325,9 +332,10 @@ int enqueue_sweep(const SweepTables &t, SweepScratch &s, int kernel_sel, const u
         stream = post_stream;
     }
     if (use_runs)  // row counts of the run-merged candidates: u16 partials per word group -> hproj
-        OMR_HIP(launch_fold_parts(s.hpart.as<uint16_t>(), t.Gh, d.rows, t.list_runs.as<int32_t>(), t.n_runs, hp, stream));
-    OMR_HIP(launch_stddev(vp, hp, d, vs, hs, stream));
-    if (d_best) OMR_HIP(launch_argmax_path1(vs, hs, d.A, d_best, stream));
+        OMR_HIP(launch_fold_parts(s.hpart.as<uint16_t>(), t.Gh, d.rows, t.list_runs.as<int32_t>(), t.n_runs, hp, stream,
+                                  scans, d.A));
+    OMR_HIP(launch_stddev(vp, hp, d, vs, hs, stream, scans));
+    if (d_best) OMR_HIP(launch_argmax_path1(vs, hs, d.A, d_best, stream, scans));
     return OMR_OK;
 }
 
@@ -634,8 +642,9 @@ int omr_batch_run_device(omr_batch_ctx *ctx, const uint8_t *d_scans, int64_t sca
     OMR_HIP(hipSetDevice(ctx->tables.device));
     const int S = (int)ctx->streams.size();
     const int A = ctx->tables.dims.A;
-    for (int i = 0; i < n; i++) {
-        const int k = i % S;
+    for (int i = 0, launch = 0; i < n; launch++) {
+        const int z = std::min(ctx->group, n - i);  // scans of this launch
+        const int k = launch % S;
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (ctx->timing) {
             if (ctx->events_used == ctx->events.size()) {
@@ -656,14 +665,32 @@ int omr_batch_run_device(omr_batch_ctx *ctx, const uint8_t *d_scans, int64_t sca
                                step_bytes, black_max, ctx->streams[k], nullptr, nullptr,
                                d_v_sd ? d_v_sd + (size_t)i * A : nullptr, d_h_sd ? d_h_sd + (size_t)i * A : nullptr,
                                d_best_idx ? d_best_idx + i : nullptr, e0, e1, false, ctx->post_streams[k],
-                               ctx->ev_mid[set]);
+                               ctx->ev_mid[set], z, scan_stride);
         if (!rc) {
             if (hipEventRecord(ctx->ev_post[set], ctx->post_streams[k]) != hipSuccess)
                 return fail(OMR_ERR_GPU, "hipEventRecord failed");
             ctx->post_pending[set] = 1;
         }
         if (rc) return rc;
+        i += z;
     }
+    return OMR_OK;
+}
+
+int omr_batch_set_group(omr_batch_ctx *ctx, int32_t scans_per_launch)
+{
+    if (!ctx || scans_per_launch < 1 || scans_per_launch > 64) return fail(OMR_ERR_BADARG, "scans per launch must be 1..64");
+    int rc = omr_batch_sync(ctx);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    OMR_HIP(hipSetDevice(ctx->tables.device));
+    for (auto &sc : ctx->scratch) {
+        std::unique_ptr<SweepScratch> fresh(new SweepScratch);
+        sc.reset();  // release before allocating the larger set
+        if ((rc = fresh->create(ctx->tables, scans_per_launch))) return rc;
+        sc = std::move(fresh);
+    }
+    ctx->group = scans_per_launch;
     return OMR_OK;
 }
 

@@ -68,16 +68,18 @@ struct SweepTables {
 struct SweepScratch {
     DevBuf bits, vproj, hproj, vsd, hsd, best;
     DevBuf hpart, guard;  // run-merging scratch: u16 row-count partials per word group
-    int create(const SweepTables &t);
+    int zmax = 1;         // scans a launch may carry (every buffer above holds that many result sets)
+    int create(const SweepTables &t, int scans_per_launch = 1);
 };
 
 enum KernelSel { KERNEL_AUTO = 0, KERNEL_GENERIC = 1, KERNEL_LDS = 2, KERNEL_RUNS = 3 };
 
-// Enqueue pack -> sweep -> std-dev -> arg-max for one device-resident scan.
+// Enqueue pack -> sweep -> std-dev -> arg-max for `scans` device-resident scans (img_stride bytes apart)
+// in one launch of each kernel; scores / best index of scan z land at d_v_sd + z * A, d_best + z.
 int enqueue_sweep(const SweepTables &t, SweepScratch &s, int kernel_sel, const uint8_t *d_img, int64_t step,
                   int black_max, hipStream_t stream, uint32_t *d_vproj, uint32_t *d_hproj, double *d_v_sd,
                   double *d_h_sd, int32_t *d_best, hipEvent_t ev0, hipEvent_t ev1, bool want_proj = false,
-                  hipStream_t post_stream = nullptr, hipEvent_t ev_mid = nullptr);
+                  hipStream_t post_stream = nullptr, hipEvent_t ev_mid = nullptr, int scans = 1, int64_t img_stride = 0);
 
 }  // namespace omr
 
@@ -107,6 +109,7 @@ struct omr_batch_ctx {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
     size_t events_used = 0;
     bool timing = false;
+    int group = 1;  // scans per kernel launch (omr_batch_set_group)
     std::mutex mu;
     ~omr_batch_ctx();
 };

@@ -35,8 +35,10 @@ __device__ __forceinline__ int write_lane(int vreg, int value, int lane)
 // threshold(127,255,BINARY) leaves 0 exactly where gray <= 127, and the projections count == 0.
 __global__ __launch_bounds__(256) void pack_bits_kernel(const uint8_t *__restrict__ img, int64_t step,
                                                         int rows, int cols, int black_max,
-                                                        uint32_t *__restrict__ bits, int wpr)
+                                                        uint32_t *__restrict__ bits, int wpr, int64_t img_stride)
 {
+    img += (int64_t)blockIdx.z * img_stride;  // blockIdx.z = scan of the launch
+    bits += (int64_t)blockIdx.z * rows * wpr;
     const int y = blockIdx.y;
     const int x = blockIdx.x * 256 + threadIdx.x;
     bool black = false;
@@ -62,8 +64,10 @@ __device__ __forceinline__ uint32_t bytes_lt_nibble(uint32_t x, uint32_t n_rep)
 
 __global__ __launch_bounds__(256) void pack_bits16_kernel(const uint8_t *__restrict__ img, int64_t step, int rows,
                                                           int cols, int black_max, uint32_t *__restrict__ bits,
-                                                          int wpr)
+                                                          int wpr, int64_t img_stride)
 {
+    img += (int64_t)blockIdx.z * img_stride;  // blockIdx.z = scan of the launch
+    bits += (int64_t)blockIdx.z * rows * wpr;
     const int y = blockIdx.y;
     const int q = blockIdx.x * 256 + threadIdx.x;  // 16-pixel group of this lane
     const int x0 = q * 16;
@@ -82,15 +86,18 @@ __global__ __launch_bounds__(256) void pack_bits16_kernel(const uint8_t *__restr
 }
 
 hipError_t launch_pack_bits(const uint8_t *d_img, int64_t step, int rows, int cols, int black_max,
-                            uint32_t *d_bits, int wpr, hipStream_t s)
+                            uint32_t *d_bits, int wpr, hipStream_t s, int scans, int64_t img_stride)
 {
-    if (black_max >= 0 && black_max < 128 && (step & 15) == 0 && ((uintptr_t)d_img & 15) == 0) {
-        dim3 grid((wpr * 2 + 255) / 256, rows);
-        hipLaunchKernelGGL(pack_bits16_kernel, grid, dim3(256), 0, s, d_img, step, rows, cols, black_max, d_bits, wpr);
+    if (black_max >= 0 && black_max < 128 && (step & 15) == 0 && ((uintptr_t)d_img & 15) == 0 &&
+        (scans == 1 || (img_stride & 15) == 0)) {
+        dim3 grid((wpr * 2 + 255) / 256, rows, scans);
+        hipLaunchKernelGGL(pack_bits16_kernel, grid, dim3(256), 0, s, d_img, step, rows, cols, black_max, d_bits, wpr,
+                           img_stride);
         return hipGetLastError();
     }
-    dim3 grid((wpr * 32 + 255) / 256, rows);
-    hipLaunchKernelGGL(pack_bits_kernel, grid, dim3(256), 0, s, d_img, step, rows, cols, black_max, d_bits, wpr);
+    dim3 grid((wpr * 32 + 255) / 256, rows, scans);
+    hipLaunchKernelGGL(pack_bits_kernel, grid, dim3(256), 0, s, d_img, step, rows, cols, black_max, d_bits, wpr,
+                       img_stride);
     return hipGetLastError();
 }
 
@@ -379,90 +386,96 @@ hipError_t launch_sweep_lds(const uint32_t *d_bits, SweepDims d, const int32_t *
 //                                          the same number as the reference's sequential f64 sum
 //   sum  = (v[0]-mean)^2; sum = sum + (v[i]-mean)^2 for i = 1..n-1   -- STRICTLY sequential
 //   sd   = sqrt(sum / n)                -- IEEE f64 divide and sqrt (correctly rounded on gfx950)
-// One block per (candidate, axis): all threads square the deviations of a chunk into LDS, then
-// thread 0 folds the chunk in index order (a tree reduction would round differently).
-#define SD_THREADS 256
-#define SD_CHUNK 512
-
-// 4 KiB of LDS per block on purpose: the kernel is a latency chain (one dependent f64 add per
-// element) that runs on the post stream beside the next scan's sweep, whose two blocks per CU
-// leave only ~6 KiB of LDS free -- a fatter block would evict a sweep block from its CU.
-__global__ __launch_bounds__(SD_THREADS) void stddev_kernel(const uint32_t *__restrict__ vproj,
-                                                            const uint32_t *__restrict__ hproj, SweepDims d,
-                                                            double *__restrict__ v_sd, double *__restrict__ h_sd)
+// One LANE per (candidate, axis) chain: 2A chains = 2A / 64 single-wave
+// blocks.  The chains cannot be shortened (the add order is the specification), but 64 of them can
+// run side by side in one wave, every lane streaming its own row 64 elements ahead of its add
+// chain.  A sweep of 400 candidates needs 13 waves instead of 800 four-wave blocks, so the kernel no
+// longer pushes blocks of the next scan's sweep off their CUs while it waits on its add chain (it
+// runs on the post stream, concurrently with that sweep).
+#define SD_B 32  // elements per batch; three batches are in flight (the kernel runs beside the sweep,
+                 // whose table traffic owns the L1: a row load is an L2 round trip, about 1 us)
+struct SdBatch {
+    uint32_t v[SD_B];
+};
+__device__ __forceinline__ SdBatch sd_load(const uint32_t *__restrict__ p, int i, int n, bool vec)
 {
-    __shared__ double sq[SD_CHUNK];
-    __shared__ unsigned long long part[SD_THREADS / OMR_WAVE];
-    __shared__ double mean_s;
-    const int a = blockIdx.x >> 1;
-    const int axis = blockIdx.x & 1;  // 0: vertical projection (per column), 1: horizontal (per row)
-    const int n = axis ? d.rows : d.cols;
-    const uint32_t *__restrict__ p = axis ? hproj + (int64_t)a * d.rows : vproj + (int64_t)a * d.cols;
+    SdBatch b;
+    if (vec && i + SD_B <= n) {
+        const uint4 *q = (const uint4 *)(p + i);
+#pragma unroll
+        for (int k = 0; k < SD_B / 4; k++) {
+            const uint4 t = q[k];
+            b.v[4 * k] = t.x, b.v[4 * k + 1] = t.y, b.v[4 * k + 2] = t.z, b.v[4 * k + 3] = t.w;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < SD_B; k++) b.v[k] = i + k < n ? p[i + k] : 0u;
+    }
+    return b;
+}
 
-    // the integer total: every partial sum of the reference's sequential f64 loop is exact, so the
-    // total converted once is the same number
-    unsigned long long s = 0;
-    for (int i = threadIdx.x; i < n; i += SD_THREADS) s += p[i];
-    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
-    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        unsigned long long t = 0;
-        for (int w = 0; w < SD_THREADS / OMR_WAVE; w++) t += part[w];
-        mean_s = (double)t / (double)n;
+__global__ __launch_bounds__(64) void stddev_lanes_kernel(const uint32_t *__restrict__ vproj,
+                                                          const uint32_t *__restrict__ hproj, SweepDims d,
+                                                          double *__restrict__ v_sd, double *__restrict__ h_sd,
+                                                          int scans)
+{
+    // 13 waves of pure latency chain sharing SIMDs with the sweep's VALU-bound waves: ask the
+    // instruction arbiter to serve this wave first (it issues one dependent op at a time anyway)
+    __builtin_amdgcn_s_setprio(3);
+    // per scan: chains 0..A-1 are the vertical projections, A..2A-1 the horizontal ones
+    const int gid = blockIdx.x * 64 + threadIdx.x;
+    if (gid >= 2 * d.A * scans) return;
+    const int scan = gid / (2 * d.A), id = gid - scan * 2 * d.A;
+    vproj += (int64_t)scan * d.A * d.cols;
+    hproj += (int64_t)scan * d.A * d.rows;
+    v_sd += (int64_t)scan * d.A;
+    h_sd += (int64_t)scan * d.A;
+    const bool vert = id < d.A;
+    const int n = vert ? d.cols : d.rows;
+    const uint32_t *__restrict__ p = vert ? vproj + (int64_t)id * d.cols : hproj + (int64_t)(id - d.A) * d.rows;
+    const bool vec = (((uintptr_t)p) & 15u) == 0;
+    unsigned long long s = 0;  // the integer total (exact; see above)
+    {
+        SdBatch cur = sd_load(p, 0, n, vec), n1 = sd_load(p, SD_B, n, vec);
+        for (int i = 0; i < n; i += SD_B) {
+            const SdBatch n2 = sd_load(p, i + 2 * SD_B, n, vec);
+#pragma unroll
+            for (int k = 0; k < SD_B; k++) s += cur.v[k];  // zeros past the end
+            cur = n1;
+            n1 = n2;
+        }
     }
-    __syncthreads();
-    const double mean = mean_s;
+    const double mean = (double)s / (double)n;
     double acc = 0.0;  // 0.0 + (v0-mean)^2 == (v0-mean)^2 exactly
-    for (int base = 0; base < n; base += SD_CHUNK) {
-        const int m = min(SD_CHUNK, n - base);
-        for (int i = threadIdx.x; i < m; i += SD_THREADS) {
-            const double dv = (double)p[base + i] - mean;
-            sq[i] = dv * dv;
+    SdBatch cur = sd_load(p, 0, n, vec), n1 = sd_load(p, SD_B, n, vec);
+    for (int i = 0; i < n; i += SD_B) {
+        const SdBatch n2 = sd_load(p, i + 2 * SD_B, n, vec);
+        if (i + SD_B <= n) {
+#pragma unroll
+            for (int k = 0; k < SD_B; k++) {
+                const double dv = (double)cur.v[k] - mean;
+                acc = acc + dv * dv;  // strictly in index order; no contraction (-ffp-contract=off)
+            }
+        } else {
+            for (int k = 0; k < n - i; k++) {
+                const double dv = (double)cur.v[k] - mean;
+                acc = acc + dv * dv;
+            }
         }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            // the adds form one dependent chain (that order IS the specification); two batches of 16
-            // LDS reads are kept in flight so the chain runs at f64-add latency, not LDS latency
-            int i = 0;
-            double t0[16], t1[16];
-            if (m >= 16) {
-#pragma unroll
-                for (int j = 0; j < 16; j++) t0[j] = sq[j];
-            }
-            for (; i + 32 <= m; i += 32) {
-#pragma unroll
-                for (int j = 0; j < 16; j++) t1[j] = sq[i + 16 + j];
-#pragma unroll
-                for (int j = 0; j < 16; j++) acc = acc + t0[j];
-                if (i + 48 <= m) {
-#pragma unroll
-                    for (int j = 0; j < 16; j++) t0[j] = sq[i + 32 + j];
-                }
-#pragma unroll
-                for (int j = 0; j < 16; j++) acc = acc + t1[j];
-            }
-            if (i + 16 <= m) {  // t0 holds sq[i .. i+15]
-#pragma unroll
-                for (int j = 0; j < 16; j++) acc = acc + t0[j];
-                i += 16;
-            }
-            for (; i < m; i++) acc = acc + sq[i];
-        }
-        __syncthreads();
+        cur = n1;
+        n1 = n2;
     }
-    if (threadIdx.x == 0) {
-        const double sd = sqrt(acc / (double)n);
-        if (axis) h_sd[a] = sd;
-        else v_sd[a] = sd;
-    }
+    const double sd = sqrt(acc / (double)n);
+    if (vert) v_sd[id] = sd;
+    else h_sd[id - d.A] = sd;
 }
 
 hipError_t launch_stddev(const uint32_t *d_vproj, const uint32_t *d_hproj, SweepDims d, double *d_v_sd,
-                         double *d_h_sd, hipStream_t s)
+                         double *d_h_sd, hipStream_t s, int scans)
 {
-    if (d.A <= 0) return hipSuccess;
-    hipLaunchKernelGGL(stddev_kernel, dim3(2 * d.A), dim3(SD_THREADS), 0, s, d_vproj, d_hproj, d, d_v_sd, d_h_sd);
+    if (d.A <= 0 || scans <= 0) return hipSuccess;
+    hipLaunchKernelGGL(stddev_lanes_kernel, dim3((2 * d.A * scans + 63) / 64), dim3(64), 0, s, d_vproj, d_hproj, d,
+                       d_v_sd, d_h_sd, scans);
     return hipGetLastError();
 }
 
@@ -508,6 +521,9 @@ __global__ __launch_bounds__(AM_THREADS) void argmax_path1_kernel(const double *
 {
     __shared__ unsigned long long shm[AM_THREADS / OMR_WAVE];
     __shared__ unsigned shc[AM_THREADS / OMR_WAVE];
+    v += (int64_t)blockIdx.x * n;  // blockIdx.x = scan of the launch
+    h += (int64_t)blockIdx.x * n;
+    best += blockIdx.x;
     // pass 1: maxima of both score vectors
     double lv = 0.0, lh = 0.0;  // scores are >= 0
     for (int i = threadIdx.x; i < n; i += AM_THREADS) {
@@ -567,10 +583,11 @@ __global__ __launch_bounds__(AM_THREADS) void argmax_path1_kernel(const double *
     }
 }
 
-hipError_t launch_argmax_path1(const double *d_v_sd, const double *d_h_sd, int A, int32_t *d_best, hipStream_t s)
+hipError_t launch_argmax_path1(const double *d_v_sd, const double *d_h_sd, int A, int32_t *d_best, hipStream_t s,
+                               int scans)
 {
-    if (A <= 0) return hipSuccess;
-    hipLaunchKernelGGL(argmax_path1_kernel, dim3(1), dim3(AM_THREADS), 0, s, d_v_sd, d_h_sd, A, d_best);
+    if (A <= 0 || scans <= 0) return hipSuccess;
+    hipLaunchKernelGGL(argmax_path1_kernel, dim3(scans), dim3(AM_THREADS), 0, s, d_v_sd, d_h_sd, A, d_best);
     return hipGetLastError();
 }
 

@@ -25,8 +25,9 @@ struct LdsTile {
 };
 
 // u8 image -> bit image: bit (x & 31) of word [y][x >> 5] is 1 iff px <= black_max.
+// `scans` images img_stride bytes apart -> `scans` bit images, packed one after the other.
 hipError_t launch_pack_bits(const uint8_t *d_img, int64_t step, int rows, int cols, int black_max,
-                            uint32_t *d_bits, int wpr, hipStream_t s);
+                            uint32_t *d_bits, int wpr, hipStream_t s, int scans = 1, int64_t img_stride = 0);
 
 // OpenCV hal::warpAffine fixed-point tables for A inverse matrices.
 // adelta/bdelta: [A][cols]; xy0: [A][rows] (X0, Y0 incl. round_delta). *d_overflow != 0 when a
@@ -90,6 +91,8 @@ struct RunPass {  // one orientation
     uint16_t *part;       // [A][G][NR] partial counts, G = ceil(NW / OMR_RUN_K)
     int32_t G;
     int32_t dbg;          // development switches (0 in production)
+    int32_t scans;        // scans per launch (blockIdx.z): src, part and vproj hold them back to back
+    int32_t A;            // candidates of the plan (stride of part / vproj between scans)
 };
 hipError_t launch_runtab(const int32_t *d_CA, const int32_t *d_CB, int A, int NC, int NW, RunTab *d_tabs,
                          RunMeta *d_meta, RunBlk *d_blk, hipStream_t s);
@@ -97,20 +100,21 @@ hipError_t launch_runtab(const int32_t *d_CA, const int32_t *d_CB, int A, int NC
 // Row counts go to p.part (u16 partials per word group), column counts to d_vproj[a][NC] (complete,
 // plain stores).
 hipError_t launch_runs(const RunPass &p, const int32_t *d_list, int n_list, int32_t *d_guard, uint32_t *d_vproj,
-                       hipStream_t s);
+                       hipStream_t s);  // p.scans launches' worth of blocks in one grid
 // hproj[a][r] = sum of the G partial row counts, for the listed (run-merged) candidates
 // development aid: phase clocks summed by runs_kernel when OMR_RUNS_DBG=8 (see runs.hip)
 hipError_t debug_runs_stamps(unsigned long long out[8], bool reset);
 hipError_t launch_fold_parts(const uint16_t *d_part, int G, int NR, const int32_t *d_list, int n_list,
-                             uint32_t *d_proj, hipStream_t s);
+                             uint32_t *d_proj, hipStream_t s, int scans = 1, int A = 0);
 
 // calculate.rs:13-23 on the integer projections: one block per (candidate, axis).
+// `scans` result sets back to back: vproj [scans][A][cols], hproj [scans][A][rows], sd [scans][A]
 hipError_t launch_stddev(const uint32_t *d_vproj, const uint32_t *d_hproj, SweepDims d, double *d_v_sd,
-                         double *d_h_sd, hipStream_t s);
+                         double *d_h_sd, hipStream_t s, int scans = 1);
 
 // projection.rs:125-190 arg-max (lowest index on exact ties).
 hipError_t launch_argmax_path1(const double *d_v_sd, const double *d_h_sd, int A, int32_t *d_best,
-                               hipStream_t s);
+                               hipStream_t s, int scans = 1);
 
 // ---- per-image helpers -------------------------------------------------------------------
 hipError_t launch_threshold(const uint8_t *d_src, int64_t sstep, int rows, int cols, uint8_t *d_dst,

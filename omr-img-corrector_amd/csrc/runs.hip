@@ -502,8 +502,11 @@ __global__ __launch_bounds__(RUN_BAND, 4) void runs_kernel(const RunPass p, cons
         st_acc[I] += now_ - st_prev;                   \
         st_prev = now_;                                \
     }
-    const int a = __builtin_amdgcn_readfirstlane(list[blockIdx.y]);
-    const int g = blockIdx.x;
+    // grid = (scans, word groups, candidates): the blocks that share a run table (same candidate and
+    // word group, different scans) are neighbours in dispatch order, so the table comes from L2
+    const int a = __builtin_amdgcn_readfirstlane(list[blockIdx.z]);
+    const int g = blockIdx.y;
+    const int zscan = blockIdx.x;  // scan of the launch
     const int w0 = g * RUN_K;
     const int kw = min(RUN_K, p.NW - w0);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -515,7 +518,7 @@ __global__ __launch_bounds__(RUN_BAND, 4) void runs_kernel(const RunPass p, cons
     const int ca_min = bk.ca_min, ca_max = bk.ca_max, cb_min = bk.cb_min, cb_max = bk.cb_max;
     const int2_t *__restrict__ RT = p.RT + (int64_t)a * p.NR;
     const int c_first = w0 * 32;
-    uint16_t *__restrict__ out = p.part + ((int64_t)a * p.G + g) * p.NR;
+    uint16_t *__restrict__ out = p.part + (((int64_t)zscan * p.A + a) * p.G + g) * p.NR;
 
     // source bounding box of a band x word group: the map is monotone in r and in c, so the four
     // corner samples bound it.  The corner rows' (X0, Y0) are fetched one band ahead of their use.
@@ -554,7 +557,8 @@ __global__ __launch_bounds__(RUN_BAND, 4) void runs_kernel(const RunPass p, cons
     static_assert(RUN_QUADS == 5 && RUN_BAND == 512, "piece -> row uses 16-bit reciprocals of 3 and 5");
     static_assert(PIECES * (RUN_BAND / RUN_QUADS) >= RUN_WIN_ROWS, "rounds cover the window");
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        (void *)p.src, /*stride*/ 0, (int)((uint32_t)p.src_rows * (uint32_t)p.src_wpr * 4u), 0x00020000);
+        (void *)(p.src + (int64_t)zscan * p.src_rows * p.src_wpr), /*stride*/ 0,
+        (int)((uint32_t)p.src_rows * (uint32_t)p.src_wpr * 4u), 0x00020000);
     // (row, first word) of the thread's round-0 piece.  Recomputed where it is used from an opaque
     // copy of tid: cached or loop-hoisted offsets cost more registers than the kernel has, and a
     // spill reload inside the fetch sequence would wait for the loads already in flight.
@@ -682,7 +686,8 @@ __global__ __launch_bounds__(RUN_BAND, 4) void runs_kernel(const RunPass p, cons
     }
     __syncthreads();
     // column counts of this block's (up to) 256 columns over ALL rows: one plain store each
-    if (tid < RUN_K * 32 && c_first + tid < p.NC) vproj[(int64_t)a * p.NC + c_first + tid] = colacc[tid];
+    if (tid < RUN_K * 32 && c_first + tid < p.NC)
+        vproj[((int64_t)zscan * p.A + a) * p.NC + c_first + tid] = colacc[tid];
     if (stamp && tid == 0) {
         for (int i = 0; i < 5; i++) atomicAdd(&g_run_stamps[i], st_acc[i]);
         atomicAdd(&g_run_stamps[5], run_clock() - st_t0);
@@ -714,15 +719,18 @@ hipError_t launch_runs(const RunPass &p0, const int32_t *d_list, int n_list, int
     auto *kern = (p.dbg & 8) ? runs_kernel<true> : runs_kernel<false>;
     hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, RUN_LDS_BYTES);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3(p.G, n_list), dim3(RUN_BAND), RUN_LDS_BYTES, s, p, d_list, d_guard, d_vproj);
+    if (p.scans < 1) p.scans = 1;
+    hipLaunchKernelGGL(kern, dim3(p.scans, p.G, n_list), dim3(RUN_BAND), RUN_LDS_BYTES, s, p, d_list, d_guard, d_vproj);
     return hipGetLastError();
 }
 
 // proj[a][r] = sum_g part[a][g][r] for the listed candidates
 __global__ __launch_bounds__(256) void fold_parts_kernel(const uint16_t *__restrict__ part, int G, int NR,
                                                          const int32_t *__restrict__ list,
-                                                         uint32_t *__restrict__ proj)
+                                                         uint32_t *__restrict__ proj, int A)
 {
+    part += (int64_t)blockIdx.z * A * G * NR;  // blockIdx.z = scan of the launch
+    proj += (int64_t)blockIdx.z * A * NR;
     const int a = list[blockIdx.y];
     const int r = blockIdx.x * 256 + threadIdx.x;
     if (r >= NR) return;
@@ -732,11 +740,11 @@ __global__ __launch_bounds__(256) void fold_parts_kernel(const uint16_t *__restr
 }
 
 hipError_t launch_fold_parts(const uint16_t *d_part, int G, int NR, const int32_t *d_list, int n_list,
-                             uint32_t *d_proj, hipStream_t s)
+                             uint32_t *d_proj, hipStream_t s, int scans, int A)
 {
-    if (n_list <= 0) return hipSuccess;
-    hipLaunchKernelGGL(fold_parts_kernel, dim3((NR + 255) / 256, n_list), dim3(256), 0, s, d_part, G, NR, d_list,
-                       d_proj);
+    if (n_list <= 0 || scans <= 0) return hipSuccess;
+    hipLaunchKernelGGL(fold_parts_kernel, dim3((NR + 255) / 256, n_list, scans), dim3(256), 0, s, d_part, G, NR, d_list,
+                       d_proj, A);
     return hipGetLastError();
 }
 

@@ -62,6 +62,7 @@ SYMBOLS = {
     "omr_batch_run_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_void_p,
                                        C.c_void_p, C.c_void_p]),
     "omr_batch_sync": (C.c_int, [C.c_void_p]),
+    "omr_batch_set_group": (C.c_int, [C.c_void_p, C.c_int32]),
     "omr_batch_info": (C.c_int, [C.c_void_p, i32p, i32p]),
     "omr_batch_set_timing": (C.c_int, [C.c_void_p, C.c_int32]),
     "omr_batch_kernel_ms": (C.c_int, [C.c_void_p, f64p, i32p]),

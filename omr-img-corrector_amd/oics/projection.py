@@ -147,6 +147,10 @@ class Batch:
     def sync(self):
         check(lib().omr_batch_sync(self.handle))
 
+    def set_group(self, scans_per_launch):
+        """Scans carried by one launch of each kernel (amortises the launch-to-launch cost)."""
+        check(lib().omr_batch_set_group(self.handle, int(scans_per_launch)))
+
     def info(self):
         r, g = C.c_int32(), C.c_int32()
         check(lib().omr_batch_info(self.handle, C.byref(r), C.byref(g)))

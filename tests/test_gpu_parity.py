@@ -435,3 +435,33 @@ def test_device_resident_stages_match_oracle(oracle):
                             assert (got == exp).all(), (rows, cols, clip, ang, cn)
                         else:  # north_star tolerance for the bilinear warp: 1 grey level
                             assert np.abs(got.astype(int) - exp.astype(int)).max() <= 1, (rows, cols, clip, ang, cn)
+
+
+def test_batch_launch_groups_do_not_change_results(oracle):
+    """omr_batch_set_group: several scans per kernel launch (blockIdx.z) -- same bits as one per launch."""
+    import torch
+    rows, cols, n = 301, 437, 7
+    cards = [synth.make_card(rows, cols, 70 + i)[0] for i in range(n)]
+    d = torch.from_numpy(np.stack(cards)).to("cuda:0")
+    N, A = projection.candidate_count(10, 0.25)
+    res = {}
+    for group in (1, 3, 4):
+        best = torch.full((n,), -1, dtype=torch.int32, device="cuda:0")
+        vs = torch.zeros((n, A), dtype=torch.float64, device="cuda:0")
+        hs = torch.zeros((n, A), dtype=torch.float64, device="cuda:0")
+        b = projection.Batch(rows, cols, 10, 0.25, device=0, n_streams=1)
+        b.set_group(group)
+        for _ in range(2):  # twice: scratch sets are reused
+            b.run_device(d.data_ptr(), rows * cols, cols, n, 127, best.data_ptr(), vs.data_ptr(), hs.data_ptr())
+        b.sync()
+        res[group] = (best.cpu().numpy().copy(), vs.cpu().numpy().copy(), hs.cpu().numpy().copy())
+        b.close()
+    for group in (3, 4):
+        assert (res[group][0] == res[1][0]).all()
+        assert (res[group][1].view(np.uint64) == res[1][1].view(np.uint64)).all()
+        assert (res[group][2].view(np.uint64) == res[1][2].view(np.uint64)).all()
+    for i in (0, n - 1):
+        bimg = oracle.threshold_binary(cards[i])
+        _, _, evs, ehs = oracle.sweep(bimg, 10, 0.25)
+        assert (res[4][1][i].view(np.uint64) == evs.view(np.uint64)).all()
+        assert (res[4][2][i].view(np.uint64) == ehs.view(np.uint64)).all()

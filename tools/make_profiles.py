@@ -26,7 +26,7 @@ def short(name):
 
 def find(sub, pat):
     r = glob.glob(os.path.join(src, sub, "**", pat), recursive=True)
-    return r[0] if r else None
+    return max(r, key=os.path.getmtime) if r else None  # gpurun merges runs: take the newest
 
 
 def counters(sub):
@@ -69,7 +69,7 @@ with open(os.path.join(dst, tag + "_rocprofv3_kernel_stats_bench.md"), "w") as f
     f.write("\nUn-profiled bench line of the same build (`profiles/%s_bench_line.json`): **%.0f images/s**, "
             "`roofline.kernel_ms` %.4f ms (HIP events on the launch stream, mean over %d launches), `roofline.frac` %.3f, "
             "`cpu_baseline` %.2f images/s on %d cores (single thread %.3f), parity_vs_gpu %s.\n\n" % (
-                tag, line["value"], rl["kernel_ms"], rl["scans_timed"], rl["frac"], line["cpu_baseline"]["value"],
+                tag, line["value"], rl["kernel_ms"], rl["launch_groups_timed"], rl["frac"], line["cpu_baseline"]["value"],
                 line["cpu_baseline"]["cores"], line["cpu_baseline"]["single_thread_value"],
                 line["cpu_baseline"]["parity_vs_gpu"]))
     f.write("`omr::runs_kernel` is launched once per scan; its rocprof average agrees with `roofline.kernel_ms` up to the "
