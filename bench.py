@@ -204,7 +204,7 @@ def main():
             "accuracy_ok": acc_ok,
             "gathered_results": int(all_best.numel()),
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # reported at N = 1 only
             out["cpu_baseline"] = cpu_baseline(scans[0].cpu().numpy(), vs[0].cpu().numpy(), hs[0].cpu().numpy(),
                                                args.cpu_seconds)
     batch.close()
