@@ -334,7 +334,7 @@ int enqueue_sweep(const SweepTables &t, SweepScratch &s, int kernel_sel, const u
     if (use_runs)  // row counts of the run-merged candidates: u16 partials per word group -> hproj
         OMR_HIP(launch_fold_parts(s.hpart.as<uint16_t>(), t.Gh, d.rows, t.list_runs.as<int32_t>(), t.n_runs, hp, stream,
                                   scans, d.A));
-    OMR_HIP(launch_stddev(vp, hp, d, vs, hs, stream, scans));
+    OMR_HIP(launch_stddev(vp, hp, d, vs, hs, stream, scans, /*latency=*/post_stream == nullptr));
     if (d_best) OMR_HIP(launch_argmax_path1(vs, hs, d.A, d_best, stream, scans));
     return OMR_OK;
 }

@@ -386,7 +386,84 @@ hipError_t launch_sweep_lds(const uint32_t *d_bits, SweepDims d, const int32_t *
 //                                          the same number as the reference's sequential f64 sum
 //   sum  = (v[0]-mean)^2; sum = sum + (v[i]-mean)^2 for i = 1..n-1   -- STRICTLY sequential
 //   sd   = sqrt(sum / n)                -- IEEE f64 divide and sqrt (correctly rounded on gfx950)
-// One LANE per (candidate, axis) chain: 2A chains = 2A / 64 single-wave
+// Latency form, one block per (candidate, axis): all threads square the deviations of a chunk into
+// LDS, then thread 0 folds the chunk in index order (a tree reduction would round differently).
+// Used when a single scan is waited for (plan API): 40 us instead of the 170 us of the lane form.
+#define SD_THREADS 256
+#define SD_CHUNK 512
+
+__global__ __launch_bounds__(SD_THREADS) void stddev_kernel(const uint32_t *__restrict__ vproj,
+                                                            const uint32_t *__restrict__ hproj, SweepDims d,
+                                                            double *__restrict__ v_sd, double *__restrict__ h_sd)
+{
+    __shared__ double sq[SD_CHUNK];
+    __shared__ unsigned long long part[SD_THREADS / OMR_WAVE];
+    __shared__ double mean_s;
+    const int a = blockIdx.x >> 1;
+    const int axis = blockIdx.x & 1;  // 0: vertical projection (per column), 1: horizontal (per row)
+    const int n = axis ? d.rows : d.cols;
+    const uint32_t *__restrict__ p = axis ? hproj + (int64_t)a * d.rows : vproj + (int64_t)a * d.cols;
+
+    // the integer total: every partial sum of the reference's sequential f64 loop is exact, so the
+    // total converted once is the same number
+    unsigned long long s = 0;
+    for (int i = threadIdx.x; i < n; i += SD_THREADS) s += p[i];
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long t = 0;
+        for (int w = 0; w < SD_THREADS / OMR_WAVE; w++) t += part[w];
+        mean_s = (double)t / (double)n;
+    }
+    __syncthreads();
+    const double mean = mean_s;
+    double acc = 0.0;  // 0.0 + (v0-mean)^2 == (v0-mean)^2 exactly
+    for (int base = 0; base < n; base += SD_CHUNK) {
+        const int m = min(SD_CHUNK, n - base);
+        for (int i = threadIdx.x; i < m; i += SD_THREADS) {
+            const double dv = (double)p[base + i] - mean;
+            sq[i] = dv * dv;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            // the adds form one dependent chain (that order IS the specification); two batches of 16
+            // LDS reads are kept in flight so the chain runs at f64-add latency, not LDS latency
+            int i = 0;
+            double t0[16], t1[16];
+            if (m >= 16) {
+#pragma unroll
+                for (int j = 0; j < 16; j++) t0[j] = sq[j];
+            }
+            for (; i + 32 <= m; i += 32) {
+#pragma unroll
+                for (int j = 0; j < 16; j++) t1[j] = sq[i + 16 + j];
+#pragma unroll
+                for (int j = 0; j < 16; j++) acc = acc + t0[j];
+                if (i + 48 <= m) {
+#pragma unroll
+                    for (int j = 0; j < 16; j++) t0[j] = sq[i + 32 + j];
+                }
+#pragma unroll
+                for (int j = 0; j < 16; j++) acc = acc + t1[j];
+            }
+            if (i + 16 <= m) {  // t0 holds sq[i .. i+15]
+#pragma unroll
+                for (int j = 0; j < 16; j++) acc = acc + t0[j];
+                i += 16;
+            }
+            for (; i < m; i++) acc = acc + sq[i];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const double sd = sqrt(acc / (double)n);
+        if (axis) h_sd[a] = sd;
+        else v_sd[a] = sd;
+    }
+}
+
+// Throughput form.  One LANE per (candidate, axis) chain: 2A chains = 2A / 64 single-wave
 // blocks.  The chains cannot be shortened (the add order is the specification), but 64 of them can
 // run side by side in one wave, every lane streaming its own row 64 elements ahead of its add
 // chain.  A sweep of 400 candidates needs 13 waves instead of 800 four-wave blocks, so the kernel no
@@ -471,9 +548,13 @@ __global__ __launch_bounds__(64) void stddev_lanes_kernel(const uint32_t *__rest
 }
 
 hipError_t launch_stddev(const uint32_t *d_vproj, const uint32_t *d_hproj, SweepDims d, double *d_v_sd,
-                         double *d_h_sd, hipStream_t s, int scans)
+                         double *d_h_sd, hipStream_t s, int scans, bool latency)
 {
     if (d.A <= 0 || scans <= 0) return hipSuccess;
+    if (latency && scans == 1) {
+        hipLaunchKernelGGL(stddev_kernel, dim3(2 * d.A), dim3(SD_THREADS), 0, s, d_vproj, d_hproj, d, d_v_sd, d_h_sd);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(stddev_lanes_kernel, dim3((2 * d.A * scans + 63) / 64), dim3(64), 0, s, d_vproj, d_hproj, d,
                        d_v_sd, d_h_sd, scans);
     return hipGetLastError();

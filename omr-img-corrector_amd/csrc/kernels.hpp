@@ -108,9 +108,11 @@ hipError_t launch_fold_parts(const uint16_t *d_part, int G, int NR, const int32_
                              uint32_t *d_proj, hipStream_t s, int scans = 1, int A = 0);
 
 // calculate.rs:13-23 on the integer projections: one block per (candidate, axis).
-// `scans` result sets back to back: vproj [scans][A][cols], hproj [scans][A][rows], sd [scans][A]
+// `scans` result sets back to back: vproj [scans][A][cols], hproj [scans][A][rows], sd [scans][A].
+// latency: one block per chain (a single scan that is waited for) instead of one lane per chain
+// (batches, where the kernel runs beside the next sweep and must stay out of its way)
 hipError_t launch_stddev(const uint32_t *d_vproj, const uint32_t *d_hproj, SweepDims d, double *d_v_sd,
-                         double *d_h_sd, hipStream_t s, int scans = 1);
+                         double *d_h_sd, hipStream_t s, int scans = 1, bool latency = false);
 
 // projection.rs:125-190 arg-max (lowest index on exact ties).
 hipError_t launch_argmax_path1(const double *d_v_sd, const double *d_h_sd, int A, int32_t *d_best,
