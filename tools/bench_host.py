@@ -1,0 +1,25 @@
+"""End-to-end rate of the host-buffer entry point omr_sweep_batch (H2D copy of every 8.7 MB scan included,
+pageable host memory as a caller's cv::Mat would be).  Never bench.py's `value` -- that is HBM-resident by
+contract; this is the PCIe-inclusive figure DESIGN.md quotes.  Usage: python tools/bench_host.py [scans]"""
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "omr-img-corrector_amd"))
+import numpy as np
+import torch  # noqa: F401
+
+from oics import projection, synth
+
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+cards = [synth.make_card(3508, 2480, 3 + i)[0] for i in range(4)]
+scans = [cards[i % 4].copy() for i in range(N)]
+projection.sweep_batch(scans[:4], 10, 0.05, n_devices=1)  # warm-up (plan creation)
+t0 = time.perf_counter()
+best, ang, _, _ = projection.sweep_batch(scans, 10, 0.05, n_devices=1)
+dt = time.perf_counter() - t0
+print(json.dumps({"entry_point": "omr_sweep_batch (host images, 1 GPU)", "scans": N, "images_per_s": N / dt,
+                  "seconds": dt, "note": "includes plan creation per call and one pageable H2D copy per scan"}))
