@@ -3,7 +3,7 @@
 //
 // The reference transforms the scan at its own size (no padding to a fast size), so lengths like
 // 2480 = 2^4 * 5 * 31 or 3508 = 2^2 * 877 must work: a line is transformed entirely inside LDS, by a
-// radix-4 Stockham FFT when its length is a power of two and by Bluestein's chirp-z (two power-of-two
+// radix-8 Stockham FFT when its length is a power of two and by Bluestein's chirp-z (two power-of-two
 // FFTs of length m >= 2n - 1 and three pointwise products) otherwise.  Twiddles and chirps are
 // tabulated by the host in double precision.  The 2-D transform is rows -> transpose -> rows ->
 // transpose; float32 throughout (the reference's dft is CV_32F), built without FMA contraction.
@@ -21,44 +21,79 @@ __device__ __forceinline__ cfloat cmul(const cfloat a, const cfloat b)
 
 #define FFT_THREADS 512
 
-// forward FFT of length m = 2^log2m, Stockham autosort: one radix-2 stage when log2m is odd, then
-// radix-4 stages (half the barriers and LDS round trips of radix 2); ping-pong between `in` and
-// `out`, returns the buffer that holds the result (natural order).  W: m twiddles exp(-2 pi i t / m).
+// forward FFT of length m = 2^log2m, Stockham autosort.  Stages are radix 8 (three radix-2 levels in
+// registers per LDS round trip) with one leading radix-2 or radix-4 stage when log2m is not a multiple of
+// three; ping-pong between `in` and `out`, returns the buffer that holds the result (natural order).
+// W: m twiddles exp(-2 pi i t / m).
+__device__ __forceinline__ cfloat cadd(const cfloat a, const cfloat b) { return cfloat{a.x + b.x, a.y + b.y}; }
+__device__ __forceinline__ cfloat csub(const cfloat a, const cfloat b) { return cfloat{a.x - b.x, a.y - b.y}; }
+__device__ __forceinline__ cfloat cmul_mi(const cfloat a) { return cfloat{a.y, -a.x}; }  // a * (-i)
+
 __device__ cfloat *fft_forward_lds(cfloat *in, cfloat *out, const int m, const int log2m,
                                    const cfloat *__restrict__ W, const int tid)
 {
     int s = 0;
-    if (log2m & 1) {  // Ns = 1: no twiddles
+    const int lead = log2m % 3;
+    if (lead == 1) {  // radix 2, Ns = 1: no twiddles
         const int half = m >> 1;
         __syncthreads();
         for (int j = tid; j < half; j += FFT_THREADS) {
             const cfloat u0 = in[j], u1 = in[j + half];
-            out[2 * j] = cfloat{u0.x + u1.x, u0.y + u1.y};
-            out[2 * j + 1] = cfloat{u0.x - u1.x, u0.y - u1.y};
+            out[2 * j] = cadd(u0, u1);
+            out[2 * j + 1] = csub(u0, u1);
         }
         cfloat *t = in;
         in = out;
         out = t;
         s = 1;
-    }
-    const int quarter = m >> 2;
-    for (; s < log2m; s += 2) {
-        const int Ns = 1 << s;
+    } else if (lead == 2) {  // radix 4, Ns = 1: no twiddles
+        const int quarter = m >> 2;
         __syncthreads();
         for (int j = tid; j < quarter; j += FFT_THREADS) {
+            const cfloat u0 = in[j], u1 = in[j + quarter], u2 = in[j + 2 * quarter], u3 = in[j + 3 * quarter];
+            const cfloat a = cadd(u0, u2), b = csub(u0, u2), c = cadd(u1, u3), d = cmul_mi(csub(u1, u3));
+            out[4 * j] = cadd(a, c);
+            out[4 * j + 1] = cadd(b, d);
+            out[4 * j + 2] = csub(a, c);
+            out[4 * j + 3] = csub(b, d);
+        }
+        cfloat *t = in;
+        in = out;
+        out = t;
+        s = 2;
+    }
+    const int eighth = m >> 3;
+    const float r2 = 0.70710678118654752440f;
+    for (; s < log2m; s += 3) {
+        const int Ns = 1 << s;
+        __syncthreads();
+        for (int j = tid; j < eighth; j += FFT_THREADS) {
             const int k = j & (Ns - 1);
-            const int tw = k << (log2m - 2 - s);  // exp(-2 pi i k / (4 Ns)) = W[tw]
-            const cfloat u0 = in[j];
-            const cfloat u1 = cmul(in[j + quarter], W[tw]);
-            const cfloat u2 = cmul(in[j + 2 * quarter], W[2 * tw]);
-            const cfloat u3 = cmul(in[j + 3 * quarter], W[3 * tw]);
-            const cfloat a{u0.x + u2.x, u0.y + u2.y}, b{u0.x - u2.x, u0.y - u2.y};
-            const cfloat c{u1.x + u3.x, u1.y + u3.y}, d{u1.x - u3.x, u1.y - u3.y};
-            const int j0 = ((j - k) << 2) + k;
-            out[j0] = cfloat{a.x + c.x, a.y + c.y};
-            out[j0 + Ns] = cfloat{b.x + d.y, b.y - d.x};      // b - i d
-            out[j0 + 2 * Ns] = cfloat{a.x - c.x, a.y - c.y};
-            out[j0 + 3 * Ns] = cfloat{b.x - d.y, b.y + d.x};  // b + i d
+            const int tw = k << (log2m - 3 - s);  // exp(-2 pi i k / (8 Ns)) = W[tw]
+            cfloat u[8];
+            u[0] = in[j];
+#pragma unroll
+            for (int q = 1; q < 8; q++) u[q] = cmul(in[j + q * eighth], W[q * tw]);
+            // radix-8 butterfly: y[q] = sum_p u[p] exp(-2 pi i p q / 8)
+            const cfloat a0 = cadd(u[0], u[4]), a1 = csub(u[0], u[4]);
+            const cfloat a2 = cadd(u[2], u[6]), a3 = cmul_mi(csub(u[2], u[6]));
+            const cfloat a4 = cadd(u[1], u[5]), a5 = csub(u[1], u[5]);
+            const cfloat a6 = cadd(u[3], u[7]), a7 = cmul_mi(csub(u[3], u[7]));
+            const cfloat b0 = cadd(a0, a2), b2 = csub(a0, a2);  // even outputs of the first half
+            const cfloat b1 = cadd(a1, a3), b3 = csub(a1, a3);
+            const cfloat b4 = cadd(a4, a6), b6 = cmul_mi(csub(a4, a6));
+            const cfloat t5 = cadd(a5, a7), t7 = csub(a5, a7);
+            const cfloat b5 = cfloat{(t5.x + t5.y) * r2, (t5.y - t5.x) * r2};    // t5 * exp(-i pi / 4)
+            const cfloat b7 = cfloat{(-t7.x + t7.y) * r2, (-t7.y - t7.x) * r2};  // t7 * exp(-3 i pi / 4)
+            const int j0 = ((j - k) << 3) + k;
+            out[j0] = cadd(b0, b4);
+            out[j0 + Ns] = cadd(b1, b5);
+            out[j0 + 2 * Ns] = cadd(b2, b6);
+            out[j0 + 3 * Ns] = cadd(b3, b7);
+            out[j0 + 4 * Ns] = csub(b0, b4);
+            out[j0 + 5 * Ns] = csub(b1, b5);
+            out[j0 + 6 * Ns] = csub(b2, b6);
+            out[j0 + 7 * Ns] = csub(b3, b7);
         }
         cfloat *t = in;
         in = out;
