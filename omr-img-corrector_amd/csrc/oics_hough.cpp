@@ -491,8 +491,10 @@ int omr_correct_default(const omr_image *src, uint16_t projection_max_angle, dou
     if (rc) return rc;
     double pa = 0;
     int32_t pst = 0, pn = 0;
-    const int cap = 2 * (int)projection_max_angle * 1024 + 16;  // generous: candidates <= number of sweep angles
-    std::vector<double> pc((size_t)std::min(cap, 1 << 20));
+    int32_t n_half = 0;
+    const int n_cand = omr_candidate_count(projection_max_angle, projection_angle_step, &n_half);  // candidates <= sweep angles
+    if (n_cand <= 0) return fail(OMR_ERR_BADARG, "empty candidate range");
+    std::vector<double> pc((size_t)n_cand + 1);
     rc = omr_get_result_from_projection(src, projection_max_angle, projection_angle_step, projection_max_width,
                                         projection_max_height, &pa, &pst, pc.data(), (int32_t)pc.size(), &pn);
     if (rc) return rc;

@@ -176,3 +176,15 @@ def test_entry_points_are_reentrant(oracle):
     for t in ts:
         t.join()
     assert not errs, errs
+
+
+def test_large_line_sets_use_the_device_vote(oracle):
+    """More than 2048 segments: the O(n^2) +-0.1 degree vote runs on the GPU (angle_votes_kernel)."""
+    img, _ = card(1754, 1240, 12)
+    ea, es, ec, en = oracle.get_result_from_edges_detection(img, 60.0, 20.0)
+    assert en > 2048
+    r = omr.get_result_from_edges_detection(img, 60.0, 20.0)
+    assert np.float64(r.angle).view(np.uint64) == np.float64(ea).view(np.uint64) and int(r.status) == es
+    assert r.candidates.size == ec.size and (r.candidates.view(np.uint64) == ec.view(np.uint64)).all()
+    e_ang, e_n = oracle.get_angle_with_hough(img, 60.0, 20.0)
+    assert np.float64(hough.get_angle_with_hough(img, 60.0, 20.0)).view(np.uint64) == np.float64(e_ang).view(np.uint64)
