@@ -164,18 +164,19 @@ int omr_batch_sync(omr_batch_ctx *ctx);
  * cost between dependent launches (about 30 us per sweep at 2480x3508) over more work; the scratch
  * grows accordingly (about 40 MB per scan of the group at 2480x3508).  Results do not change. */
 int omr_batch_set_group(omr_batch_ctx *ctx, int32_t scans_per_launch);
-/* Sum over scans of the sweep-stage duration (ms; HIP events on the launch stream around the
- * sweep kernels of a scan: one run-merging launch (row pass and column pass) plus one gather
- * launch when some candidates do not qualify) and the number of scans timed since the last call
- * (timing must be enabled with omr_batch_set_timing). Synchronises. */
 /* Split of the candidates between the run-merging kernel and the gather kernels (see
  * omr_sweep_plan_info). */
 int omr_batch_info(const omr_batch_ctx *ctx, int32_t *n_runs, int32_t *n_gather);
+/* Sum over launch groups of the sweep-stage duration (ms; HIP events on the launch stream around
+ * the sweep kernels of a group: one run-merging launch -- all scans of the group, both projections
+ * -- plus one gather launch per scan when some candidates do not qualify) and the number of groups
+ * timed since the last call (timing must be enabled with omr_batch_set_timing).  Synchronises. */
 int omr_batch_set_timing(omr_batch_ctx *ctx, int32_t enabled);
 int omr_batch_kernel_ms(omr_batch_ctx *ctx, double *sum_ms, int32_t *launches);
 
 /* Host-buffer batch over the visible devices (SURVEY.md 8b `omr_sweep_batch`): scans[i] goes
- * to device i % n_devices; the only "collective" is the host-side gather of the results.
+ * to device i % n_devices (pinned staging ring, copy / sweep overlapped, four scans per launch);
+ * the only "collective" is the host-side gather of the results.
  * best_angle[i] = (best_idx[i] - N) * step (projection.rs:189-190). */
 int omr_sweep_batch(const omr_image *scans, int32_t n, uint16_t max_angle, double step,
                     int32_t n_devices, int32_t *best_idx, double *best_angle, double *v_sd_opt,

@@ -1,5 +1,5 @@
-"""End-to-end rate of the host-buffer entry point omr_sweep_batch (H2D copy of every 8.7 MB scan included,
-pageable host memory as a caller's cv::Mat would be).  Never bench.py's `value` -- that is HBM-resident by
+"""End-to-end rate of the host-buffer entry point omr_sweep_batch (copy of every 8.7 MB scan out of pageable
+host memory -- what a caller's cv::Mat is -- through the pinned ring to the device included).  Never bench.py's `value` -- that is HBM-resident by
 contract; this is the PCIe-inclusive figure DESIGN.md quotes.  Usage: python tools/bench_host.py [scans]"""
 import json
 import os
@@ -22,4 +22,4 @@ t0 = time.perf_counter()
 best, ang, _, _ = projection.sweep_batch(scans, 10, 0.05, n_devices=1)
 dt = time.perf_counter() - t0
 print(json.dumps({"entry_point": "omr_sweep_batch (host images, 1 GPU)", "scans": N, "images_per_s": N / dt,
-                  "seconds": dt, "note": "includes plan creation per call and one pageable H2D copy per scan"}))
+                  "seconds": dt, "note": "includes plan creation, pinned-ring allocation and the copy of every scan out of pageable memory"}))
