@@ -101,3 +101,13 @@ def test_golden_picture(golden_dir):
     assert dmax <= PICTURE_TOL and same >= PICTURE_EQUAL_MIN
     dmax, same = close(m, d["magnitude"])
     assert dmax <= PICTURE_TOL and same >= PICTURE_EQUAL_MIN
+
+
+def test_headline_size_pictures():
+    """BASELINE config 5's scan size (4096x4096, powers of two) and the A4 scan (Bluestein on both axes)."""
+    for rows, cols, seed in ((4096, 4096, 3), (3508, 2480, 2)):
+        g, _ = synth.make_card(rows, cols, seed)
+        _, lg = fft.get_fft_image(g)
+        _, elg = offt.get_fft_image(g)
+        dmax, same = close(lg, elg)
+        assert dmax <= PICTURE_TOL and same >= 0.999, (rows, cols, dmax, same)

@@ -188,3 +188,17 @@ def test_large_line_sets_use_the_device_vote(oracle):
     assert r.candidates.size == ec.size and (r.candidates.view(np.uint64) == ec.view(np.uint64)).all()
     e_ang, e_n = oracle.get_angle_with_hough(img, 60.0, 20.0)
     assert np.float64(hough.get_angle_with_hough(img, 60.0, 20.0)).view(np.uint64) == np.float64(e_ang).view(np.uint64)
+
+
+def test_headline_size_matches_oracle(oracle):
+    """BASELINE config 4's scan size (2480x3508): edges, segments and result against the oracle."""
+    img, _ = card(3508, 2480, 2)
+    edges = hough.canny(img)
+    assert (edges == oracle.canny(img, fast=True)).all()
+    exp = oracle.hough_lines_p(edges, 150.0, 50.0, fast=True)
+    got = hough.hough_lines_p(edges, 1.0, np.pi / 180.0, 0, 150.0, 50.0)
+    assert got.shape == exp.shape and (got == exp).all()
+    ea, es, ec, en = oracle.get_result_from_edges_detection(img, 150.0, 50.0, fast=True)
+    r = omr.get_result_from_edges_detection(img, 150.0, 50.0)
+    assert en == len(exp)
+    assert np.float64(r.angle).view(np.uint64) == np.float64(ea).view(np.uint64) and int(r.status) == es
