@@ -5,8 +5,11 @@
 // 2480 = 2^4 * 5 * 31 or 3508 = 2^2 * 877 must work: a line is transformed entirely inside LDS, by a
 // radix-8 Stockham FFT when its length is a power of two and by Bluestein's chirp-z (two power-of-two
 // FFTs of length m >= 2n - 1 and three pointwise products) otherwise.  Twiddles and chirps are
-// tabulated by the host in double precision.  The 2-D transform is rows -> transpose -> rows ->
-// transpose; float32 throughout (the reference's dft is CV_32F), built without FMA contraction.
+// tabulated by the host in double precision.  The 2-D transform is a pass along the rows, then a pass
+// along the columns on strided lines of the same row-major array (row pitch padded by 8 elements so a
+// column does not alias onto one memory channel; workgroup -> column mapping keeps the eight columns of
+// a 64-byte sector on one XCD): no transposes.  float32 throughout (the reference's dft is CV_32F),
+// built without FMA contraction.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -108,22 +111,30 @@ __global__ __launch_bounds__(FFT_THREADS) void fft_pass_kernel(const FftPass p)
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
     cfloat *A = (cfloat *)lds_raw, *B = A + p.m;
     const int tid = threadIdx.x, n = p.n, m = p.m;
-    const int64_t line = blockIdx.x;
+    // Column passes (elem_stride > 1) touch 8 bytes per 64-byte sector: the eight columns that share a
+    // sector must meet in one XCD's L2.  Workgroups go round-robin to the 8 XCDs, so XCD x takes the
+    // lines [x * lines / 8, (x + 1) * lines / 8) in order instead of every eighth line.
+    int64_t line = blockIdx.x;
+    if (p.elem_stride > 1) {
+        const int per = p.lines / 8, body = per * 8;
+        if ((int)blockIdx.x < body) line = (int64_t)(blockIdx.x % 8) * per + blockIdx.x / 8;
+    }
     const bool blue = p.chirp != nullptr;
     for (int k = tid; k < m; k += FFT_THREADS) {
         cfloat v{0.f, 0.f};
         if (k < n) {
             if (p.src_u8) v.x = (float)p.src_u8[line * p.src_step + k] * p.in_scale + 0.0f;
-            else v = p.src_c[line * n + k];
+            else v = p.src_c[line * p.line_stride + (int64_t)k * p.elem_stride];
             if (blue) v = cmul(v, p.chirp[k]);
         }
         A[k] = v;
     }
     cfloat *P = fft_forward_lds(A, B, m, p.log2m, p.W, tid);
     cfloat *Q = P == A ? B : A;
-    cfloat *dst = p.dst + line * n;
+    cfloat *dst = p.dst + line * p.line_stride;
     if (!blue) {
-        for (int k = tid; k < n; k += FFT_THREADS) dst[k] = cfloat{P[k].x * p.out_scale, P[k].y * p.out_scale};
+        for (int k = tid; k < n; k += FFT_THREADS)
+            dst[(int64_t)k * p.elem_stride] = cfloat{P[k].x * p.out_scale, P[k].y * p.out_scale};
         return;
     }
     // convolution with the conjugate chirp: pointwise product, then an inverse FFT as conj(FFT(conj(.))) / m
@@ -135,7 +146,7 @@ __global__ __launch_bounds__(FFT_THREADS) void fft_pass_kernel(const FftPass p)
     const float inv_m = 1.0f / (float)m;
     for (int k = tid; k < n; k += FFT_THREADS) {
         const cfloat c = cmul(cfloat{R[k].x * inv_m, -R[k].y * inv_m}, p.chirp[k]);
-        dst[k] = cfloat{c.x * p.out_scale, c.y * p.out_scale};
+        dst[(int64_t)k * p.elem_stride] = cfloat{c.x * p.out_scale, c.y * p.out_scale};
     }
 }
 
@@ -147,30 +158,6 @@ hipError_t launch_fft_pass(const FftPass &p, hipStream_t s)
     hipError_t e = hipFuncSetAttribute((const void *)fft_pass_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(fft_pass_kernel, dim3(p.lines), dim3(FFT_THREADS), lds, s, p);
-    return hipGetLastError();
-}
-
-__global__ __launch_bounds__(256) void transpose_c_kernel(const cfloat *__restrict__ src, int rows, int cols,
-                                                          cfloat *__restrict__ dst)
-{
-    __shared__ cfloat t[32][33];
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
-    const int x0 = blockIdx.x * 32, y0 = blockIdx.y * 32;
-    for (int i = ty; i < 32; i += 8) {
-        const int y = y0 + i, x = x0 + tx;
-        if (y < rows && x < cols) t[i][tx] = src[(int64_t)y * cols + x];
-    }
-    __syncthreads();
-    for (int i = ty; i < 32; i += 8) {
-        const int x = x0 + i, y = y0 + tx;  // dst row = source column
-        if (x < cols && y < rows) dst[(int64_t)x * rows + y] = t[tx][i];
-    }
-}
-
-hipError_t launch_transpose_c(const cfloat *d_src, int rows, int cols, cfloat *d_dst, hipStream_t s)
-{
-    hipLaunchKernelGGL(transpose_c_kernel, dim3((cols + 31) / 32, (rows + 31) / 32), dim3(256), 0, s, d_src, rows, cols,
-                       d_dst);
     return hipGetLastError();
 }
 
@@ -239,7 +226,7 @@ __global__ __launch_bounds__(1024) void minmax_final_kernel(const float *__restr
 
 // out(r, c) = |F(sr, sc)|: quadrants of cx x cy swapped diagonally, an odd last row / column untouched.
 // Block = 1024 consecutive pixels of one row (4 per thread), so source and destination are both runs.
-__global__ __launch_bounds__(256) void spec_magnitude_kernel(const cfloat *__restrict__ F, int rows, int cols,
+__global__ __launch_bounds__(256) void spec_magnitude_kernel(const cfloat *__restrict__ F, int rows, int cols, int pitch,
                                                              float *__restrict__ mag, float *__restrict__ part)
 {
     const int cx = cols / 2, cy = rows / 2;
@@ -252,7 +239,7 @@ __global__ __launch_bounds__(256) void spec_magnitude_kernel(const cfloat *__res
         if (c < cols) {
             const int sc = (r < 2 * cy && c < 2 * cx) ? (c < cx ? c + cx : c - cx) : c;
             const int srr = (c < 2 * cx) ? sr : r;  // the odd last column is outside every quadrant
-            const cfloat v = F[(int64_t)srr * cols + sc];
+            const cfloat v = F[(int64_t)srr * pitch + sc];
             const float m = sqrtf(v.x * v.x + v.y * v.y);
             mag[(int64_t)r * cols + c] = m;
             lo = fminf(lo, m);
@@ -262,11 +249,11 @@ __global__ __launch_bounds__(256) void spec_magnitude_kernel(const cfloat *__res
     block_minmax(lo, hi, part, blockIdx.y * gridDim.x + blockIdx.x);
 }
 
-hipError_t launch_spec_magnitude(const cfloat *d_F, int rows, int cols, float *d_mag, float *d_part, uint32_t *d_minmax,
+hipError_t launch_spec_magnitude(const cfloat *d_F, int rows, int cols, int pitch, float *d_mag, float *d_part, uint32_t *d_minmax,
                                  hipStream_t s)
 {
     const dim3 grid((cols + 1023) / 1024, rows);
-    hipLaunchKernelGGL(spec_magnitude_kernel, grid, dim3(256), 0, s, d_F, rows, cols, d_mag, d_part);
+    hipLaunchKernelGGL(spec_magnitude_kernel, grid, dim3(256), 0, s, d_F, rows, cols, pitch, d_mag, d_part);
     hipLaunchKernelGGL(minmax_final_kernel, dim3(1), dim3(1024), 0, s, d_part, (int)(grid.x * grid.y), d_minmax);
     return hipGetLastError();
 }

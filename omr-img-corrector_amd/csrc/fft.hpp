@@ -18,8 +18,10 @@ struct FftPass {
     const uint8_t *src_u8;  // real 8-bit input (im = 0), x = (float)v * in_scale; or NULL
     int64_t src_step;       // bytes between lines of src_u8
     float in_scale;
-    const cfloat *src_c;    // complex input, lines of n elements, packed; used when src_u8 == NULL
-    cfloat *dst;            // [lines][n]
+    const cfloat *src_c;    // complex input; used when src_u8 == NULL
+    cfloat *dst;            // complex output
+    int64_t line_stride;    // elements between consecutive lines of src_c and dst (n for packed rows, 1 for columns)
+    int64_t elem_stride;    // elements between consecutive points of a line (1 for rows, the row pitch for columns)
     int32_t n, m, log2m, lines;
     const cfloat *W;        // m twiddles exp(-2 pi i t / m)
     const cfloat *chirp;    // n: exp(-i pi k^2 / n); NULL for the direct transform
@@ -29,9 +31,6 @@ struct FftPass {
 #define OMR_FFT_MAX_M 8192
 hipError_t launch_fft_pass(const FftPass &p, hipStream_t s);
 
-// [rows][cols] -> [cols][rows]
-hipError_t launch_transpose_c(const cfloat *d_src, int rows, int cols, cfloat *d_dst, hipStream_t s);
-
 // d_minmax: 4 ordered-uint words {min |F|, max |F|, min log, max log}; d_part: scratch for per-block
 // extrema, spec_part_floats(rows, cols) floats
 inline size_t spec_part_floats(int rows, int cols)
@@ -40,7 +39,7 @@ inline size_t spec_part_floats(int rows, int cols)
     return 2 * (a > b ? a : b);
 }
 // |F| of the quadrant-swapped spectrum (fft.rs:68-88, :108-110) and its min / max
-hipError_t launch_spec_magnitude(const cfloat *d_F, int rows, int cols, float *d_mag, float *d_part, uint32_t *d_minmax,
+hipError_t launch_spec_magnitude(const cfloat *d_F, int rows, int cols, int pitch, float *d_mag, float *d_part, uint32_t *d_minmax,
                                  hipStream_t s);
 // correction(|F|) * 255 -> 8-bit "magnitude_image" (x 255 again, fft.rs:134) and log(. + 1/255) with its
 // min / max (fft.rs:113-119)
