@@ -162,7 +162,9 @@ int omr_batch_run_device(omr_batch_ctx *ctx, const uint8_t *d_scans, int64_t sca
 int omr_batch_sync(omr_batch_ctx *ctx);
 /* Scans carried by one launch of each kernel (default 1; 1..64).  Larger groups amortise the fixed
  * cost between dependent launches (about 30 us per sweep at 2480x3508) over more work; the scratch
- * grows accordingly (about 40 MB per scan of the group at 2480x3508).  Results do not change. */
+ * grows accordingly (about 40 MB per scan of the group at 2480x3508).  Results do not change.
+ * Prefer 1, 2, 4, 8 or a multiple of 8: the sweep's grid runs scans fastest and workgroups go
+ * round-robin to the 8 XCDs, so each XCD then sees one scan (or two) and keeps its bit image in L2. */
 int omr_batch_set_group(omr_batch_ctx *ctx, int32_t scans_per_launch);
 /* Split of the candidates between the run-merging kernel and the gather kernels (see
  * omr_sweep_plan_info). */
