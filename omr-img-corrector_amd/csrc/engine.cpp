@@ -459,8 +459,11 @@ int omr_sweep_plan_run(omr_sweep_plan *plan, const omr_image *img, int32_t black
     const size_t need = (size_t)d.rows * d.cols;
     if (plan->img.bytes < need) OMR_HIP(plan->img.alloc(need));
     hipStream_t s = plan->stream;
-    OMR_HIP(hipMemcpy2DAsync(plan->img.p, (size_t)d.cols, img->data, (size_t)img->step_bytes, (size_t)d.cols,
-                             (size_t)d.rows, hipMemcpyHostToDevice, s));
+    if (img->step_bytes == d.cols)  // packed: one linear copy (the 2-D path is row-by-row DMA for odd widths)
+        OMR_HIP(hipMemcpyAsync(plan->img.p, img->data, need, hipMemcpyHostToDevice, s));
+    else
+        OMR_HIP(hipMemcpy2DAsync(plan->img.p, (size_t)d.cols, img->data, (size_t)img->step_bytes, (size_t)d.cols,
+                                 (size_t)d.rows, hipMemcpyHostToDevice, s));
     plan->timed = plan->timing;
     int rc = enqueue_sweep(plan->tables, plan->scratch, plan->kernel_sel, plan->img.as<uint8_t>(), d.cols, black_max, s,
                            nullptr, nullptr, nullptr, nullptr, plan->scratch.best.as<int32_t>(),

@@ -257,7 +257,10 @@ int upload(const omr_image *im, DevBuf *buf, hipStream_t s)
 {
     const size_t row = (size_t)im->cols * im->channels;
     OMR_HIP(buf->alloc(row * (size_t)im->rows));
-    OMR_HIP(hipMemcpy2DAsync(buf->p, row, im->data, (size_t)im->step_bytes, row, (size_t)im->rows, hipMemcpyHostToDevice, s));
+    if ((size_t)im->step_bytes == row)  // packed: one linear copy (the 2-D path is slow for odd widths)
+        OMR_HIP(hipMemcpyAsync(buf->p, im->data, row * (size_t)im->rows, hipMemcpyHostToDevice, s));
+    else
+        OMR_HIP(hipMemcpy2DAsync(buf->p, row, im->data, (size_t)im->step_bytes, row, (size_t)im->rows, hipMemcpyHostToDevice, s));
     return OMR_OK;
 }
 
