@@ -303,43 +303,47 @@ __global__ __launch_bounds__(LDS_WAVES *OMR_WAVE) void sweep_lds_kernel(
                 const int xoff = wx0 << 15;  // (wx0 * 32) << 10
                 const int yoff = ya << 10;
                 const int adl = ad - xoff, bdl = bd - yoff;  // window-local lane constants
-                int r = 0;
-                // y0, R and 64 are multiples of 4: a group of four rows never straddles a 64-row
-                // flush boundary, so four gathers are in flight before the first is consumed
-                for (; r + 4 <= tr; r += 4) {
+                // four gathers are in flight before the first is consumed, as long as the group of four
+                // rows stays inside the current 64-row block of hrow (R need not be a multiple of 4: the
+                // tile sizes 6, 3, 2, 1 of strongly magnified maps start tiles anywhere); the rows in
+                // between go one at a time
+                for (int r = 0; r < tr;) {
                     const int y = ty + r;
-                    int2_t s4[4];
-                    uint32_t w[4];
-                    int sh[4];
+                    if (r + 4 <= tr && y - hbase + 3 < OMR_WAVE) {
+                        int2_t s4[4];
+                        uint32_t w[4];
+                        int sh[4];
 #pragma unroll
-                    for (int j = 0; j < 4; j++) s4[j] = s0p[y + j];
+                        for (int j = 0; j < 4; j++) s4[j] = s0p[y + j];
 #pragma unroll
-                    for (int j = 0; j < 4; j++) {
-                        const int sx = s4[j].x + adl;  // >= 0 inside the window
-                        const int sy = s4[j].y + bdl;
-                        // byte address = Y * pitch4 + 4 * (X >> 5) + slab base (and_or + mad24)
-                        const int off = __mul24(sy >> 10, pitch4) + (((sx >> 13) & 0xFFC) | slab_byte);
-                        w[j] = *(const uint32_t *)((const char *)slab_all + off);
-                        sh[j] = sx >> 10;
-                    }
+                        for (int j = 0; j < 4; j++) {
+                            const int sx = s4[j].x + adl;  // >= 0 inside the window
+                            const int sy = s4[j].y + bdl;
+                            // byte address = Y * pitch4 + 4 * (X >> 5) + slab base (and_or + mad24)
+                            const int off = __mul24(sy >> 10, pitch4) + (((sx >> 13) & 0xFFC) | slab_byte);
+                            w[j] = *(const uint32_t *)((const char *)slab_all + off);
+                            sh[j] = sx >> 10;
+                        }
 #pragma unroll
-                    for (int j = 0; j < 4; j++) {
-                        const uint32_t bit = __builtin_amdgcn_ubfe(w[j], (uint32_t)sh[j], 1u);
+                        for (int j = 0; j < 4; j++) {
+                            const uint32_t bit = __builtin_amdgcn_ubfe(w[j], (uint32_t)sh[j], 1u);
+                            vacc += bit;
+                            const unsigned long long m = __ballot(bit != 0) & active_mask;
+                            hrow = write_lane(hrow, __popcll(m), y + j - hbase);
+                        }
+                        flush_rows(y + 3);
+                        r += 4;
+                    } else {
+                        const int2_t s0 = s0p[y];
+                        const int sx = s0.x + adl, sy = s0.y + bdl;
+                        const uint32_t bit =
+                            __builtin_amdgcn_ubfe(slab[__mul24(sy >> 10, pitch) + (sx >> 15)], (uint32_t)(sx >> 10), 1u);
                         vacc += bit;
                         const unsigned long long m = __ballot(bit != 0) & active_mask;
-                        hrow = write_lane(hrow, __popcll(m), y + j - hbase);
+                        hrow = write_lane(hrow, __popcll(m), y - hbase);
+                        flush_rows(y);
+                        r++;
                     }
-                    flush_rows(y + 3);
-                }
-                for (; r < tr; r++) {
-                    const int y = ty + r;
-                    const int2_t s0 = s0p[y];
-                    const int sx = s0.x + adl, sy = s0.y + bdl;
-                    const uint32_t bit = __builtin_amdgcn_ubfe(slab[__mul24(sy >> 10, pitch) + (sx >> 15)], (uint32_t)(sx >> 10), 1u);
-                    vacc += bit;
-                    const unsigned long long m = __ballot(bit != 0) & active_mask;
-                    hrow = write_lane(hrow, __popcll(m), y - hbase);
-                    flush_rows(y);
                 }
             } else {
                 for (int r = 0; r < tr; r++) {

@@ -465,3 +465,19 @@ def test_batch_launch_groups_do_not_change_results(oracle):
         _, _, evs, ehs = oracle.sweep(bimg, 10, 0.25)
         assert (res[4][1][i].view(np.uint64) == evs.view(np.uint64)).all()
         assert (res[4][2][i].view(np.uint64) == ehs.view(np.uint64)).all()
+
+
+@pytest.mark.parametrize("rows,cols,ma,st,sc", [(253, 129, 15, 0.2, 0.2), (394, 882, 15, 0.25, 0.2), (610, 685, 15, 1.0, 0.2)])
+def test_gather_tiles_of_odd_height(oracle, rows, cols, ma, st, sc):
+    """Strongly magnified inverse maps (omr.rs:162's scale 0.2 at 15 degrees) get LDS tiles of 6, 3, 2 or 1
+    rows: a group of four rows may then straddle the 64-row block of the row counters (found by
+    tools/fuzz_sweep.py; the gather kernel used to mis-park those counts)."""
+    rng = np.random.Generator(np.random.PCG64(rows + cols))
+    b = np.where(rng.random((rows, cols)) < 0.3, 0, 255).astype(np.uint8)
+    exp = oracle.sweep(b, ma, st, sc)
+    for kernel in (0, GENERIC, LDS):
+        plan = projection.SweepPlan(rows, cols, ma, st, sc)
+        plan.set_kernel(kernel)
+        got = plan.run(b)
+        plan.close()
+        assert_sweep_equal(got, exp, "kernel %d" % kernel)
