@@ -481,3 +481,36 @@ def test_gather_tiles_of_odd_height(oracle, rows, cols, ma, st, sc):
         got = plan.run(b)
         plan.close()
         assert_sweep_equal(got, exp, "kernel %d" % kernel)
+
+
+def test_strided_and_unaligned_views(oracle):
+    """cv::Mat ROIs reach the ABI with step_bytes > cols * channels and odd base addresses: the entry
+    points must honour the stride (2-D copies, the scalar bit-pack) exactly like packed inputs."""
+    import ctypes as C
+    from oics import hough
+    from oics._lib import OmrImage, OmrImageOwned, check, f64p, lib, u8p, u32p
+    rng = np.random.Generator(np.random.PCG64(99))
+    big = np.where(rng.random((300, 517)) < 0.25, 0, 255).astype(np.uint8)
+    view = big[7:7 + 240, 13:13 + 401]                      # step 517, base address odd
+    assert not view.flags["C_CONTIGUOUS"]
+    packed = np.ascontiguousarray(view)
+    im = OmrImage(view.ctypes.data, view.shape[0], view.shape[1], 1, view.strides[0])
+    Ms = oracle.rotation_matrices(240, 401, 5, 0.5)
+    A = Ms.shape[0]
+    vp, hp = np.zeros((A, 401), np.uint32), np.zeros((A, 240), np.uint32)
+    vs, hs = np.zeros(A), np.zeros(A)
+    check(lib().omr_projection_sweep(C.byref(im), Ms.ctypes.data_as(f64p), A, vp.ctypes.data_as(u32p),
+                                     hp.ctypes.data_as(u32p), vs.ctypes.data_as(f64p), hs.ctypes.data_as(f64p)))
+    assert_sweep_equal((vp, hp, vs, hs), oracle.sweep(packed, 5, 0.5), "strided view")
+    # Canny and rotate on a strided 3-channel ROI
+    col = rng.integers(0, 256, (200, 333, 3), dtype=np.uint8)
+    v3 = col[5:150, 9:290]
+    p3 = np.ascontiguousarray(v3)
+    im3 = OmrImage(v3.ctypes.data, v3.shape[0], v3.shape[1], 3, v3.strides[0])
+    out = OmrImageOwned()
+    check(lib().omr_canny(C.byref(im3), 50.0, 150.0, C.byref(out)))
+    assert (hough._take(out) == oracle.canny(p3)).all()
+    out = OmrImageOwned()
+    border = np.array([255, 255, 255, 0], np.uint8)
+    check(lib().omr_rotate(C.byref(im3), 7.5, 1.0, 0, border.ctypes.data_as(u8p), 1, C.byref(out)))
+    assert (hough._take(out) == oracle.rotate_mat(p3, 7.5, 1.0, 0, (255, 255, 255, 0), 1)).all()
