@@ -202,3 +202,14 @@ def test_headline_size_matches_oracle(oracle):
     r = omr.get_result_from_edges_detection(img, 150.0, 50.0)
     assert en == len(exp)
     assert np.float64(r.angle).view(np.uint64) == np.float64(ea).view(np.uint64) and int(r.status) == es
+
+
+@pytest.mark.parametrize("theta_div,rho", [(90, 1.0), (250, 1.0), (180, 2.0), (180, 0.5), (45, 3.0)])
+def test_hough_lines_p_other_resolutions(oracle, theta_div, rho):
+    """rho / theta other than the reference's (1, pi/180): accumulator shape, trig table and walks follow."""
+    img, _ = card(300, 420, 9)
+    edges = oracle.canny(img)
+    for thr in (0, 20):
+        exp = oracle.hough_lines_p(edges, 30, 5, rho=rho, theta=np.pi / theta_div, threshold=thr)
+        got = hough.hough_lines_p(edges, rho, np.pi / theta_div, thr, 30, 5)
+        assert got.shape == exp.shape and (got == exp).all()
