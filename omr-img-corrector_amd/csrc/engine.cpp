@@ -3,6 +3,8 @@
 // like OpenCV's (no FMA contraction).
 #include "engine.hpp"
 
+#include <map>
+
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
@@ -34,10 +36,91 @@ int fail_gpu(const char *what, hipError_t e)
 const char *last_error() { return g_err.c_str(); }
 void clear_error() { g_err.clear(); }
 
+// ---- device buffer cache ---------------------------------------------------------------------
+namespace {
+thread_local hipStream_t t_pool_stream = nullptr;
+thread_local bool t_pool_on = false;
+
+struct BlockCache {
+    std::mutex mu;
+    std::multimap<size_t, void *> free_blocks;  // size -> block
+    size_t cached = 0;
+};
+BlockCache &cache_of(int dev)
+{
+    static BlockCache caches[16];
+    return caches[dev & 15];
+}
+size_t cache_limit()
+{
+    static const size_t lim = [] {
+        const char *e = getenv("OMR_POOL_MB");
+        return (size_t)(e ? atoll(e) : 2048) << 20;
+    }();
+    return lim;
+}
+size_t round_block(size_t n)
+{
+    const size_t g = n >= ((size_t)1 << 20) ? ((size_t)1 << 20) : (size_t)4096;
+    return (n + g - 1) / g * g;
+}
+}  // namespace
+
+PoolScope::PoolScope(hipStream_t stream) : prev_(t_pool_stream), prev_on_(t_pool_on)
+{
+    t_pool_stream = stream;
+    t_pool_on = true;
+}
+PoolScope::~PoolScope()
+{
+    t_pool_stream = prev_;
+    t_pool_on = prev_on_;
+}
+
+NoPoolScope::NoPoolScope() : prev_(t_pool_stream), prev_on_(t_pool_on)
+{
+    t_pool_stream = nullptr;
+    t_pool_on = false;
+}
+NoPoolScope::~NoPoolScope()
+{
+    t_pool_stream = prev_;
+    t_pool_on = prev_on_;
+}
+
 hipError_t DevBuf::alloc(size_t n)
 {
     release();
     if (n == 0) n = 16;
+    if (t_pool_on && cache_limit() > 0) {
+        int dev = 0;
+        if (hipGetDevice(&dev) == hipSuccess && dev < 16) {
+            const size_t want = round_block(n);
+            BlockCache &c = cache_of(dev);
+            {
+                std::lock_guard<std::mutex> lk(c.mu);
+                auto it = c.free_blocks.lower_bound(want);
+                if (it != c.free_blocks.end() && it->first <= 2 * want) {
+                    p = it->second;
+                    cap_ = it->first;
+                    c.cached -= cap_;
+                    c.free_blocks.erase(it);
+                }
+            }
+            if (!p) {
+                hipError_t e = hipMalloc(&p, want);
+                if (e != hipSuccess) {
+                    p = nullptr;
+                    return e;
+                }
+                cap_ = want;
+            }
+            bytes = n;
+            owner_ = t_pool_stream;
+            dev_ = dev;
+            return hipSuccess;
+        }
+    }
     hipError_t e = hipMalloc(&p, n);
     if (e == hipSuccess) bytes = n;
     else p = nullptr;
@@ -46,9 +129,28 @@ hipError_t DevBuf::alloc(size_t n)
 
 void DevBuf::release()
 {
-    if (p) (void)hipFree(p);
+    if (p && dev_ >= 0) {
+        // the owner's queued work may still use the block: drain that one stream, not the device
+        bool keep = hipStreamSynchronize(owner_) == hipSuccess;
+        BlockCache &c = cache_of(dev_);
+        if (keep) {
+            std::lock_guard<std::mutex> lk(c.mu);
+            if (c.cached + cap_ <= cache_limit()) {
+                c.free_blocks.emplace(cap_, p);
+                c.cached += cap_;
+            } else {
+                keep = false;
+            }
+        }
+        if (!keep) (void)hipFree(p);
+    } else if (p) {
+        (void)hipFree(p);
+    }
     p = nullptr;
     bytes = 0;
+    owner_ = nullptr;
+    cap_ = 0;
+    dev_ = -1;
 }
 
 // ---- OpenCV 4.6.0 geometry on the host ------------------------------------------------------
@@ -404,6 +506,7 @@ int omr_sweep_matrices(int32_t rows, int32_t cols, uint16_t max_angle, double st
 int omr_sweep_plan_create(int32_t rows, int32_t cols, const double *fwd_M, int32_t A, int32_t device,
                           omr_sweep_plan **plan_out)
 {
+    NoPoolScope plan_owned;  // these buffers outlive the calling entry point
     if (!plan_out) return fail(OMR_ERR_BADARG, "null plan_out");
     *plan_out = nullptr;
     std::unique_ptr<omr_sweep_plan> p(new omr_sweep_plan);
@@ -421,6 +524,7 @@ int omr_sweep_plan_create(int32_t rows, int32_t cols, const double *fwd_M, int32
 int omr_sweep_plan_create_angles(int32_t rows, int32_t cols, uint16_t max_angle, double step, double scale,
                                  int32_t device, omr_sweep_plan **plan_out)
 {
+    NoPoolScope plan_owned;  // these buffers outlive the calling entry point
     int N, A = candidate_count(max_angle, step, &N);
     if (A <= 0) return fail(OMR_ERR_BADARG, "empty candidate range (max_angle %u, step %g)", (unsigned)max_angle, step);
     std::vector<double> M((size_t)A * 6);
@@ -457,7 +561,10 @@ int omr_sweep_plan_run(omr_sweep_plan *plan, const omr_image *img, int32_t black
     std::lock_guard<std::mutex> lk(plan->mu);
     OMR_HIP(hipSetDevice(plan->tables.device));
     const size_t need = (size_t)d.rows * d.cols;
-    if (plan->img.bytes < need) OMR_HIP(plan->img.alloc(need));
+    if (plan->img.bytes < need) {
+        NoPoolScope plan_owned;  // the staging buffer stays with the plan
+        OMR_HIP(plan->img.alloc(need));
+    }
     hipStream_t s = plan->stream;
     if (img->step_bytes == d.cols)  // packed: one linear copy (the 2-D path is row-by-row DMA for odd widths)
         OMR_HIP(hipMemcpyAsync(plan->img.p, img->data, need, hipMemcpyHostToDevice, s));
@@ -581,6 +688,7 @@ int omr_argmax_projection_device(const double *d_v_sd, const double *d_h_sd, int
 int omr_batch_create(int32_t rows, int32_t cols, uint16_t max_angle, double step, double scale, int32_t device,
                      int32_t n_streams, omr_batch_ctx **ctx_out)
 {
+    NoPoolScope plan_owned;  // these buffers outlive the calling entry point
     if (!ctx_out) return fail(OMR_ERR_BADARG, "null ctx_out");
     *ctx_out = nullptr;
     if (n_streams < 1 || n_streams > 16) return fail(OMR_ERR_BADARG, "n_streams must be in 1..16");
@@ -682,6 +790,7 @@ int omr_batch_run_device(omr_batch_ctx *ctx, const uint8_t *d_scans, int64_t sca
 
 int omr_batch_set_group(omr_batch_ctx *ctx, int32_t scans_per_launch)
 {
+    NoPoolScope plan_owned;  // these buffers outlive the calling entry point
     if (!ctx || scans_per_launch < 1 || scans_per_launch > 64) return fail(OMR_ERR_BADARG, "scans per launch must be 1..64");
     int rc = omr_batch_sync(ctx);
     if (rc) return rc;

@@ -24,7 +24,11 @@ void clear_error();
         if (e__ != hipSuccess) return ::omr::fail_gpu(#expr, e__); \
     } while (0)
 
-// RAII device allocation
+// RAII device allocation.  Buffers allocated while a PoolScope is active on the calling thread (the
+// per-call entry points open one around their private stream) come from a per-device cache and go
+// back to it after that stream has drained: hipMalloc costs 0.1-0.5 ms and hipFree synchronises the
+// whole device, which would serialise the host's worker threads (thread_pool.rs:41-54).  Long-lived
+// owners (plans, batch contexts) allocate outside any scope and keep plain hipMalloc / hipFree.
 struct DevBuf {
     void *p = nullptr;
     size_t bytes = 0;
@@ -36,6 +40,32 @@ struct DevBuf {
     void release();
     template <class T>
     T *as() const { return static_cast<T *>(p); }
+
+  private:
+    hipStream_t owner_ = nullptr;  // pooled: the stream whose work may still touch the buffer
+    size_t cap_ = 0;               // pooled: size of the cached block
+    int dev_ = -1;
+};
+
+// Marks the calling thread's allocations as short-lived work of `stream` (nests; restores on exit).
+struct PoolScope {
+    explicit PoolScope(hipStream_t stream);
+    ~PoolScope();
+    PoolScope(const PoolScope &) = delete;
+    PoolScope &operator=(const PoolScope &) = delete;
+
+  private:
+    hipStream_t prev_;
+    bool prev_on_;
+};
+// Suspends pooling on the calling thread: for allocations that outlive the call (plans, batch contexts).
+struct NoPoolScope {
+    NoPoolScope();
+    ~NoPoolScope();
+
+  private:
+    hipStream_t prev_;
+    bool prev_on_;
 };
 
 // getRotationMatrix2D / warpAffine inversion on the host (fp64, built -ffp-contract=off, same

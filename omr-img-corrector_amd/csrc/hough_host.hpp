@@ -3,6 +3,7 @@
 #pragma once
 #include <stdint.h>
 
+#include <memory>
 #include <vector>
 
 #include "../../include/omrdeskew.h"
@@ -13,6 +14,7 @@ namespace hh {
 
 struct HStream {
     hipStream_t s = nullptr;
+    std::unique_ptr<PoolScope> pool;  // the call's device buffers come from / return to the block cache
     ~HStream();
     int create();
 };

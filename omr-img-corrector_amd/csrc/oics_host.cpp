@@ -89,13 +89,16 @@ struct DevImage {
 
 struct Stream {
     hipStream_t s = nullptr;
+    std::unique_ptr<PoolScope> pool;  // the call's device buffers come from / return to the block cache
     ~Stream()
     {
+        pool.reset();
         if (s) (void)hipStreamDestroy(s);
     }
     int create()
     {
         OMR_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+        pool.reset(new PoolScope(s));
         return OMR_OK;
     }
 };

@@ -32,10 +32,12 @@ namespace hh {
 int HStream::create()
 {
     OMR_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    pool.reset(new PoolScope(s));
     return OMR_OK;
 }
 HStream::~HStream()
 {
+    pool.reset();
     if (s) (void)hipStreamDestroy(s);
 }
 

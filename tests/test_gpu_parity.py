@@ -514,3 +514,34 @@ def test_strided_and_unaligned_views(oracle):
     border = np.array([255, 255, 255, 0], np.uint8)
     check(lib().omr_rotate(C.byref(im3), 7.5, 1.0, 0, border.ctypes.data_as(u8p), 1, C.byref(out)))
     assert (hough._take(out) == oracle.rotate_mat(p3, 7.5, 1.0, 0, (255, 255, 255, 0), 1)).all()
+
+
+def test_per_call_drivers_under_threads(oracle):
+    """Worker threads of the host application call the per-file drivers concurrently; their device
+    buffers come from the shared block cache (engine.cpp) -- results must not depend on the interleaving."""
+    import threading
+    from oics import omr
+    cards = []
+    for k in range(4):
+        g, _ = synth.make_card(400 + 37 * k, 520 - 29 * k, 80 + k)
+        cards.append(np.stack([g, np.roll(g, 1, 0), g], axis=2))
+    exp = [oracle.get_result_from_projection(c, 45, 0.2, 248, 230) for c in cards]
+    rot = [oracle.rotate_mat(c, 3.0 + k, 1.0, 0, (255, 255, 255, 0), 1) for k, c in enumerate(cards)]
+    errs = []
+
+    def work(k):
+        try:
+            for _ in range(15):
+                r = omr.get_result_from_projection(cards[k], 45, 0.2, 248, 230)
+                assert r.angle == exp[k][0] and int(r.status) == exp[k][1] and r.candidates.tolist() == exp[k][2].tolist()
+                got = transfer.rotate_mat(cards[k], 3.0 + k, 1.0, 0, 0, (255, 255, 255, 0), RotateClipStrategy.CONTAIN).get_mat()
+                assert (got == rot[k]).all()
+        except Exception as e:  # noqa: BLE001
+            errs.append((k, repr(e)[:200]))
+
+    ts = [threading.Thread(target=work, args=(k % 4,)) for k in range(8)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errs, errs
