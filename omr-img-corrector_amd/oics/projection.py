@@ -80,7 +80,11 @@ class SweepPlan:
             lib().omr_sweep_plan_destroy(self.handle)
             self.handle = C.c_void_p()
 
-    __del__ = close
+    def __del__(self):
+        try:  # at interpreter shutdown the module globals may already be gone
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
 
     def set_kernel(self, which):
         check(lib().omr_sweep_plan_set_kernel(self.handle, which))
@@ -138,7 +142,11 @@ class Batch:
             lib().omr_batch_destroy(self.handle)
             self.handle = C.c_void_p()
 
-    __del__ = close
+    def __del__(self):
+        try:  # at interpreter shutdown the module globals may already be gone
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
 
     def run_device(self, d_scans, scan_stride, step_bytes, n, black_max, d_best, d_v_sd=None, d_h_sd=None):
         check(lib().omr_batch_run_device(self.handle, d_scans, scan_stride, step_bytes, n, black_max, d_best, d_v_sd,
