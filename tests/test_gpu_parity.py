@@ -545,3 +545,35 @@ def test_per_call_drivers_under_threads(oracle):
     for t in ts:
         t.join()
     assert not errs, errs
+
+
+def test_degenerate_inputs(oracle):
+    """Blank, solid, one-pixel-wide and tiny scans; null / empty images are refused with the
+    OpenCV-style codes instead of crashing."""
+    import ctypes as C
+    from oics import omr
+    from oics._lib import OmrImage, lib
+    for rows, cols in ((1, 1), (1, 200), (200, 1), (2, 3), (33, 64)):
+        for fill in (255, 0):
+            b = np.full((rows, cols), fill, np.uint8)
+            plan = projection.SweepPlan(rows, cols, 5, 0.5)
+            got = plan.run(b)
+            plan.close()
+            assert_sweep_equal(got, oracle.sweep(b, 5, 0.5), "%dx%d fill %d" % (rows, cols, fill))
+            assert got[4] == oracle.argmax_path1(got[2], got[3])[0]
+    # path 2 on a blank sheet: the reference would index an empty candidate list (omr.rs:211) -> NotAResult
+    blank = np.full((300, 400, 3), 255, np.uint8)
+    r = omr.get_result_from_projection(blank, 45, 0.2, 248, 230)
+    ea, es, ec = oracle.get_result_from_projection(blank, 45, 0.2, 248, 230)
+    assert int(r.status) == es == 2 and r.angle == ea
+    # refused inputs
+    vs, hs = np.zeros(4), np.zeros(4)
+    M = oracle.rotation_matrices(8, 8, 1, 0.5)
+    A = M.shape[0]
+    data = np.zeros((8, 8), np.uint8)
+    f64p = C.POINTER(C.c_double)
+    for im, code in ((OmrImage(None, 8, 8, 1, 8), -5), (OmrImage(data.ctypes.data, 0, 8, 1, 8), -215),
+                     (OmrImage(data.ctypes.data, 8, 8, 1, 4), -5), (OmrImage(data.ctypes.data, 8, 8, 3, 24), -215)):
+        rc = lib().omr_projection_sweep(C.byref(im), M.ctypes.data_as(f64p), A, None, None, vs.ctypes.data_as(f64p),
+                                        hs.ctypes.data_as(f64p))
+        assert rc == code, (rc, code, lib().omr_last_error())
