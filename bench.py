@@ -87,8 +87,8 @@ def cpu_baseline(gray, gpu_vs, gpu_hs, budget_s):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--scans", type=int, default=8, help="scans per GPU per step")
     ap.add_argument("--streams", type=int, default=1,
                     help="HIP streams per GPU; the sweep kernel fills the chip by itself, so 1 keeps the "
