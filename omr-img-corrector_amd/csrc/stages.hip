@@ -110,13 +110,25 @@ __global__ __launch_bounds__(256) void resize_area_int_c1_kernel(const uint8_t *
                                                                  uint8_t *__restrict__ dst, int64_t dstep, int drows,
                                                                  int dcols, int k)
 {
-    __shared__ uint8_t tile[RA_OH * RA_MAXK][RA_OW * RA_MAXK + 4];
+    __shared__ __attribute__((aligned(16))) uint8_t tile[RA_OH * RA_MAXK][RA_OW * RA_MAXK + 4];
     const int ox0 = blockIdx.x * RA_OW, oy0 = blockIdx.y * RA_OH;
     const int iw = min(RA_OW, dcols - ox0) * k, ih = min(RA_OH, drows - oy0) * k;
     const uint8_t *S = src + (int64_t)oy0 * k * sstep + (int64_t)ox0 * k;
-    for (int i = threadIdx.x; i < iw * ih; i += 256) {
-        const int ly = i / iw, lx = i - ly * iw;
-        tile[ly][lx] = S[(int64_t)ly * sstep + lx];
+    if ((((uintptr_t)S | (uintptr_t)sstep) & 3) == 0) {  // dword loads: a quarter of the load instructions
+        const int iw4 = iw >> 2;
+        for (int i = threadIdx.x; i < iw4 * ih; i += 256) {
+            const int ly = i / iw4, lq = i - ly * iw4;
+            *(uint32_t *)&tile[ly][lq * 4] = *(const uint32_t *)(S + (int64_t)ly * sstep + lq * 4);
+        }
+        for (int i = threadIdx.x; i < (iw & 3) * ih; i += 256) {  // last, partial block of a row
+            const int ly = i / (iw & 3), lx = (iw & ~3) + i % (iw & 3);
+            tile[ly][lx] = S[(int64_t)ly * sstep + lx];
+        }
+    } else {
+        for (int i = threadIdx.x; i < iw * ih; i += 256) {
+            const int ly = i / iw, lx = i - ly * iw;
+            tile[ly][lx] = S[(int64_t)ly * sstep + lx];
+        }
     }
     __syncthreads();
     const int lx = threadIdx.x & (RA_OW - 1), ly = threadIdx.x / RA_OW;
