@@ -166,10 +166,11 @@ hipError_t launch_canny_hysteresis(uint8_t *d_map, int rows, int cols, int n, in
 
 // ------------------------------------------------------------------------------------------
 // raster-order point list (hough.cpp stage 1) and the tiled mask
-__host__ __device__ __forceinline__ int64_t mask_offset(int y, int x, int tiles_x)
+__host__ __device__ __forceinline__ int64_t mask_word(int y, int x, int tiles_x)
 {
-    return ((int64_t)(y >> 3) * tiles_x + (x >> 3)) * 64 + (y & 7) * 8 + (x & 7);
+    return (int64_t)(y >> 3) * tiles_x + (x >> 3);
 }
+__host__ __device__ __forceinline__ int mask_bit(int y, int x) { return (y & 7) * 8 + (x & 7); }
 
 __device__ __forceinline__ int block_sum_256(int v, int *sh)
 {
@@ -254,8 +255,14 @@ __global__ __launch_bounds__(256) void edges_compact_kernel(const uint8_t *__res
     for (int xb = 0; xb < cols; xb += 256) {
         const int x = xb + threadIdx.x;
         const bool f = x < cols && p[x] != 0;
-        if (x < cols) tiled[ppht_mask_bytes(rows, cols) * scan + mask_offset(y, x, ppht_tiles_x(cols))] = f ? 1 : 0;
         const unsigned long long m = __ballot(f);
+        if ((lane & 7) == 0 && x < cols) {  // this lane's 8 pixels = one row of a tile
+            const unsigned long long byte = (m >> lane) & 0xffull;
+            if (byte)
+                atomicOr((unsigned long long *)tiled + (ppht_mask_bytes(rows, cols) / 8) * scan +
+                             mask_word(y, x, ppht_tiles_x(cols)),
+                         byte << ((y & 7) * 8));
+        }
         __syncthreads();
         if (lane == 0) sh[wave] = __popcll(m);
         __syncthreads();
@@ -300,14 +307,16 @@ struct PphtShared {
     int pts[OMR_PPHT_THREADS];     // points to un-vote in this round (y << 16 | x)
 };
 
-// device-scope accesses: served by L2, so a wave sees what other waves stored before the last barrier
-__device__ __forceinline__ uint8_t mask_load(const uint8_t *p)
+// device-scope accesses: served by L2, so a wave sees what other waves did before the last barrier
+__device__ __forceinline__ bool mask_test(const unsigned long long *mask, int y, int x, int tx)
 {
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long w = __hip_atomic_load(mask + mask_word(y, x, tx), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return (w >> mask_bit(y, x)) & 1ull;
 }
-__device__ __forceinline__ void mask_clear(uint8_t *p)
+__device__ __forceinline__ void mask_clear(unsigned long long *mask, int y, int x, int tx)
 {
-    __hip_atomic_store(p, (uint8_t)0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // several lanes may clear bits of one word: atomic AND, no return value
+    __hip_atomic_fetch_and(mask + mask_word(y, x, tx), ~(1ull << mask_bit(y, x)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 __device__ __forceinline__ uint32_t list_load(const uint32_t *p)
 {
@@ -323,7 +332,7 @@ __global__ __launch_bounds__(OMR_PPHT_THREADS) void ppht_kernel(const PphtArgs a
     __shared__ PphtShared sh;
     const int scan = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int W = a.width, H = a.height;
-    uint8_t *mask = a.mask + (int64_t)scan * ppht_mask_bytes(H, W);
+    unsigned long long *mask = (unsigned long long *)a.mask + (int64_t)scan * (ppht_mask_bytes(H, W) / 8);
     const int TX = ppht_tiles_x(W);
     uint32_t *nz = a.nz + a.scan_off[scan];
     int32_t *accum = a.accum + (int64_t)scan * a.numangle * a.numrho;
@@ -387,7 +396,7 @@ __global__ __launch_bounds__(OMR_PPHT_THREADS) void ppht_kernel(const PphtArgs a
                 }
                 count -= nd;
                 pt = p;
-                const bool on = act && mask_load(mask + mask_offset((int)(p >> 16), (int)(p & 0xffffu), TX)) != 0;
+                const bool on = act && mask_test(mask, (int)(p >> 16), (int)(p & 0xffffu), TX);
                 pend = __ballot(on);
             }
             int pi = -1, pj = -1;
@@ -449,7 +458,7 @@ __global__ __launch_bounds__(OMR_PPHT_THREADS) void ppht_kernel(const PphtArgs a
                     const int x = x0 + t * dx, y = y0 + t * dy;
                     const int j1 = wk.xflag ? x : x >> 16, i1 = wk.xflag ? y >> 16 : y;
                     out = j1 < 0 || j1 >= W || i1 < 0 || i1 >= H;
-                    on = !out && mask_load(mask + mask_offset(i1, j1, TX)) != 0;
+                    on = !out && mask_test(mask, i1, j1, TX);
                 }
                 if (base == 0) on0 = on;
                 const unsigned long long bn = __ballot(on), bo = __ballot(out);
@@ -510,11 +519,10 @@ __global__ __launch_bounds__(OMR_PPHT_THREADS) void ppht_kernel(const PphtArgs a
                 if (t <= last && !(dir == 1 && t == 0)) {  // step 0 belongs to direction 0
                     const int x = x0 + t * dx, y = y0 + t * dy;
                     const int j1 = wk.xflag ? x : x >> 16, i1 = wk.xflag ? y >> 16 : y;
-                    uint8_t *m = mask + mask_offset(i1, j1, TX);
-                    on = base == 0 ? on0 : mask_load(m) != 0;
+                    on = base == 0 ? on0 : mask_test(mask, i1, j1, TX);
                     if (on) {
                         ptw = ((uint32_t)i1 << 16) | (uint32_t)j1;
-                        mask_clear(m);
+                        mask_clear(mask, i1, j1, TX);
                     }
                 }
                 if (good) {  // block-uniform
@@ -582,7 +590,7 @@ __global__ __launch_bounds__(OMR_PPHT_THREADS) void ppht_kernel(const PphtArgs a
         }
         __syncthreads();  // erasures are complete: wave 0 re-tests the points it still holds
         if (wave == 0 && pend) {
-            const bool on = ((pend >> lane) & 1ull) && mask_load(mask + mask_offset((int)(pt >> 16), (int)(pt & 0xffffu), TX)) != 0;
+            const bool on = ((pend >> lane) & 1ull) && mask_test(mask, (int)(pt >> 16), (int)(pt & 0xffffu), TX);
             pend = __ballot(on);
         }
     }

@@ -22,18 +22,19 @@ hipError_t launch_edges_rowcount(uint8_t *d_map, int rows, int cols, int n, int 
 hipError_t launch_edges_rowscan(const int32_t *d_rowcnt, int rows, int n, int32_t *d_rowoff, int32_t *d_total,
                                 hipStream_t s);
 // raster-order list of the non-zero pixels: nz[scan_off[scan] + k] = y << 16 | x, and the mask of the
-// Hough stage in 8x8-pixel tiles (one 64-byte line per tile: a line walk of 128 steps touches ~16
-// lines instead of up to 128): byte of (y, x) = ((y >> 3) * tiles_x + (x >> 3)) * 64 + (y & 7) * 8 + (x & 7)
+// Hough stage, one bit per pixel in 8x8-pixel tiles of one 64-bit word each (a line walk of 128 steps
+// touches a few dozen words; an A4 scan's mask is 1.1 MB): bit (y & 7) * 8 + (x & 7) of word
+// (y >> 3) * tiles_x + (x >> 3).  d_mask_tiled must be zeroed before the call.
 hipError_t launch_edges_compact(const uint8_t *d_edges, int rows, int cols, int n, const int32_t *d_rowoff,
                                 const int64_t *d_scan_off, uint32_t *d_nz, uint8_t *d_mask_tiled, hipStream_t s);
 __host__ __device__ inline int ppht_tiles_x(int cols) { return (cols + 7) / 8; }
-__host__ __device__ inline int64_t ppht_mask_bytes(int rows, int cols) { return (int64_t)((rows + 7) / 8) * ppht_tiles_x(cols) * 64; }
+__host__ __device__ inline int64_t ppht_mask_bytes(int rows, int cols) { return (int64_t)((rows + 7) / 8) * ppht_tiles_x(cols) * 8; }
 
 struct PphtWalk {  // per accumulator angle: the line walk of hough.cpp (16.16 fixed point)
     int32_t xflag, dx0, dy0, pad;
 };
 struct PphtArgs {
-    uint8_t *mask;            // n x ppht_mask_bytes(), 8x8 tiles, non-zero = point still available (destroyed)
+    uint8_t *mask;            // n x ppht_mask_bytes(): 64-bit words of 8x8 pixels, bit set = point still available
     int32_t width, height;
     uint32_t *nz;             // point lists (destroyed)
     const int64_t *scan_off;  // [n] offset of a scan's list in nz

@@ -131,6 +131,7 @@ int ppht_device(uint8_t *d_edges, int32_t *d_rowcnt, int rows, int cols, int n, 
     OMR_HIP(nz.alloc(sizeof(uint32_t) * (size_t)std::max<int64_t>(sum, 1)));
     OMR_HIP(hipMemcpyAsync(scanoff.p, off.data(), sizeof(int64_t) * (size_t)n, hipMemcpyHostToDevice, s));
     OMR_HIP(tiled.alloc((size_t)n * (size_t)ppht_mask_bytes(rows, cols)));
+    OMR_HIP(hipMemsetAsync(tiled.p, 0, tiled.bytes, s));
     OMR_HIP(launch_edges_compact(d_edges, rows, cols, n, rowoff.as<int32_t>(), scanoff.as<int64_t>(), nz.as<uint32_t>(),
                                  tiled.as<uint8_t>(), s));
     OMR_HIP(d_ttab.alloc(sizeof(float) * ttab.size()));
