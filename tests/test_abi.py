@@ -93,3 +93,22 @@ def test_bad_arguments_are_errors_not_crashes():
         oics.projection.SweepPlan(40000, 10, 5, 0.5)
     with pytest.raises(oics.OmrError):
         oics.projection.SweepPlan(10, 10, 1, 2.0)  # empty candidate range
+
+
+def test_plain_c_example_builds_and_runs(tmp_path):
+    """examples/deskew_c_abi.c: the boundary from plain C (gcc, no torch, no Python).  Without a GPU the
+    first compute call must answer -217; with one the program deskews its synthetic sheet."""
+    import shutil
+    import subprocess
+    if not shutil.which("gcc"):
+        pytest.skip("gcc not available")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    libdir = os.path.join(root, "omr-img-corrector_amd", "lib")
+    exe = str(tmp_path / "deskew_c_abi")
+    subprocess.check_call(["gcc", "-std=c11", "-O2", "-Wall", "-I", os.path.join(root, "include"),
+                           os.path.join(root, "examples", "deskew_c_abi.c"), "-o", exe, "-L", libdir, "-lomrdeskew",
+                           "-Wl,-rpath," + libdir, "-lm"])
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "libomrdeskew version" in r.stdout
+    assert ("-217" in r.stdout) or ("correct_default" in r.stdout and "rc 0" in r.stdout)
