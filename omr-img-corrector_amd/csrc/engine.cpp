@@ -293,8 +293,7 @@ int SweepTables::build_runs()
     NWh = (cols + 31) / 32;
     Gh = (NWh + OMR_RUN_K - 1) / OMR_RUN_K;
     const size_t tab_bytes = (size_t)A * (size_t)NWh * sizeof(RunTab);
-    const char *off = getenv("OMR_DISABLE_RUNS");
-    if ((off && off[0] == '1') || tab_bytes > ((size_t)3 << 30)) return OMR_OK;  // gather kernels only
+    if (tab_bytes > ((size_t)3 << 30)) return OMR_OK;  // gather kernels only
     OMR_HIP(tabsH.alloc(sizeof(RunTab) * (size_t)A * NWh));
     OMR_HIP(metaH.alloc(sizeof(RunMeta) * (size_t)A * NWh));
     OMR_HIP(blkH.alloc(sizeof(RunBlk) * (size_t)A * Gh));
@@ -323,6 +322,7 @@ int SweepTables::build_runs()
     std::vector<RunMeta> mh((size_t)A * NWh);
     OMR_HIP(hipMemcpy(g.data(), gd.p, sizeof(int32_t) * (size_t)A, hipMemcpyDeviceToHost));
     OMR_HIP(hipMemcpy(mh.data(), metaH.p, sizeof(RunMeta) * mh.size(), hipMemcpyDeviceToHost));
+#ifdef OMR_RUNS_DEBUG
     if (getenv("OMR_DEBUG")) {
         int ng = 0, nh = 0;
         for (int a = 0; a < A; a++) {
@@ -334,6 +334,7 @@ int SweepTables::build_runs()
         fprintf(stderr, "[omr] runs: A=%d guard-fail=%d meta-bad=%d | [0,0]: nlev=%d smax=%d ok=%d\n", A, ng, nh,
                 mh[0].nlev, mh[0].smax, mh[0].ok);
     }
+#endif
     std::vector<int32_t> lr, lg;
     for (int a = 0; a < A; a++) {
         bool ok = g[a] == 0;

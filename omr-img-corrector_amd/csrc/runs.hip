@@ -24,6 +24,14 @@
 
 namespace omr {
 
+// Development switches exist only in the debug build (`make debug`, -DOMR_RUNS_DEBUG, loaded by
+// tools/kstamps.py): a release library reads no environment variable and has no stage-skipping path.
+#ifdef OMR_RUNS_DEBUG
+#define RUN_DBG(p) ((p).dbg)
+#else
+#define RUN_DBG(p) 0
+#endif
+
 #define RUN_K OMR_RUN_K    // destination words per block column group (kernels.hpp)
 #define RUN_BAND 512       // destination rows per band (8 waves x 64 lanes)
 #define RUN_QUADS ((RUN_K * 32 + 127 + 96) / 128 + 2)  // aligned 4-word pieces per window row
@@ -657,7 +665,7 @@ __global__ __launch_bounds__(RUN_BAND, 4) void runs_kernel(const RunPass p, cons
         const int r = yb + wave * 64 + lane;
         __syncthreads();  // previous band's readers are done (first pass: tables, meta, colacc staged)
         if (cur.fits) {
-            if (!(p.dbg & 2)) commit(cur);
+            if (!(RUN_DBG(p) & 2)) commit(cur);
         } else if (tid == 0) {
             guard[a] = 1;
         }
@@ -667,12 +675,12 @@ __global__ __launch_bounds__(RUN_BAND, 4) void runs_kernel(const RunPass p, cons
         const int2_t rt_now = rt;
         if (yb + RUN_BAND < p.NR) {
             cur = geometry(cn0, cn1);
-            if (!(p.dbg & 2)) prefetch(cur);
+            if (!(RUN_DBG(p) & 2)) prefetch(cur);
             corners(yb + 2 * RUN_BAND, cn0, cn1);
             rt = RT[min(r + RUN_BAND, p.NR - 1)];
         }
         RUN_STAMP(2)
-        if (now.fits && yb + wave * 64 < p.NR && !(p.dbg & 1)) {
+        if (now.fits && yb + wave * 64 < p.NR && !(RUN_DBG(p) & 1)) {
             const int rx = rt_now.x - (now.wxw << 15);  // window-local fixed point
             const int ry = rt_now.y - (now.wy0 << 10);
             const uint32_t lane_ok = r < p.NR ? 0xffffffffu : 0u;  // rows past the end count nothing
@@ -683,7 +691,7 @@ __global__ __launch_bounds__(RUN_BAND, 4) void runs_kernel(const RunPass p, cons
         // the 3-plane counters hold at most 7 rows per lane: reduce them across lanes in time
         if (++bands_pending == RUN_FLUSH_BANDS || yb + RUN_BAND >= p.NR) {
             bands_pending = 0;
-            if (!(p.dbg & 4)) flush_columns(lds, c0, c1, c2, colacc, tid);
+            if (!(RUN_DBG(p) & 4)) flush_columns(lds, c0, c1, c2, colacc, tid);
             RUN_STAMP(4)
         }
     }
@@ -701,6 +709,11 @@ __global__ __launch_bounds__(RUN_BAND, 4) void runs_kernel(const RunPass p, cons
 
 hipError_t debug_runs_stamps(unsigned long long out[8], bool reset)
 {
+#ifndef OMR_RUNS_DEBUG
+    (void)out;
+    (void)reset;
+    return hipErrorNotSupported;  // release build: no stamp variant is compiled in
+#endif
     hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_run_stamps), 8 * sizeof(unsigned long long));
     if (e == hipSuccess && reset) {
         unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -714,12 +727,17 @@ hipError_t launch_runs(const RunPass &p0, const int32_t *d_list, int n_list, int
 {
     if (n_list <= 0) return hipSuccess;
     RunPass p = p0;
+#ifdef OMR_RUNS_DEBUG
     {
         const char *e = getenv("OMR_RUNS_DBG");
         p.dbg = e ? atoi(e) : 0;
     }
-    // per device and idempotent; cheap enough to repeat (the batch entry points use every device)
     auto *kern = (p.dbg & 8) ? runs_kernel<true> : runs_kernel<false>;
+#else
+    p.dbg = 0;
+    auto *kern = runs_kernel<false>;
+#endif
+    // per device and idempotent; cheap enough to repeat (the batch entry points use every device)
     hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, RUN_LDS_BYTES);
     if (e != hipSuccess) return e;
     if (p.scans < 1) p.scans = 1;

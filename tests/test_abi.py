@@ -12,6 +12,7 @@ import oics
 from oics import _lib
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "omr-img-corrector_amd")
 
 
 def header_symbols():
@@ -112,3 +113,19 @@ def test_plain_c_example_builds_and_runs(tmp_path):
     assert r.returncode == 0, r.stdout + r.stderr
     assert "libomrdeskew version" in r.stdout
     assert ("-217" in r.stdout) or ("correct_default" in r.stdout and "rc 0" in r.stdout)
+
+
+def test_release_library_has_no_debug_switches():
+    """Round-1 advice: OMR_RUNS_DBG made the sweep kernel skip stages (wrong projections, rc 0) from a
+    stray environment variable.  The switches now exist only under -DOMR_RUNS_DEBUG (`make debug`);
+    the shipped library must not even contain their names, and must read no OMR_* switch but the pool
+    size."""
+    import re
+    blob = open(os.path.join(PKG, "lib", "libomrdeskew.so"), "rb").read()
+    for name in (b"OMR_RUNS_DBG", b"OMR_DISABLE_RUNS", b"OMR_DEBUG"):
+        assert name not in blob, name
+    envs = set(re.findall(rb"OMR_[A-Z_]{3,}", blob))
+    assert envs <= {b"OMR_POOL_MB"}, envs
+    src = open(os.path.join(PKG, "csrc", "runs.hip")).read()
+    rel = src.split("#ifdef OMR_RUNS_DEBUG\n    {\n        const char *e = getenv", 1)
+    assert len(rel) == 2 and "getenv" not in rel[0].split("hipError_t launch_runs", 1)[1]

@@ -1,0 +1,53 @@
+"""bench.py's own N-rank launch, rehearsed on CPU (`--dry-run`: gloo ranks, no GPU work).
+
+`python bench.py --gpus N` without a torchrun environment must start N rank processes itself (before
+any GPU call) and report n_gpus == N; a --gpus / WORLD_SIZE mismatch must be an error, never a silent
+single-GPU measurement (round-1 verdict, weak item 4)."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _env(**kw):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(kw)
+    return env
+
+
+def test_gpus2_spawns_two_ranks_and_gathers():
+    p = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--dry-run", "--scans", "5", "--steps", "3"],
+                       env=_env(), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    lines = [ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, "exactly one JSON line"
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["dry_run"] is True
+    assert rec["shard_sizes"] == [5, 5] and rec["gathered_results"] == 10  # weak scaling: --scans per rank
+    assert rec["config"]["global_batch"] == 10 and rec["scaling"] == "weak"
+    assert "spawned 2 rank processes" in rec["launcher"]
+
+
+def test_world_size_mismatch_is_an_error():
+    # a torchrun-like environment that disagrees with --gpus: must exit non-zero, not run single-rank
+    p = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--dry-run"], env=_env(WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"),
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert p.returncode != 0
+    assert b"does not match WORLD_SIZE" in p.stderr + p.stdout
+    p = subprocess.run([sys.executable, BENCH, "--gpus", "1", "--no-pmc", "--dry-run"],
+                       env=_env(WORLD_SIZE="2", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="1"),
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=60)
+    assert p.returncode != 0
+
+
+def test_launcher_parent_never_touches_the_gpu():
+    """The parent of the rank processes must not import torch or the HIP library (a process that has
+    initialised the GPU must not start others by exec; and the ranks own the devices)."""
+    src = open(BENCH).read()
+    head = src.split("def launch_ranks", 1)[0]
+    assert "import torch" not in head and "oics.lib()" not in head
+    body = src.split("def launch_ranks", 1)[1].split("\ndef ", 1)[0]
+    assert "import torch" not in body and "import oics" not in body and "from oics" not in body

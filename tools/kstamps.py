@@ -1,12 +1,15 @@
-"""Phase shares of runs_kernel (diagnostic build path: OMR_RUNS_DBG=8)."""
+"""Phase shares of runs_kernel.  Needs the DEBUG library (`make -C omr-img-corrector_amd/csrc debug`,
+-DOMR_RUNS_DEBUG): the release library has neither the stamp variant nor any environment switch.
+This script points the ctypes loader at lib/libomrdeskew_dbg.so explicitly."""
 import ctypes as C, os, sys
 os.environ["OMR_RUNS_DBG"] = "8"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "omr-img-corrector_amd"))
 import numpy as np, torch
+from oics import _lib as _l
+_l.LIB_PATH = os.path.join(os.path.dirname(_l.LIB_PATH), "libomrdeskew_dbg.so")  # before the first lib() call
 from oics import projection, synth
-from oics._lib import LIB_PATH
-L = C.CDLL(LIB_PATH)
+L = C.CDLL(_l.LIB_PATH)
 ROWS, COLS = 3508, 2480
 g, th = synth.make_card(ROWS, COLS, 2)
 d = torch.from_numpy(g).to("cuda:0")
