@@ -57,7 +57,11 @@ hipError_t launch_sweep_lds(const uint32_t *d_bits, SweepDims d, const int32_t *
 #define OMR_RUN_K 8  // destination words per run-merging block (partials are per group of OMR_RUN_K words)
 #endif
 struct RunTab {                        // per (candidate, 32-column word); 3648 B, 16-B aligned
-    uint32_t tupY[OMR_RUN_TUPLES][8];  // [id][level]: destination bits that read source row level
+    // [id][level]: destination bits that read source row `level`; levels 0-3 and 4-7 are kept in two planes of
+    // 16-byte entries: a wave's lanes use up to ~14 consecutive ids at once, and 32-byte entries put ids 8
+    // apart on the same LDS banks (ds_read_b128 conflicts); at 16 bytes only ids 16 apart collide
+    uint32_t tupYlo[OMR_RUN_TUPLES][4];
+    uint32_t tupYhi[OMR_RUN_TUPLES][4];
     uint32_t tupX[OMR_RUN_TUPLES][2];  // [id][s-1]:   destination bits whose source column lags by s
     uint8_t idxY[1024];                // row-coordinate fraction -> tupY id
     uint8_t idxX[1024];                // bit-coordinate fraction -> tupX id

@@ -39,6 +39,7 @@ namespace omr {
 #define RUN_PITCHB (RUN_PITCH * 4)
 #define RUN_WIN_ROWS 588   // window rows; 588 x 84 B also holds the 8 x 3 x 512 counter words of a flush
 #define RUN_TAB_BYTES 3648
+#define RUN_TUPHI_OFS 640
 #define RUN_TUPX_OFS 1280
 #define RUN_IDXY_OFS 1600
 #define RUN_IDXX_OFS 2624
@@ -140,8 +141,14 @@ __global__ __launch_bounds__(1024) void runtab_kernel(const int32_t *__restrict_
         bad = true;
         idy = 0;
     } else if (change) {
+        // destination bits that exist (last word of a row): folded into the level masks, so the sweep
+        // kernel needs no per-word validity mask (the lag merge happens before the level select)
+        const uint32_t valid = (c0 + 32 <= NC) ? 0xffffffffu : ((1u << (NC - c0)) - 1u);
 #pragma unroll
-        for (int lv = 0; lv < 8; lv++) T->tupY[idy][lv] = my[lv];
+        for (int lv = 0; lv < 4; lv++) {
+            T->tupYlo[idy][lv] = my[lv] & valid;
+            T->tupYhi[idy][lv] = my[lv + 4] & valid;
+        }
     }
     T->idxY[f] = (uint8_t)idy;
     // ---- column-lag masks of this fraction: st(i) = -((f - ea(i)) >> 10), ea(i) = 1024 i - ca(i)
@@ -238,7 +245,32 @@ hipError_t launch_runtab(const int32_t *d_CA, const int32_t *d_CB, int A, int NC
 //                  bands); the counters are reduced across the 64 lanes with one
 //                  v_add_co_u32 (shift + carry-out = ballot of the top bit) and one s_bcnt1 per bit,
 //                  added up in LDS over the 8 waves and stored once per block (no atomics).
-__device__ __forceinline__ uint32_t lds_u8(const char *lds, int ofs) { return *(const uint8_t *)(lds + ofs); }
+// LDS accesses of the inner loop take INTEGER byte addresses (the dynamic segment starts at LDS address
+// 0, checked once per block): table offsets then fold into the ds_read immediates and no per-access
+// "base + offset" VALU add is left.
+typedef __attribute__((address_space(3))) const uint8_t lds_cu8;
+typedef __attribute__((address_space(3))) const uint32_t lds_cu32;
+typedef uint32_t v2u32 __attribute__((ext_vector_type(2)));
+typedef uint32_t v4u32 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) const v2u32 lds_cu2;
+typedef __attribute__((address_space(3))) const v4u32 lds_cu4;
+__device__ __forceinline__ uint32_t ldsr_u8(uint32_t a) { return *(lds_cu8 *)(uintptr_t)a; }
+__device__ __forceinline__ uint32_t ldsr_u32(uint32_t a) { return *(lds_cu32 *)(uintptr_t)a; }
+__device__ __forceinline__ uint2 ldsr_u2(uint32_t a)
+{
+    const v2u32 v = *(lds_cu2 *)(uintptr_t)a;
+    return make_uint2(v.x, v.y);
+}
+__device__ __forceinline__ uint4 ldsr_u4(uint32_t a)
+{
+    const v4u32 v = *(lds_cu4 *)(uintptr_t)a;
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ int4 ldsr_i4(uint32_t a)
+{
+    const v4u32 v = *(lds_cu4 *)(uintptr_t)a;
+    return make_int4((int)v.x, (int)v.y, (int)v.z, (int)v.w);
+}
 
 template <int LANE>
 __device__ __forceinline__ uint32_t write_lane_imm(uint32_t vreg, uint32_t value)
@@ -280,16 +312,22 @@ __device__ __forceinline__ uint32_t shl1_sum6(uint32_t &p0, uint32_t &p1, uint32
     return n;
 }
 
+// Issue costs that shaped this loop (tools/valu_ops.hip on MI355X, >= 2 waves per SIMD; profiles/r02_valu_issue.md):
+// only the plain two-VGPR-source VOP2 ops (v_add/sub, v_and/or/xor, v_lshrrev, v_ashrrev, v_mov) issue in
+// 2 cycles per wave64; every VOP3 op (v_alignbit, v_bfi, v_and_or, v_lshl_add, v_mad_u32_u24, v_bcnt, v_bfe),
+// v_lshlrev_b32, v_mul_u32_u24 and any VOP2 with an SGPR source take 4; v_cndmask on an SGPR mask far more.
+// One word = 22 cycles of addressing + (8 NLEV - 2) of merge + 10 of column counters + 4 of row count.
+
 // one word: NLEV unaligned 32-bit windows -> destination word
 template <int NLEV, int SMAX>
-__device__ __forceinline__ uint32_t merge_word(const uint32_t *d0, const uint32_t *d1, const uint32_t sh,
-                                               const uint4 s03, const uint4 s47, const uint2 sx)
+__device__ __forceinline__ uint32_t merge_word(const uint2 (&d)[NLEV], const uint32_t sh, const uint4 s03, const uint4 s47,
+                                               const uint2 sx)
 {
     const uint32_t sel[8] = {s03.x, s03.y, s03.z, s03.w, s47.x, s47.y, s47.z, s47.w};
     uint32_t D = 0;
 #pragma unroll
     for (int lv = 0; lv < NLEV; lv++) {
-        const uint32_t W = __builtin_amdgcn_alignbit(d1[lv], d0[lv], sh);
+        const uint32_t W = __builtin_amdgcn_alignbit(d[lv].y, d[lv].x, sh);  // uses sh & 31
         uint32_t U = W;
         if (SMAX >= 1) U = (sx.x & (W << 1)) | (~sx.x & U);
         if (SMAX >= 2) U = (sx.y & (W << 2)) | (~sx.y & U);
@@ -298,120 +336,118 @@ __device__ __forceinline__ uint32_t merge_word(const uint32_t *d0, const uint32_
     return D;
 }
 
-// The RUN_K words of one band for one wave.  NLEV / SMAX are uniform for the whole block (maxima
-// over its words; unused levels have empty masks), so the block dispatches once per band to a
-// straight-line specialisation.  Words are processed two at a time: both fraction look-ups and all
-// 2 x NLEV window reads are issued before anything is consumed (LDS latency hiding at 4 waves per
-// SIMD).  Words past the end of the row are exact copies of the last real word with an empty mask.
-// One pair of words of one band for one wave.  Both fraction look-ups and all 2 x NLEV window reads
-// are issued before anything is consumed (LDS latency hiding at 4 waves per SIMD).  Words past the
-// end of the row are exact copies of the last real word with an empty mask.
+// bit-sliced add of a 1-bit value per column into a 3-plane counter: five 2-cycle ops
+__device__ __forceinline__ void count_columns(uint32_t &c0, uint32_t &c1, uint32_t &c2, const uint32_t D)
+{
+    const uint32_t t = c0 & D;
+    c0 ^= D;
+    const uint32_t u = c1 & t;
+    c1 ^= t;
+    c2 |= u;
+}
+
+// One pair of words of one band for one wave.  Both words are in flight together: both fraction
+// look-ups and all 2 x NLEV window reads are issued before anything is consumed (LDS latency hiding at
+// 4 waves per SIMD).  Words past the end of the row were staged with
+// empty level masks, the last word's masks carry the row-end mask (runtab_kernel), rows past the end
+// of the image are EXEC-masked by the caller: nothing to mask here.
 template <int NLEV, int SMAX, int K>
-__device__ __forceinline__ uint32_t pair_words(const char *lds, const int rx, const int ry, const int kw,
-                                               const uint32_t valid_last, const uint32_t lane_ok,
-                                               uint32_t (&c0)[RUN_K], uint32_t (&c1)[RUN_K], uint32_t (&c2)[RUN_K])
+__device__ __forceinline__ uint32_t pair_words(const int rx, const int ry, uint32_t (&c0)[RUN_K], uint32_t (&c1)[RUN_K],
+                                               uint32_t (&c2)[RUN_K])
 {
     constexpr int k = K;
-    const int2 ma = *(const int2 *)(lds + RUN_META_OFS + k * 8);  // same address in every lane
-    const int2 mb = *(const int2 *)(lds + RUN_META_OFS + (k + 1) * 8);
-    const int ta = RUN_TABS_OFS + k * RUN_TAB_BYTES, tb = ta + RUN_TAB_BYTES;
-    const int A0a = rx + ma.x, B0a = ry + ma.y, A0b = rx + mb.x, B0b = ry + mb.y;
-    const uint32_t idya = lds_u8(lds, ta + RUN_IDXY_OFS + (B0a & 1023));
-    const uint32_t idyb = lds_u8(lds, tb + RUN_IDXY_OFS + (B0b & 1023));
+    constexpr uint32_t ta = RUN_TABS_OFS + k * RUN_TAB_BYTES, tb = ta + RUN_TAB_BYTES;
+    const int4 m = ldsr_i4(RUN_META_OFS + k * 8);  // (ca0, cb0) of both words: same address in every lane
+    const int A0a = rx + m.x, B0a = ry + m.y, A0b = rx + m.z, B0b = ry + m.w;
+    uint32_t Da, Db;
+    const uint32_t idya = ldsr_u8(ta + RUN_IDXY_OFS + (uint32_t)(B0a & 1023));
+    const uint32_t idyb = ldsr_u8(tb + RUN_IDXY_OFS + (uint32_t)(B0b & 1023));
     uint32_t idxa = 0, idxb = 0;
     if (SMAX > 0) {
-        idxa = lds_u8(lds, ta + RUN_IDXX_OFS + (A0a & 1023));
-        idxb = lds_u8(lds, tb + RUN_IDXX_OFS + (A0b & 1023));
+        idxa = ldsr_u8(ta + RUN_IDXX_OFS + (uint32_t)(A0a & 1023));
+        idxb = ldsr_u8(tb + RUN_IDXX_OFS + (uint32_t)(A0b & 1023));
     }
-    const int addra = RUN_WIN_OFS + __mul24(B0a >> 10, RUN_PITCHB) + ((A0a >> 13) & ~3);
-    const int addrb = RUN_WIN_OFS + __mul24(B0b >> 10, RUN_PITCHB) + ((A0b >> 13) & ~3);
-    uint32_t a0[NLEV], a1[NLEV], b0[NLEV], b1[NLEV];
+    // window byte address: row * pitch + first word * 4 (v_mad_i32_i24; window-local coordinates are >= 0)
+    const uint32_t addra = RUN_WIN_OFS + (uint32_t)(__mul24(B0a >> 10, RUN_PITCHB) + ((A0a >> 13) & ~3));
+    const uint32_t addrb = RUN_WIN_OFS + (uint32_t)(__mul24(B0b >> 10, RUN_PITCHB) + ((A0b >> 13) & ~3));
+    uint2 wa[NLEV], wb[NLEV];
+#pragma unroll
+    for (int lv = 0; lv < NLEV; lv++) {  // two adjacent dwords, 4-byte aligned: ds_read2_b32
+        wa[lv].x = ldsr_u32(addra + lv * RUN_PITCHB);
+        wa[lv].y = ldsr_u32(addra + lv * RUN_PITCHB + 4);
+    }
 #pragma unroll
     for (int lv = 0; lv < NLEV; lv++) {
-        a0[lv] = *(const uint32_t *)(lds + addra + lv * RUN_PITCHB);
-        a1[lv] = *(const uint32_t *)(lds + addra + lv * RUN_PITCHB + 4);
+        wb[lv].x = ldsr_u32(addrb + lv * RUN_PITCHB);
+        wb[lv].y = ldsr_u32(addrb + lv * RUN_PITCHB + 4);
     }
-#pragma unroll
-    for (int lv = 0; lv < NLEV; lv++) {
-        b0[lv] = *(const uint32_t *)(lds + addrb + lv * RUN_PITCHB);
-        b1[lv] = *(const uint32_t *)(lds + addrb + lv * RUN_PITCHB + 4);
-    }
-    const uint4 *tya = (const uint4 *)(lds + ta + (idya << 5));
-    const uint4 *tyb = (const uint4 *)(lds + tb + (idyb << 5));
     const uint4 z4 = make_uint4(0, 0, 0, 0);
-    const uint4 sa03 = tya[0], sa47 = NLEV > 4 ? tya[1] : z4;
-    const uint4 sb03 = tyb[0], sb47 = NLEV > 4 ? tyb[1] : z4;
+    const uint32_t tya = ta + (idya << 4), tyb = tb + (idyb << 4);
+    const uint4 sa03 = ldsr_u4(tya), sa47 = NLEV > 4 ? ldsr_u4(tya + RUN_TUPHI_OFS) : z4;
+    const uint4 sb03 = ldsr_u4(tyb), sb47 = NLEV > 4 ? ldsr_u4(tyb + RUN_TUPHI_OFS) : z4;
     uint2 sxa = make_uint2(0, 0), sxb = make_uint2(0, 0);
     if (SMAX > 0) {
-        sxa = *(const uint2 *)(lds + ta + RUN_TUPX_OFS + (idxa << 3));
-        sxb = *(const uint2 *)(lds + tb + RUN_TUPX_OFS + (idxb << 3));
+        sxa = ldsr_u2(ta + RUN_TUPX_OFS + (idxa << 3));
+        sxb = ldsr_u2(tb + RUN_TUPX_OFS + (idxb << 3));
     }
-    // word masks: everything for words before the row's last, `valid` for the last, nothing after
-    const uint32_t wma = k < kw - 1 ? 0xffffffffu : (k == kw - 1 ? valid_last : 0u);
-    const uint32_t wmb = k + 1 < kw - 1 ? 0xffffffffu : (k + 1 == kw - 1 ? valid_last : 0u);
-    const uint32_t Da = merge_word<NLEV, SMAX>(a0, a1, (uint32_t)(A0a >> 10), sa03, sa47, sxa) & wma & lane_ok;
-    const uint32_t Db = merge_word<NLEV, SMAX>(b0, b1, (uint32_t)(A0b >> 10), sb03, sb47, sxb) & wmb & lane_ok;
-    // bit-sliced add of a 1-bit value per column into the 3-plane counters (K is a constant, so the
-    // counters stay in registers)
-    uint32_t t = c0[k] & Da;
-    c2[k] |= c1[k] & t;
-    c1[k] ^= t;
-    c0[k] ^= Da;
-    t = c0[k + 1] & Db;
-    c2[k + 1] |= c1[k + 1] & t;
-    c1[k + 1] ^= t;
-    c0[k + 1] ^= Db;
+#ifdef RUN_FENCE_MERGE
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+    Da = merge_word<NLEV, SMAX>(wa, (uint32_t)A0a >> 10, sa03, sa47, sxa);
+#ifdef RUN_FENCE_MERGE
+    count_columns(c0[k], c1[k], c2[k], Da);
+    __builtin_amdgcn_sched_barrier(0);
+    Db = merge_word<NLEV, SMAX>(wb, (uint32_t)A0b >> 10, sb03, sb47, sxb);
+#else
+    Db = merge_word<NLEV, SMAX>(wb, (uint32_t)A0b >> 10, sb03, sb47, sxb);
+    count_columns(c0[k], c1[k], c2[k], Da);
+#endif
+    count_columns(c0[k + 1], c1[k + 1], c2[k + 1], Db);
     return __popc(Da) + __popc(Db);
 }
 
 // A pair's column lag bound (0, 1 or 2; wave-uniform) picks its specialisation: most words of a
 // candidate need no lag handling even when some word of the block does.
 template <int NLEV, int K>
-__device__ __forceinline__ uint32_t pair_dispatch(const char *lds, const int rx, const int ry, const int kw,
-                                                  const uint32_t valid_last, const uint32_t lane_ok,
-                                                  uint32_t (&c0)[RUN_K], uint32_t (&c1)[RUN_K], uint32_t (&c2)[RUN_K],
-                                                  const int lagbits)
+__device__ __forceinline__ uint32_t pair_dispatch(const int rx, const int ry, uint32_t (&c0)[RUN_K],
+                                                  uint32_t (&c1)[RUN_K], uint32_t (&c2)[RUN_K], const int lagbits)
 {
     // keep the pairs apart: without this fence the scheduler hoists all four pairs' loads and the
     // kernel needs 180 VGPRs (2 waves per SIMD instead of 4)
     __builtin_amdgcn_sched_barrier(0);
     const int lag = (lagbits >> K) & 3;
-    if (lag == 0) return pair_words<NLEV, 0, K>(lds, rx, ry, kw, valid_last, lane_ok, c0, c1, c2);
-    if (lag == 1) return pair_words<NLEV, 1, K>(lds, rx, ry, kw, valid_last, lane_ok, c0, c1, c2);
-    return pair_words<NLEV, 2, K>(lds, rx, ry, kw, valid_last, lane_ok, c0, c1, c2);
+    if (lag == 0) return pair_words<NLEV, 0, K>(rx, ry, c0, c1, c2);
+    if (lag == 1) return pair_words<NLEV, 1, K>(rx, ry, c0, c1, c2);
+    return pair_words<NLEV, 2, K>(rx, ry, c0, c1, c2);
 }
 
 // The RUN_K words of one band for one wave.  NLEV is uniform for the whole block (maximum over its
 // words; unused levels have empty masks), so the block dispatches once per band to a straight-line
 // specialisation.
 template <int NLEV>
-__device__ __forceinline__ uint32_t band_words(const char *lds, const int rx, const int ry, const int kw,
-                                               const uint32_t valid_last, const uint32_t lane_ok,
-                                               uint32_t (&c0)[RUN_K], uint32_t (&c1)[RUN_K], uint32_t (&c2)[RUN_K],
-                                               const int lagbits)
+__device__ __forceinline__ uint32_t band_words(const int rx, const int ry, uint32_t (&c0)[RUN_K], uint32_t (&c1)[RUN_K],
+                                               uint32_t (&c2)[RUN_K], const int lagbits)
 {
     static_assert(RUN_K == 8, "four pairs");
-    uint32_t cnt = pair_dispatch<NLEV, 0>(lds, rx, ry, kw, valid_last, lane_ok, c0, c1, c2, lagbits);
-    cnt += pair_dispatch<NLEV, 2>(lds, rx, ry, kw, valid_last, lane_ok, c0, c1, c2, lagbits);
-    cnt += pair_dispatch<NLEV, 4>(lds, rx, ry, kw, valid_last, lane_ok, c0, c1, c2, lagbits);
-    cnt += pair_dispatch<NLEV, 6>(lds, rx, ry, kw, valid_last, lane_ok, c0, c1, c2, lagbits);
+    uint32_t cnt = pair_dispatch<NLEV, 0>(rx, ry, c0, c1, c2, lagbits);
+    cnt += pair_dispatch<NLEV, 2>(rx, ry, c0, c1, c2, lagbits);
+    cnt += pair_dispatch<NLEV, 4>(rx, ry, c0, c1, c2, lagbits);
+    cnt += pair_dispatch<NLEV, 6>(rx, ry, c0, c1, c2, lagbits);
     return cnt;
 }
 
-__device__ __forceinline__ uint32_t band_words_s(const char *lds, const int rx, const int ry, const int kw,
-                                                 const uint32_t valid_last, const uint32_t lane_ok,
-                                                 uint32_t (&c0)[RUN_K], uint32_t (&c1)[RUN_K], uint32_t (&c2)[RUN_K],
-                                                 const int nlev, const int lagbits)
+__device__ __forceinline__ uint32_t band_words_s(const int rx, const int ry, uint32_t (&c0)[RUN_K], uint32_t (&c1)[RUN_K],
+                                                 uint32_t (&c2)[RUN_K], const int nlev, const int lagbits)
 {
     switch (nlev) {
-    case 1: return band_words<1>(lds, rx, ry, kw, valid_last, lane_ok, c0, c1, c2, lagbits);
-    case 2: return band_words<2>(lds, rx, ry, kw, valid_last, lane_ok, c0, c1, c2, lagbits);
-    case 3: return band_words<3>(lds, rx, ry, kw, valid_last, lane_ok, c0, c1, c2, lagbits);
-    case 4: return band_words<4>(lds, rx, ry, kw, valid_last, lane_ok, c0, c1, c2, lagbits);
-    case 5: return band_words<5>(lds, rx, ry, kw, valid_last, lane_ok, c0, c1, c2, lagbits);
-    case 6: return band_words<6>(lds, rx, ry, kw, valid_last, lane_ok, c0, c1, c2, lagbits);
-    case 7: return band_words<7>(lds, rx, ry, kw, valid_last, lane_ok, c0, c1, c2, lagbits);
-    default: return band_words<8>(lds, rx, ry, kw, valid_last, lane_ok, c0, c1, c2, lagbits);
+    case 1: return band_words<1>(rx, ry, c0, c1, c2, lagbits);
+    case 2: return band_words<2>(rx, ry, c0, c1, c2, lagbits);
+    case 3: return band_words<3>(rx, ry, c0, c1, c2, lagbits);
+    case 4: return band_words<4>(rx, ry, c0, c1, c2, lagbits);
+    case 5: return band_words<5>(rx, ry, c0, c1, c2, lagbits);
+    case 6: return band_words<6>(rx, ry, c0, c1, c2, lagbits);
+    case 7: return band_words<7>(rx, ry, c0, c1, c2, lagbits);
+    default: return band_words<8>(rx, ry, c0, c1, c2, lagbits);
     }
 }
 
@@ -521,11 +557,24 @@ __global__ __launch_bounds__(RUN_BAND, 4) void runs_kernel(const RunPass p, cons
     const int w0 = g * RUN_K;
     const int kw = min(RUN_K, p.NW - w0);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // the inner loop addresses LDS by integer: the dynamic segment must start at LDS address 0 (no
+    // static LDS in this kernel).  If a toolchain ever places it elsewhere the candidate is handed to
+    // the gather kernel instead of computing from wrong addresses.
+    if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char *)lds != 0u) {
+        if (tid == 0) guard[a] = 1;
+        return;
+    }
 
+#ifdef OMR_RUNS_DEBUG
+    {   // experiment: de-phase the two workgroups of a CU (they otherwise run fetch / compute / flush in lockstep)
+        const int st = p.dbg >> 8;  // units of 1024 cycles
+        const uint32_t tg = __builtin_amdgcn_s_getreg(((4 - 1) << 11) | (16 << 6) | 4);  // HW_ID.TG_ID
+        if (st > 0 && (tg & 1)) for (int i = 0; i < st; i++) __builtin_amdgcn_s_sleep(16);
+    }
+#endif
     // block constants: one scalar load (the address is uniform)
     const RunBlk bk = p.blk[(int64_t)a * p.G + g];
     const int nlev_blk = bk.nlev, lagbits = bk.lagbits;
-    const uint32_t valid_last = bk.valid_last;
     const int ca_min = bk.ca_min, ca_max = bk.ca_max, cb_min = bk.cb_min, cb_max = bk.cb_max;
     const int2_t *__restrict__ RT = p.RT + (int64_t)a * p.NR;
     const int c_first = w0 * 32;
@@ -581,9 +630,19 @@ __global__ __launch_bounds__(RUN_BAND, 4) void runs_kernel(const RunPass p, cons
         row0 = (int)(((uint32_t)t * magic) >> 16);
         w4 = 4 * (t - row0 * q.nq);
     };
+    // The loads of a window are issued as soon as a wave has finished the previous band (before the
+    // barrier: they do not touch LDS) and committed after it.  They are NOT held in registers across a
+    // compute phase: the merge loop runs at the edge of the 128-VGPR budget of 4 waves per SIMD, and every
+    // variant that kept 16-24 piece registers live through it ended with the allocator spilling them
+    // (round 2: six variants, 16-78 spilled VGPRs); the second workgroup of the CU covers the fetch instead.
+    // Rounds 0..3 (all of a 3-piece window: 69 % of the bands at C2) fly across the loop-top barrier; the
+    // rounds of wider windows are loaded inside the commit, so that no more than 16 piece registers are
+    // ever live at the loop's back edge (with 24 the allocator spilled two pieces around the whole loop).
+    constexpr int EARLY = 4;
+    static_assert(EARLY * 170 >= RUN_WIN_ROWS, "the early rounds cover a 3-piece window");
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-    u32x4 pre[PIECES];
-    auto prefetch = [&](const RunGeom &q) {
+    u32x4 pre[EARLY];
+    auto fetch = [&](const RunGeom &q) {
         if (!q.fits) return;
         int row0, w4, rpr;
         piece0(q, row0, w4, rpr);
@@ -593,7 +652,7 @@ __global__ __launch_bounds__(RUN_BAND, 4) void runs_kernel(const RunPass p, cons
         const uint32_t voff = in_w ? (uint32_t)(((q.wy0 + row0) * p.src_wpr + w) * 4) : 0x80000000u;
         const uint32_t stride = (uint32_t)(rpr * p.src_wpr * 4);
 #pragma unroll
-        for (int n = 0; n < PIECES; n++) {
+        for (int n = 0; n < EARLY; n++) {
             if (n * rpr >= q.nrows) break;  // wave-uniform: this round has no rows
             pre[n] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(voff + n * stride), 0, 0);
         }
@@ -604,15 +663,28 @@ __global__ __launch_bounds__(RUN_BAND, 4) void runs_kernel(const RunPass p, cons
         char *d0 = lds + RUN_WIN_OFS + row0 * RUN_PITCHB + w4 * 4;
         const int rows_left = row0 < rpr ? q.nrows - row0 : 0;
         const int dstride = rpr * RUN_PITCHB;
+        u32x4 late[PIECES - EARLY];
+        if (EARLY * rpr < q.nrows) {  // wave-uniform: a 4- or 5-piece window has late rounds
+            const int w = q.wxw + w4;
+            const bool in_w = row0 < rpr && w >= 0 && w + 3 < p.src_wpr;
+            const uint32_t voff = in_w ? (uint32_t)(((q.wy0 + row0) * p.src_wpr + w) * 4) : 0x80000000u;
+            const uint32_t stride = (uint32_t)(rpr * p.src_wpr * 4);
+#pragma unroll
+            for (int n = EARLY; n < PIECES; n++) {
+                if (n * rpr >= q.nrows) break;
+                late[n - EARLY] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(voff + n * stride), 0, 0);
+            }
+        }
 #pragma unroll
         for (int n = 0; n < PIECES; n++) {
             if (n * rpr >= q.nrows) break;
             if (n * rpr < rows_left) {
+                const u32x4 v = n < EARLY ? pre[n < EARLY ? n : 0] : late[n >= EARLY ? n - EARLY : 0];
                 uint32_t *d = (uint32_t *)(d0 + n * dstride);
-                d[0] = pre[n].x;
-                d[1] = pre[n].y;
-                d[2] = pre[n].z;
-                d[3] = pre[n].w;
+                d[0] = v.x;
+                d[1] = v.y;
+                d[2] = v.z;
+                d[3] = v.w;
             }
         }
     };
@@ -632,7 +704,10 @@ __global__ __launch_bounds__(RUN_BAND, 4) void runs_kernel(const RunPass p, cons
         for (int n = 0; n < TP; n++) {
             const int i = tid + n * RUN_BAND;
             const int k = i / W16, c = i - k * W16;
-            tv[n] = i < RUN_K * W16 ? src[min(k, kw - 1) * W16 + c] : make_uint4(0, 0, 0, 0);
+            // words past the end of the row: a copy of the last real word (addresses stay meaningful) whose
+            // level masks are EMPTY, so they add nothing to any count
+            tv[n] = (i < RUN_K * W16 && !(k >= kw && c < RUN_TUPX_OFS / 16)) ? src[min(k, kw - 1) * W16 + c]
+                                                                            : make_uint4(0, 0, 0, 0);
         }
     }
     int2 mv = make_int2(0, 0);  // (ca0, cb0) of word tid: read back from LDS as a broadcast
@@ -642,7 +717,7 @@ __global__ __launch_bounds__(RUN_BAND, 4) void runs_kernel(const RunPass p, cons
         mv = make_int2(mt[kk].ca0, mt[kk].cb0);
     }
     RunGeom cur = geometry(cn0, cn1);
-    prefetch(cur);
+    if (!(RUN_DBG(p) & 2)) fetch(cur);
     corners(RUN_BAND, cn0, cn1);  // next band's corners: in flight until the end of the first iteration
     {
         uint4 *dst = (uint4 *)(lds + RUN_TABS_OFS);
@@ -673,27 +748,29 @@ __global__ __launch_bounds__(RUN_BAND, 4) void runs_kernel(const RunPass p, cons
         RUN_STAMP(1)
         const RunGeom now = cur;
         const int2_t rt_now = rt;
-        if (yb + RUN_BAND < p.NR) {
+        const bool more = yb + RUN_BAND < p.NR;
+        if (more) {
             cur = geometry(cn0, cn1);
-            if (!(RUN_DBG(p) & 2)) prefetch(cur);
             corners(yb + 2 * RUN_BAND, cn0, cn1);
             rt = RT[min(r + RUN_BAND, p.NR - 1)];
         }
         RUN_STAMP(2)
-        if (now.fits && yb + wave * 64 < p.NR && !(RUN_DBG(p) & 1)) {
+        // rows past the end of the image are masked off by EXEC for the whole compute phase (their
+        // counters must not move); the band loop's barriers are outside this branch
+        if (now.fits && r < p.NR && !(RUN_DBG(p) & 1)) {
             const int rx = rt_now.x - (now.wxw << 15);  // window-local fixed point
             const int ry = rt_now.y - (now.wy0 << 10);
-            const uint32_t lane_ok = r < p.NR ? 0xffffffffu : 0u;  // rows past the end count nothing
-            const uint32_t cnt = band_words_s(lds, rx, ry, kw, valid_last, lane_ok, c0, c1, c2, nlev_blk, lagbits);
-            if (r < p.NR) out[r] = (uint16_t)cnt;
+            const uint32_t cnt = band_words_s(rx, ry, c0, c1, c2, nlev_blk, lagbits);
+            out[r] = (uint16_t)cnt;
         }
         RUN_STAMP(3)
         // the 3-plane counters hold at most 7 rows per lane: reduce them across lanes in time
-        if (++bands_pending == RUN_FLUSH_BANDS || yb + RUN_BAND >= p.NR) {
+        if (++bands_pending == RUN_FLUSH_BANDS || !more) {
             bands_pending = 0;
             if (!(RUN_DBG(p) & 4)) flush_columns(lds, c0, c1, c2, colacc, tid);
             RUN_STAMP(4)
         }
+        if (more && !(RUN_DBG(p) & 2)) fetch(cur);  // next window: in flight across the loop-top barrier
     }
     __syncthreads();
     // column counts of this block's (up to) 256 columns over ALL rows: one plain store each
