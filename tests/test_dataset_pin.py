@@ -1,0 +1,119 @@
+"""The reference-held pin: packages/lib/src/lib.rs:103-113 -- |injected - detected| < 0.5 deg whenever
+!need_check -- over the reference's own 104-sheet dataset with the lib.rs:132-205 protocol and
+correct_default(45, 0.2, 248, 230, 150.0, 50.0).  See tests/dataset_pin.py for the protocol and
+tests/golden/make_dataset_pin.py for how the fixtures were made.
+
+  * CPU tier : the oracle on one angle per sheet (104 cases) must reproduce the committed expectations bit
+               for bit and meet the reference's criterion; the committed 936-case histogram must hold no ERROR.
+  * Criterion as asserted here: no believed case in class ERROR (distance > 0.5, lib.rs:222-223).  The
+    disabled random test's `assert < 0.5` (lib.rs:105-112) differs from that only AT 0.5: one of the 936
+    cases (image051 at 28.9 deg, detected 28.4) lands exactly there -- the reference's own comment records
+    the same experience ("one case above 0.5 was seen", lib.rs:108); the tests count such cases (<= 1).
+  * GPU tier : all 936 cases through omr_correct_default (C ABI -> HIP kernels): the reference's criterion,
+               bit-equality with the oracle's committed results, and the class histogram next to the
+               reference's claim "99.9 % < 0.4 deg" (lib.rs:108), written to gpurun_out/ for DESIGN.md.
+This is accuracy-level: parity stays "unpinned at bit level" (the reference holds no golden vectors)."""
+import json
+import os
+import struct
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import dataset_pin as dp  # noqa: E402
+
+
+def _bits(x):
+    return struct.pack("<d", float(x)).hex()
+
+
+def test_fixture_is_the_whole_reference_dataset():
+    names = dp.sheets()
+    assert len(names) == 104  # 100 x image0NN.jpg + 4 x SCN000NN_2.jpg
+    assert sum(n.startswith("image") for n in names) == 100 and sum(n.startswith("SCN") for n in names) == 4
+    exp = dp.load_expected()
+    assert exp["params"] == list(dp.PARAMS)
+    assert [(c["sheet"], c["idx"]) for c in exp["cases"]] == dp.cases()
+    assert len(exp["cases"]) == 104 * dp.ANGLES_PER_SHEET >= 900
+    assert all(-450 <= c["idx"] < 450 for c in exp["cases"])  # lib.rs:153
+
+
+def test_committed_histogram_meets_the_reference_criterion():
+    exp = dp.load_expected()
+    hist, edge = {}, 0
+    for c in exp["cases"]:
+        inj = c["idx"] * 0.1
+        cls = dp.classify(inj, c["angle"], c["need_check"])
+        hist[cls] = hist.get(cls, 0) + 1
+        assert cls == c["class"]
+        if not c["need_check"]:
+            assert abs(inj - c["angle"]) <= 0.5, (c["sheet"], inj, c["angle"])  # lib.rs:103-113 / :222
+            edge += abs(inj - c["angle"]) >= 0.5
+    assert edge <= 1  # the one boundary case (distance == 0.5 exactly)
+    assert hist == exp["histogram"] and hist.get("ERROR", 0) == 0
+    believed = sum(v for k, v in hist.items() if k != "NOT_BELIEVED")
+    assert believed >= 0.99 * len(exp["cases"])  # NOT_BELIEVED is rare (3 of 936 when the fixtures were made)
+
+
+def test_oracle_reproduces_the_committed_results(oracle):
+    """One case per sheet on the CPU (the whole set takes minutes single-threaded; make_dataset_pin.py ran it)."""
+    exp = dp.load_expected()["cases"]
+    first = {}
+    for c in exp:
+        first.setdefault(c["sheet"], c)
+
+    def one(c):
+        bgr = dp.imread_color(c["sheet"])
+        x = dp.inject(bgr, c["idx"] * 0.1, oracle)
+        det, chk, pst = dp.oracle_correct_default(x, oracle)
+        return c, det, chk, pst
+
+    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
+        for c, det, chk, pst in ex.map(one, list(first.values())):
+            assert _bits(det) == c["angle_bits"] and chk == c["need_check"] and pst == c["proj_status"], c["sheet"]
+            if not chk:
+                assert abs(c["idx"] * 0.1 - det) <= 0.5
+
+
+@pytest.mark.gpu
+def test_correct_default_on_the_dataset_gpu(oracle):
+    """All 936 cases through the product path; fixture inputs (skew injection, JPEG round trip) are made
+    with the oracle / PIL exactly as for the committed expectations, so the GPU must match them bit for bit."""
+    from oics import omr
+    exp = dp.load_expected()["cases"]
+    by_sheet = {}
+    for c in exp:
+        by_sheet.setdefault(c["sheet"], []).append(c)
+
+    def prepare(item):
+        name, cs = item
+        bgr = dp.imread_color(name)
+        return [(c, dp.inject(bgr, c["idx"] * 0.1, oracle)) for c in cs]
+
+    hist, mism, worst, n, edge = {}, [], 0.0, 0, 0
+    with ThreadPoolExecutor(max_workers=min(16, os.cpu_count() or 1)) as ex:
+        for batch in ex.map(prepare, sorted(by_sheet.items())):
+            for c, x in batch:
+                ang, chk, _ = omr.correct_default(x, *dp.PARAMS, want_image=False)
+                inj = c["idx"] * 0.1
+                cls = dp.classify(inj, ang, chk)
+                hist[cls] = hist.get(cls, 0) + 1
+                n += 1
+                if not chk:
+                    worst = max(worst, abs(inj - ang))
+                    assert abs(inj - ang) <= 0.5, (c["sheet"], inj, ang)  # lib.rs:103-113 / :222
+                    edge += abs(inj - ang) >= 0.5
+                if _bits(ang) != c["angle_bits"] or chk != c["need_check"]:
+                    mism.append((c["sheet"], c["idx"], ang, c["angle"], chk, c["need_check"]))
+    assert n == len(exp) >= 900
+    assert not mism, "GPU differs from the oracle's committed results: %s" % mism[:5]
+    assert hist.get("ERROR", 0) == 0 and edge <= 1
+    out = os.path.join(os.path.dirname(HERE), "gpurun_out")
+    if os.path.isdir(out):
+        json.dump({"cases": n, "histogram": hist, "worst_believed_error_deg": worst, "believed_cases_at_0p5": edge,
+                   "reference_claim": "99.9 % < 0.4 deg, ~100 % < 0.5 deg (lib.rs:108)",
+                   "success_rate": hist.get("SUCCESS", 0) / n}, open(os.path.join(out, "dataset_pin_gpu.json"), "w"), indent=1)
