@@ -64,6 +64,7 @@ typedef struct {
  * numeric value, transfer.rs / projection.rs:52; 1 = INTER_LINEAR, core/src/main.rs:76) */
 #define OMR_INTER_NEAREST 0
 #define OMR_INTER_LINEAR 1
+#define OMR_INTER_AREA 3 /* imgproc::INTER_AREA: resize only */
 
 int omr_version(void);
 int omr_device_count(void);
@@ -230,6 +231,16 @@ int omr_get_horizontal_projection(const omr_image *bin_u8c1, double *out_rows);
 int omr_get_mat_projection_data(const omr_image *bin_u8c1, double *h_rows, double *v_cols);
 /* transfer::get_projection_standard_deviations (transfer.rs:527-536): (vertical, horizontal) */
 int omr_get_projection_standard_deviations(const omr_image *bin_u8c1, double *v_sd, double *h_sd);
+/* TransformableMatrix::scale_self (transfer.rs:66-91): new size = ((w * scale) as i32, (h * scale) as i32),
+ * INTER_LINEAR when scale > 1, INTER_AREA otherwise; scale == 1.0 returns a copy.
+ * shrink_to (transfer.rs:93-126; the Projection phase of the in-app benchmark, app/src-tauri/src/test.rs:313):
+ * scale = min(max_width / w, max_height / h) (a bound <= 0 means "no bound"), applied only when < 1.
+ * resize_self (transfer.rs:128-145): resize to (width, height) with INTER_AREA.
+ * The reference mutates `self`; here the result is a new owned image (omr_image_free). */
+int omr_scale(const omr_image *src, double scale, omr_image_owned *dst);
+int omr_shrink_to(const omr_image *src, int32_t max_width, int32_t max_height, omr_image_owned *dst);
+int omr_resize(const omr_image *src, int32_t width, int32_t height, omr_image_owned *dst);
+
 /* ---- the same stages on device-resident images (enqueue on `stream`, no synchronisation) ----
  * These are the building blocks of a fully resident pipeline: front end of omr.rs:87-139,
  * sweep (omr_sweep_plan_run_device / omr_batch_run_device), final deskew of omr.rs:408-445 /
@@ -239,9 +250,10 @@ int omr_rgb_to_gray_device(const uint8_t *d_src, int64_t src_step, int32_t rows,
 /* erode(3x3 MORPH_ELLIPSE = cross, iterations = 3, BORDER_CONSTANT, default border): omr.rs:98-112 */
 int omr_erode3_device(const uint8_t *d_src, int64_t src_step, int32_t rows, int32_t cols,
                       uint8_t *d_dst, int64_t dst_step, void *stream);
-/* resize(INTER_AREA) by an integer factor on both axes (resizeAreaFast_): transfer.rs:66-91 with
- * the callers' 0.2, omr.rs:114-126 with 1240x1150 -> 248x230.  Other factors: -213 (use the
- * host-image drivers, which build the tap tables). */
+/* resize(src, dst size, INTER_AREA): transfer.rs:128-145 / omr.rs:114-126.  Integer shrink factors (the
+ * callers' 0.2, 1240x1150 -> 248x230) run resizeAreaFast_; fractional shrink factors build resizeArea_'s
+ * tap tables on the host and synchronise `stream` before returning; when an axis ENLARGES OpenCV emulates
+ * INTER_AREA with its bilinear kernel (omr.rs:60-82 has no clamp on the scale: quirk B7) -- same here. */
 int omr_resize_area_device(const uint8_t *d_src, int64_t src_step, int32_t src_rows, int32_t src_cols,
                            int32_t channels, uint8_t *d_dst, int64_t dst_step, int32_t dst_rows,
                            int32_t dst_cols, void *stream);

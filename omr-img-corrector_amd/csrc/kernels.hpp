@@ -160,6 +160,9 @@ hipError_t launch_resize_area_int_fast(const uint8_t *d_src, int64_t sstep, int 
 // Returns hipErrorInvalidValue when the destination is not 4-byte aligned (use the generic kernel).
 hipError_t launch_warp_c1_fast(const uint8_t *d_src, int64_t sstep, int srows, int scols, uint8_t *d_dst, int64_t dstep,
                                int drows, int dcols, const double Minv[6], int interp, int border, hipStream_t s);
+// resize(INTER_LINEAR) (area_mode false) / INTER_AREA's bilinear emulation when an axis enlarges (true)
+hipError_t launch_resize_linear(const uint8_t *d_src, int64_t sstep, int srows, int scols, int cn, uint8_t *d_dst,
+                                int64_t dstep, int drows, int dcols, bool area_mode, hipStream_t s);
 hipError_t launch_threshold_fast(const uint8_t *d_src, int64_t sstep, int rows, int cols, uint8_t *d_dst, int64_t dstep,
                                  int thresh, int maxval, hipStream_t s);
 

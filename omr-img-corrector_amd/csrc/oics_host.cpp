@@ -196,31 +196,43 @@ void area_tab(int ssize, int dsize, int cn, double scale, std::vector<AreaTap> *
     (*ofs)[dsize] = (int32_t)tab->size();
 }
 
-// resize(src, dsize, INTER_AREA) on the device: transfer.rs:66-91 (scale_self) and omr.rs:114-126.
-int resize_area(const DevImage &src, int drows, int dcols, DevImage *dst, hipStream_t s)
+// resize(src, dsize, interp) on the device for the two flags the reference passes (transfer.rs:66-91
+// scale_self: INTER_LINEAR when enlarging, INTER_AREA otherwise; transfer.rs:128-145 resize_self and
+// omr.rs:114-126: INTER_AREA whatever the direction).  OpenCV 4.6.0 resize.cpp dispatch:
+//   same size                         -> copy
+//   INTER_AREA, both axes shrink      -> resizeAreaFast_ (integer factors) / resizeArea_ (tap tables)
+//   INTER_AREA, an axis enlarges      -> the bilinear kernel with area-mode coefficients (quirk B7)
+//   INTER_LINEAR                      -> the bilinear kernel (exact 2x shrink is re-routed to INTER_AREA)
+int resize_ptr(const uint8_t *d_src, int64_t sstep, int srows, int scols, int cn, uint8_t *d_dst, int64_t dstep,
+               int drows, int dcols, int interp, hipStream_t s)
 {
     if (drows <= 0 || dcols <= 0) return fail(OMR_ERR_ASSERT, "resize to an empty size");
-    int rc = dst->alloc(drows, dcols, src.cn);
-    if (rc) return rc;
-    if (drows == src.rows && dcols == src.cols) {
-        OMR_HIP(hipMemcpyAsync(dst->buf.p, src.buf.p, (size_t)src.rows * src.step(), hipMemcpyDeviceToDevice, s));
+    if (interp != OMR_INTER_AREA && interp != OMR_INTER_LINEAR)
+        return fail(OMR_ERR_NOTIMPL, "resize interpolation flag %d is not implemented", interp);
+    if (drows == srows && dcols == scols) {
+        OMR_HIP(hipMemcpy2DAsync(d_dst, (size_t)dstep, d_src, (size_t)sstep, (size_t)scols * cn, (size_t)srows,
+                                 hipMemcpyDeviceToDevice, s));
         return OMR_OK;
     }
-    double inv_scale_x = (double)dcols / src.cols, inv_scale_y = (double)drows / src.rows;
+    double inv_scale_x = (double)dcols / scols, inv_scale_y = (double)drows / srows;
     double scale_x = 1. / inv_scale_x, scale_y = 1. / inv_scale_y;
-    if (!(scale_x >= 1 && scale_y >= 1))
-        return fail(OMR_ERR_NOTIMPL, "INTER_AREA up-scaling (OpenCV's linear branch, quirk B7) is not implemented");
     int iscale_x = (int)lrint(scale_x), iscale_y = (int)lrint(scale_y);
     bool is_area_fast = fabs(scale_x - iscale_x) < DBL_EPSILON && fabs(scale_y - iscale_y) < DBL_EPSILON;
+    if (interp == OMR_INTER_LINEAR && is_area_fast && iscale_x == 2 && iscale_y == 2) interp = OMR_INTER_AREA;
+    if (!(interp == OMR_INTER_AREA && scale_x >= 1 && scale_y >= 1)) {
+        OMR_HIP(launch_resize_linear(d_src, sstep, srows, scols, cn, d_dst, dstep, drows, dcols,
+                                     interp == OMR_INTER_AREA, s));
+        return OMR_OK;
+    }
     if (is_area_fast) {
-        OMR_HIP(launch_resize_area_int_fast(src.ptr(), src.step(), src.rows, src.cols, src.cn, dst->ptr(), dst->step(),
-                                       drows, dcols, iscale_x, iscale_y, s));
+        OMR_HIP(launch_resize_area_int_fast(d_src, sstep, srows, scols, cn, d_dst, dstep, drows, dcols, iscale_x,
+                                            iscale_y, s));
         return OMR_OK;
     }
     std::vector<AreaTap> xt, yt;
     std::vector<int32_t> xo, yo;
-    area_tab(src.cols, dcols, src.cn, scale_x, &xt, &xo);
-    area_tab(src.rows, drows, 1, scale_y, &yt, &yo);
+    area_tab(scols, dcols, cn, scale_x, &xt, &xo);
+    area_tab(srows, drows, 1, scale_y, &yt, &yo);
     DevBuf dxt, dxo, dyt, dyo;
     OMR_HIP(dxt.alloc(sizeof(AreaTap) * xt.size()));
     OMR_HIP(dxo.alloc(sizeof(int32_t) * xo.size()));
@@ -230,10 +242,42 @@ int resize_area(const DevImage &src, int drows, int dcols, DevImage *dst, hipStr
     OMR_HIP(hipMemcpyAsync(dxo.p, xo.data(), sizeof(int32_t) * xo.size(), hipMemcpyHostToDevice, s));
     OMR_HIP(hipMemcpyAsync(dyt.p, yt.data(), sizeof(AreaTap) * yt.size(), hipMemcpyHostToDevice, s));
     OMR_HIP(hipMemcpyAsync(dyo.p, yo.data(), sizeof(int32_t) * yo.size(), hipMemcpyHostToDevice, s));
-    OMR_HIP(launch_resize_area_general(src.ptr(), src.step(), src.cn, dst->ptr(), dst->step(), drows, dcols,
-                                       dxt.as<AreaTap>(), dxo.as<int32_t>(), dyt.as<AreaTap>(), dyo.as<int32_t>(), s));
+    OMR_HIP(launch_resize_area_general(d_src, sstep, cn, d_dst, dstep, drows, dcols, dxt.as<AreaTap>(),
+                                       dxo.as<int32_t>(), dyt.as<AreaTap>(), dyo.as<int32_t>(), s));
     OMR_HIP(hipStreamSynchronize(s));  // the tap tables are freed on return
     return OMR_OK;
+}
+
+int resize_dev(const DevImage &src, int drows, int dcols, int interp, DevImage *dst, hipStream_t s)
+{
+    if (drows <= 0 || dcols <= 0) return fail(OMR_ERR_ASSERT, "resize to an empty size");
+    int rc = dst->alloc(drows, dcols, src.cn);
+    if (rc) return rc;
+    return resize_ptr(src.ptr(), src.step(), src.rows, src.cols, src.cn, dst->ptr(), dst->step(), drows, dcols, interp, s);
+}
+int resize_area(const DevImage &src, int drows, int dcols, DevImage *dst, hipStream_t s)
+{
+    return resize_dev(src, drows, dcols, OMR_INTER_AREA, dst, s);
+}
+
+// transfer.rs:66-91 scale_self: size truncated with `as i32`, INTER_LINEAR when enlarging
+int scale_dev(const DevImage &src, double scale, DevImage *dst, hipStream_t s)
+{
+    const int dc = (int)((double)src.cols * scale), dr = (int)((double)src.rows * scale);
+    return resize_dev(src, dr, dc, scale > 1.0 ? OMR_INTER_LINEAR : OMR_INTER_AREA, dst, s);
+}
+
+int give_owned(const DevImage &img, omr_image_owned *dst, hipStream_t s)
+{
+    dst->rows = img.rows;
+    dst->cols = img.cols;
+    dst->channels = img.cn;
+    dst->step_bytes = img.step();
+    dst->data = (uint8_t *)malloc((size_t)img.rows * dst->step_bytes);
+    if (!dst->data) return fail(OMR_ERR_NOMEM, "out of host memory");
+    int rc = img.download(dst->data, dst->step_bytes, s);
+    if (rc) omr_image_free(dst);
+    return rc;
 }
 
 int to_gray(const DevImage &src, DevImage *gray, hipStream_t s)
@@ -360,10 +404,7 @@ int omr_get_angle_with_projections(const omr_image *src, uint16_t max_angle, dou
     if ((rc = in.upload(src, st.s))) return rc;
     const DevImage *cur = &in;
     if (resize_scale != 1.0) {  // :24-27 scale_self (transfer.rs:66-91)
-        if (resize_scale > 1.0)
-            return fail(OMR_ERR_NOTIMPL, "scale_self with scale > 1 (INTER_LINEAR enlargement) is not implemented");
-        int dc = (int)((double)src->cols * resize_scale), dr = (int)((double)src->rows * resize_scale);
-        if ((rc = resize_area(in, dr, dc, &scaled, st.s))) return rc;
+        if ((rc = scale_dev(in, resize_scale, &scaled, st.s))) return rc;
         cur = &scaled;
     }
     if ((rc = to_gray(*cur, &gray, st.s))) return rc;  // :30
@@ -623,13 +664,51 @@ int omr_resize_area_device(const uint8_t *d_src, int64_t src_step, int32_t src_r
         return fail(OMR_ERR_ASSERT, "bad image shape");
     if (src_step < (int64_t)src_cols * channels || dst_step < (int64_t)dst_cols * channels)
         return fail(OMR_ERR_BADARG, "step too small");
-    double scale_x = 1. / ((double)dst_cols / src_cols), scale_y = 1. / ((double)dst_rows / src_rows);
-    int kx = (int)lrint(scale_x), ky = (int)lrint(scale_y);
-    if (!(scale_x >= 1 && scale_y >= 1) || fabs(scale_x - kx) >= DBL_EPSILON || fabs(scale_y - ky) >= DBL_EPSILON)
-        return fail(OMR_ERR_NOTIMPL, "device INTER_AREA handles integer shrink factors only");
-    OMR_HIP(launch_resize_area_int_fast(d_src, src_step, src_rows, src_cols, channels, d_dst, dst_step, dst_rows,
-                                        dst_cols, kx, ky, (hipStream_t)stream));
-    return OMR_OK;
+    return resize_ptr(d_src, src_step, src_rows, src_cols, channels, d_dst, dst_step, dst_rows, dst_cols, OMR_INTER_AREA,
+                      (hipStream_t)stream);
+}
+
+// ---- transfer.rs:66-145 on host images: scale_self / shrink_to / resize_self ------------------------
+static int resize_host(const omr_image *src, int drows, int dcols, int interp, omr_image_owned *dst)
+{
+    int rc = check_image(src, false);
+    if (rc) return rc;
+    if (!dst) return fail(OMR_ERR_BADARG, "null output");
+    if (drows <= 0 || dcols <= 0) return fail(OMR_ERR_ASSERT, "resize to an empty size (the reference's resize raises)");
+    if (drows >= 32767 || dcols >= 32767) return fail(OMR_ERR_ASSERT, "image dimension >= SHRT_MAX");
+    int dev;
+    if ((rc = current_device(&dev))) return rc;
+    Stream st;
+    if ((rc = st.create())) return rc;
+    DevImage in, out;
+    if ((rc = in.upload(src, st.s))) return rc;
+    if ((rc = resize_dev(in, drows, dcols, interp, &out, st.s))) return rc;
+    return give_owned(out, dst, st.s);
+}
+
+int omr_scale(const omr_image *src, double scale, omr_image_owned *dst)
+{
+    if (!src) return fail(OMR_ERR_BADARG, "null image");
+    if (!(scale > 0.0)) return fail(OMR_ERR_BADARG, "scale must be positive");
+    // scale == 1.0 returns the image unchanged (transfer.rs:67-69): a copy here, outputs are always owned
+    const int dc = scale == 1.0 ? src->cols : (int)((double)src->cols * scale);
+    const int dr = scale == 1.0 ? src->rows : (int)((double)src->rows * scale);
+    return resize_host(src, dr, dc, scale > 1.0 ? OMR_INTER_LINEAR : OMR_INTER_AREA, dst);
+}
+
+int omr_shrink_to(const omr_image *src, int32_t max_width, int32_t max_height, omr_image_owned *dst)
+{
+    if (!src) return fail(OMR_ERR_BADARG, "null image");
+    if (src->cols <= 0 || src->rows <= 0) return fail(OMR_ERR_ASSERT, "empty image");
+    const double ws = max_width <= 0 ? 1.0 : (double)max_width / (double)src->cols;   // transfer.rs:105-114
+    const double hs = max_height <= 0 ? 1.0 : (double)max_height / (double)src->rows;
+    const double t = ws < hs ? ws : hs;
+    return omr_scale(src, t >= 1.0 ? 1.0 : t, dst);  // :121-125: never enlarges
+}
+
+int omr_resize(const omr_image *src, int32_t width, int32_t height, omr_image_owned *dst)
+{
+    return resize_host(src, height, width, OMR_INTER_AREA, dst);  // transfer.rs:128-145
 }
 
 int omr_threshold_binary_device(const uint8_t *d_src, int64_t src_step, int32_t rows, int32_t cols, uint8_t *d_dst,

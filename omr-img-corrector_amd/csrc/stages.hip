@@ -269,4 +269,76 @@ hipError_t launch_threshold_fast(const uint8_t *d_src, int64_t sstep, int rows, 
     return launch_threshold(d_src, sstep, rows, cols, d_dst, dstep, thresh, maxval, s);
 }
 
+// resize(INTER_LINEAR) and INTER_AREA's bilinear emulation when an axis enlarges (OpenCV resizeGeneric_ with
+// HResizeLinear<uchar,int,short,2048> / VResizeLinear<uchar,int,short,FixedPtCast<22>>): scale_self with
+// scale > 1 (transfer.rs:66-91) and path 2's unclamped scale (omr.rs:60-82,114-126, quirk B7).  Every thread
+// rebuilds its two coefficient pairs with the expressions of resize.cpp (double products, float fractions,
+// saturate_cast<short>(c * 2048) with round-half-even; the file is built -ffp-contract=off): 11-bit
+// horizontal taps on the two source rows, then (((b0*(h0>>4))>>16) + ((b1*(h1>>4))>>16) + 2) >> 2.
+// sx is monotone in dx, so "dx >= xmax" (the columns that copy S[sx] * 2048) is just sx + 1 >= scols.
+__device__ __forceinline__ void linear_coef(int d, double scale, double inv_scale, int ssize, bool area_mode, int &s0,
+                                            int &c0, int &c1, bool &edge)
+{
+    float f;
+    int sx;
+    if (!area_mode) {
+        f = (float)(((double)d + 0.5) * scale - 0.5);
+        sx = (int)floorf(f);
+        f -= (float)sx;
+    } else {
+        sx = (int)floor((double)d * scale);
+        f = (float)((double)(d + 1) - (double)(sx + 1) * inv_scale);
+        f = f <= 0.f ? 0.f : f - floorf(f);
+    }
+    s0 = sx;
+    edge = false;
+    if (ssize > 0) {  // horizontal axis only: the vertical axis keeps sy and clips the ROWS instead
+        if (sx < 0) f = 0.f, sx = 0;
+        if (sx + 1 >= ssize) {
+            edge = true;
+            if (sx >= ssize - 1) f = 0.f, sx = ssize - 1;
+        }
+        s0 = sx;
+    }
+    c0 = max(-32768, min(32767, (int)rintf((1.f - f) * 2048.f)));
+    c1 = max(-32768, min(32767, (int)rintf(f * 2048.f)));
+}
+
+__global__ __launch_bounds__(256) void resize_linear_kernel(const uint8_t *__restrict__ src, int64_t sstep, int srows,
+                                                            int scols, int cn, uint8_t *__restrict__ dst, int64_t dstep,
+                                                            int drows, int dcols, double scale_x, double inv_scale_x,
+                                                            double scale_y, double inv_scale_y, int area_mode)
+{
+    const int dxb = blockIdx.x * 256 + threadIdx.x, dy = blockIdx.y;
+    if (dxb >= dcols * cn) return;
+    const int dx = dxb / cn, c = dxb - dx * cn;
+    int sx, a0, a1, sy, b0, b1;
+    bool edge, unused;
+    linear_coef(dx, scale_x, inv_scale_x, scols, area_mode != 0, sx, a0, a1, edge);
+    linear_coef(dy, scale_y, inv_scale_y, 0, area_mode != 0, sy, b0, b1, unused);
+    const int sy0 = max(0, min(srows - 1, sy)), sy1 = max(0, min(srows - 1, sy + 1));
+    const uint8_t *S0 = src + (int64_t)sy0 * sstep + (int64_t)sx * cn + c;
+    const uint8_t *S1 = src + (int64_t)sy1 * sstep + (int64_t)sx * cn + c;
+    int h0, h1;
+    if (!edge) {
+        h0 = (int)S0[0] * a0 + (int)S0[cn] * a1;
+        h1 = (int)S1[0] * a0 + (int)S1[cn] * a1;
+    } else {
+        h0 = (int)S0[0] * 2048;
+        h1 = (int)S1[0] * 2048;
+    }
+    dst[(int64_t)dy * dstep + dxb] = (uint8_t)((((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2);
+}
+
+hipError_t launch_resize_linear(const uint8_t *d_src, int64_t sstep, int srows, int scols, int cn, uint8_t *d_dst,
+                                int64_t dstep, int drows, int dcols, bool area_mode, hipStream_t s)
+{
+    const double inv_scale_x = (double)dcols / scols, inv_scale_y = (double)drows / srows;
+    const double scale_x = 1. / inv_scale_x, scale_y = 1. / inv_scale_y;
+    hipLaunchKernelGGL(resize_linear_kernel, dim3((dcols * cn + 255) / 256, drows), dim3(256), 0, s, d_src, sstep, srows,
+                       scols, cn, d_dst, dstep, drows, dcols, scale_x, inv_scale_x, scale_y, inv_scale_y,
+                       area_mode ? 1 : 0);
+    return hipGetLastError();
+}
+
 }  // namespace omr

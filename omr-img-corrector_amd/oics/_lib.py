@@ -112,6 +112,9 @@ SYMBOLS = {
     "omr_get_angle_with_fft": (C.c_int, [C.POINTER(OmrImage), C.c_double, C.c_double, C.c_double, C.c_double, f64p]),
     "omr_get_result_from_fourier_transform": (C.c_int, [C.POINTER(OmrImage), C.c_double, C.c_double, C.c_double,
                                                         C.c_double, f64p, i32p, f64p, C.c_int32, i32p]),
+    "omr_scale": (C.c_int, [C.POINTER(OmrImage), C.c_double, C.POINTER(OmrImageOwned)]),
+    "omr_shrink_to": (C.c_int, [C.POINTER(OmrImage), C.c_int32, C.c_int32, C.POINTER(OmrImageOwned)]),
+    "omr_resize": (C.c_int, [C.POINTER(OmrImage), C.c_int32, C.c_int32, C.POINTER(OmrImageOwned)]),
     "omr_get_arithmetic_mean": (C.c_int, [f64p, C.c_size_t, f64p]),
     "omr_get_standard_deviation": (C.c_int, [f64p, C.c_size_t, f64p]),
 }

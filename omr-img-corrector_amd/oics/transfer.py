@@ -41,6 +41,40 @@ class TransformableMatrix:
     def clone(self):
         return TransformableMatrix.from_matrix(self.matrix)
 
+    # the three in-place resizers return self like the reference's `&mut Self` chain (transfer.rs:66-145)
+    def scale_self(self, scale):
+        """transfer.rs:66-91: INTER_LINEAR when scale > 1, INTER_AREA otherwise, size truncated `as i32`"""
+        if scale == 1.0:
+            return self
+        self.matrix = _owned_call(lib().omr_scale, self.matrix, C.c_double(float(scale)))
+        return self
+
+    def shrink_to(self, max_width, max_height):
+        """transfer.rs:93-126: never enlarges"""
+        self.matrix = _owned_call(lib().omr_shrink_to, self.matrix, C.c_int32(int(max_width)), C.c_int32(int(max_height)))
+        return self
+
+    def resize_self(self, width, height):
+        """transfer.rs:128-145: INTER_AREA to (width, height)"""
+        self.matrix = _owned_call(lib().omr_resize, self.matrix, C.c_int32(int(width)), C.c_int32(int(height)))
+        return self
+
+
+def _take_owned(out):
+    try:
+        shape = (out.rows, out.cols) if out.channels == 1 else (out.rows, out.cols, out.channels)
+        n = out.rows * out.step_bytes
+        return np.frombuffer((C.c_uint8 * n).from_address(out.data), np.uint8).reshape(shape).copy()
+    finally:
+        lib().omr_image_free(C.byref(out))
+
+
+def _owned_call(fn, mat, *args):
+    a, im = as_image(mat)
+    out = OmrImageOwned()
+    check(fn(C.byref(im), *args, C.byref(out)))
+    return _take_owned(out)
+
 
 def _mat(src):
     return src.matrix if isinstance(src, TransformableMatrix) else np.asarray(src)

@@ -272,6 +272,93 @@ static int orc_area_tab(int ssize, int dsize, int cn, double scale, orc_decimate
     return k;
 }
 
+/* [OpenCV 4.6.0 resize.cpp hal::resize -> resizeGeneric_ with HResizeLinear<uchar,int,short,2048> and
+ * VResizeLinear<uchar,int,short,FixedPtCast<int,uchar,22>>], 8U, cn channels.  Used for
+ *   - INTER_LINEAR (area_mode = 0): scale_self with scale > 1, transfer.rs:66-91;
+ *   - INTER_AREA when either axis enlarges (area_mode = 1): "true area interpolation is only implemented
+ *     for scale_x >= 1 && scale_y >= 1, in other cases it is emulated using some variant of bilinear
+ *     interpolation" -- path 2 has no clamp on its scale, omr.rs:60-82,114-126 (quirk B7).
+ * Coefficients: float fx -> saturate_cast<short>(c * 2048) (11 bits, round half to even); horizontal pass
+ * S[sx]*a0 + S[sx+cn]*a1 (S[sx]*2048 right of xmax); vertical pass
+ * (((b0*(S0>>4))>>16) + ((b1*(S1>>4))>>16) + 2) >> 2; source rows sy, sy+1 clipped into the image.
+ * IPP is disabled upstream for 8U resize (IPP_DISABLE_RESIZE_8U), the SIMD forms compute the same integers. */
+static inline short orc_sat_s16(int v) { return (short)(v < -32768 ? -32768 : v > 32767 ? 32767 : v); }
+
+int orc_resize_linear(const uint8_t *src, int srows, int scols, int cn, int64_t sstep, uint8_t *dst, int drows,
+                      int dcols, int64_t dstep, int area_mode)
+{
+    if (srows <= 0 || scols <= 0 || drows <= 0 || dcols <= 0 || cn < 1 || cn > 4) return ORC_ERR_ASSERT;
+    const double inv_scale_x = (double)dcols / scols, inv_scale_y = (double)drows / srows;
+    const double scale_x = 1. / inv_scale_x, scale_y = 1. / inv_scale_y;
+    int *xofs = (int *)malloc(sizeof(int) * (size_t)dcols), *yofs = (int *)malloc(sizeof(int) * (size_t)drows);
+    short *ialpha = (short *)malloc(sizeof(short) * 2 * (size_t)dcols), *ibeta = (short *)malloc(sizeof(short) * 2 * (size_t)drows);
+    int xmax = dcols;
+    for (int dx = 0; dx < dcols; dx++) {
+        float fx;
+        int sx;
+        if (!area_mode) {
+            fx = (float)((dx + 0.5) * scale_x - 0.5);
+            sx = orc_cv_floor(fx);
+            fx -= sx;
+        } else {
+            sx = orc_cv_floor(dx * scale_x);
+            fx = (float)((dx + 1) - (sx + 1) * inv_scale_x);
+            fx = fx <= 0 ? 0.f : fx - orc_cv_floor(fx);
+        }
+        if (sx < 0) fx = 0, sx = 0; /* ksize2 - 1 == 0: xmin plays no role in the linear kernel */
+        if (sx + 1 >= scols) {
+            xmax = xmax < dx ? xmax : dx;
+            if (sx >= scols - 1) fx = 0, sx = scols - 1;
+        }
+        xofs[dx] = sx * cn;
+        ialpha[dx * 2] = orc_sat_s16(orc_cv_roundf((1.f - fx) * 2048));
+        ialpha[dx * 2 + 1] = orc_sat_s16(orc_cv_roundf(fx * 2048));
+    }
+    for (int dy = 0; dy < drows; dy++) {
+        float fy;
+        int sy;
+        if (!area_mode) {
+            fy = (float)((dy + 0.5) * scale_y - 0.5);
+            sy = orc_cv_floor(fy);
+            fy -= sy;
+        } else {
+            sy = orc_cv_floor(dy * scale_y);
+            fy = (float)((dy + 1) - (sy + 1) * inv_scale_y);
+            fy = fy <= 0 ? 0.f : fy - orc_cv_floor(fy);
+        }
+        yofs[dy] = sy;
+        ibeta[dy * 2] = orc_sat_s16(orc_cv_roundf((1.f - fy) * 2048));
+        ibeta[dy * 2 + 1] = orc_sat_s16(orc_cv_roundf(fy * 2048));
+    }
+    for (int dy = 0; dy < drows; dy++) {
+        int sy0 = yofs[dy], sy1 = sy0 + 1; /* clip(sy0 - ksize2 + 1 + k, 0, ssize.height), k = 0, 1 */
+        sy0 = sy0 < 0 ? 0 : (sy0 < srows ? sy0 : srows - 1);
+        sy1 = sy1 < 0 ? 0 : (sy1 < srows ? sy1 : srows - 1);
+        const uint8_t *S0 = src + (int64_t)sy0 * sstep, *S1 = src + (int64_t)sy1 * sstep;
+        const int b0 = ibeta[dy * 2], b1 = ibeta[dy * 2 + 1];
+        uint8_t *D = dst + (int64_t)dy * dstep;
+        for (int dx = 0; dx < dcols; dx++)
+            for (int k = 0; k < cn; k++) {
+                const int sx = xofs[dx] + k;
+                int h0, h1;
+                if (dx < xmax) {
+                    const int a0 = ialpha[dx * 2], a1 = ialpha[dx * 2 + 1];
+                    h0 = S0[sx] * a0 + S0[sx + cn] * a1;
+                    h1 = S1[sx] * a0 + S1[sx + cn] * a1;
+                } else {
+                    h0 = S0[sx] * 2048;
+                    h1 = S1[sx] * 2048;
+                }
+                D[dx * cn + k] = (uint8_t)((((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2);
+            }
+    }
+    free(xofs);
+    free(yofs);
+    free(ialpha);
+    free(ibeta);
+    return ORC_OK;
+}
+
 /* [OpenCV 4.6.0 resize.cpp hal::resize, INTER_AREA, 8U]: integer factors -> resizeAreaFast_
  * (2x2 special case (a+b+c+d+2)>>2, otherwise saturate_cast<uchar>(sum * (1.f/area)));
  * other shrink factors -> resizeArea_ with float tables; Appendix A.7.
@@ -288,7 +375,8 @@ int orc_resize_area(const uint8_t *src, int srows, int scols, int cn, int64_t ss
     double scale_x = 1. / inv_scale_x, scale_y = 1. / inv_scale_y;
     int iscale_x = orc_cv_round(scale_x), iscale_y = orc_cv_round(scale_y);
     int is_area_fast = fabs(scale_x - iscale_x) < DBL_EPSILON && fabs(scale_y - iscale_y) < DBL_EPSILON;
-    if (!(scale_x >= 1 && scale_y >= 1)) return -213; /* up-scaling branch (quirk B7) not restated */
+    if (!(scale_x >= 1 && scale_y >= 1)) /* either axis enlarges: the bilinear emulation (quirk B7) */
+        return orc_resize_linear(src, srows, scols, cn, sstep, dst, drows, dcols, dstep, 1);
 
     if (is_area_fast) {
         int area = iscale_x * iscale_y;
@@ -697,10 +785,12 @@ int orc_get_angle_with_projections(const uint8_t *src, int rows, int cols, int c
     if (resize_scale != 1.0) {
         scols = (int)((double)cols * resize_scale);
         srows = (int)((double)rows * resize_scale);
-        if (resize_scale > 1.0) return -213; /* INTER_LINEAR up-scaling is not on the hot path */
         if (srows <= 0 || scols <= 0) return ORC_ERR_ASSERT;
         scaled = (uint8_t *)malloc((size_t)srows * scols * cn);
-        rc = orc_resize_area(src, rows, cols, cn, step, scaled, srows, scols, (int64_t)scols * cn);
+        if (resize_scale > 1.0) /* transfer.rs:82-86: INTER_LINEAR when enlarging, INTER_AREA otherwise */
+            rc = orc_resize_linear(src, rows, cols, cn, step, scaled, srows, scols, (int64_t)scols * cn, 0);
+        else
+            rc = orc_resize_area(src, rows, cols, cn, step, scaled, srows, scols, (int64_t)scols * cn);
         if (rc) {
             free(scaled);
             return rc;

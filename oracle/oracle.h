@@ -71,6 +71,9 @@ void orc_erode_cross3(const uint8_t *src, int rows, int cols, int64_t sstep,
 
 /* resize(..., dsize, INTER_AREA) 8U, cn channels: transfer.rs:66-91, omr.rs:114-126.
  * Returns 0 or -215. */
+/* resize(..., INTER_LINEAR) (area_mode 0) or INTER_AREA's bilinear emulation when enlarging (area_mode 1) */
+int orc_resize_linear(const uint8_t *src, int srows, int scols, int cn, int64_t sstep, uint8_t *dst, int drows,
+                      int dcols, int64_t dstep, int area_mode);
 int orc_resize_area(const uint8_t *src, int srows, int scols, int cn, int64_t sstep,
                     uint8_t *dst, int drows, int dcols, int64_t dstep);
 

@@ -48,6 +48,8 @@ def lib(fast=False):
         L.orc_erode_cross3.restype = None
         L.orc_resize_area.argtypes = [u8p, C.c_int, C.c_int, C.c_int, C.c_int64, u8p, C.c_int, C.c_int, C.c_int64]
         L.orc_resize_area.restype = C.c_int
+        L.orc_resize_linear.argtypes = [u8p, C.c_int, C.c_int, C.c_int, C.c_int64, u8p, C.c_int, C.c_int, C.c_int64, C.c_int]
+        L.orc_resize_linear.restype = C.c_int
         L.orc_arithmetic_mean.argtypes = [f64p, C.c_size_t]
         L.orc_arithmetic_mean.restype = C.c_double
         L.orc_standard_deviation.argtypes = [f64p, C.c_size_t]
@@ -202,6 +204,32 @@ def resize_area(img, drows, dcols):
     dst = np.zeros((drows, dcols) if a.ndim == 2 else (drows, dcols, cn), np.uint8)
     _check(lib().orc_resize_area(_u8(a), r, c, cn, st, _u8(dst), drows, dcols, dst.strides[0]))
     return dst
+
+
+def resize_linear(img, drows, dcols, area_mode=False):
+    """resize(INTER_LINEAR), or INTER_AREA's bilinear emulation when an axis enlarges (area_mode)"""
+    a, r, c, cn, st = _img(img)
+    dst = np.zeros((drows, dcols) if a.ndim == 2 else (drows, dcols, cn), np.uint8)
+    _check(lib().orc_resize_linear(_u8(a), r, c, cn, st, _u8(dst), drows, dcols, dst.strides[0], 1 if area_mode else 0))
+    return dst
+
+
+def scale_self(img, scale):
+    """transfer.rs:66-91"""
+    if scale == 1.0:
+        return np.array(img, copy=True)
+    r, c = img.shape[:2]
+    dc, dr = int(c * scale), int(r * scale)
+    return resize_linear(img, dr, dc, False) if scale > 1.0 else resize_area(img, dr, dc)
+
+
+def shrink_to(img, max_width, max_height):
+    """transfer.rs:93-126: never enlarges"""
+    r, c = img.shape[:2]
+    ws = 1.0 if max_width <= 0 else max_width / c
+    hs = 1.0 if max_height <= 0 else max_height / r
+    t = ws if ws < hs else hs
+    return np.array(img, copy=True) if t >= 1.0 else scale_self(img, t)
 
 
 def standard_deviation(v):

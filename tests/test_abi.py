@@ -124,7 +124,7 @@ def test_release_library_has_no_debug_switches():
     blob = open(os.path.join(PKG, "lib", "libomrdeskew.so"), "rb").read()
     for name in (b"OMR_RUNS_DBG", b"OMR_DISABLE_RUNS", b"OMR_DEBUG"):
         assert name not in blob, name
-    envs = set(re.findall(rb"OMR_[A-Z_]{3,}", blob))
+    envs = set(re.findall(rb"\x00(OMR_[A-Z_0-9]{3,})\x00", blob))  # whole NUL-terminated strings = getenv names
     assert envs <= {b"OMR_POOL_MB"}, envs
     src = open(os.path.join(PKG, "csrc", "runs.hip")).read()
     rel = src.split("#ifdef OMR_RUNS_DEBUG\n    {\n        const char *e = getenv", 1)

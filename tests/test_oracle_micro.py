@@ -174,3 +174,37 @@ def test_rgb2gray_weights(oracle):
     px = np.array([[[255, 0, 0], [0, 255, 0], [0, 0, 255], [90, 90, 90]]], np.uint8)
     assert oracle.rgb2gray(px).tolist() == [[(255 * 9798 + 16384) >> 15, (255 * 19235 + 16384) >> 15,
                                              (255 * 3735 + 16384) >> 15, 90]]
+
+
+def test_resize_linear_hand_computed(oracle):
+    """OpenCV's bilinear resize kernel (11-bit coefficients), the two ways the reference reaches it:
+    INTER_LINEAR (scale_self with scale > 1, transfer.rs:82-86) and INTER_AREA when an axis enlarges
+    (omr.rs:114-126 without a clamp, quirk B7).  Values below are worked by hand from resize.cpp's formulas."""
+    row = np.array([[0, 100]], np.uint8)
+    # INTER_LINEAR 2 -> 4: fx = (dx + 0.5) / 2 - 0.5 = -0.25 (clamped to the first pixel), 0.25, 0.75, 1.25 (clamped)
+    assert oracle.resize_linear(row, 1, 4, False).tolist() == [[0, 25, 75, 100]]
+    # INTER_AREA 2 -> 4 (integer enlargement): every area-mode fraction is 0 -> pixel replication
+    assert oracle.resize_linear(row, 1, 4, True).tolist() == [[0, 0, 100, 100]]
+    assert oracle.resize_area(row, 1, 4).tolist() == [[0, 0, 100, 100]]  # resize_area dispatches to it
+    # INTER_AREA 2 -> 3: fx = (dx + 1) - (sx + 1) * 1.5 = -0.5 -> 0, 0.5, 0 -> [0, 50, 100]
+    assert oracle.resize_area(row, 1, 3).tolist() == [[0, 50, 100]]
+    # the vertical pass uses the same tables; rows are clipped into the image instead of the coefficients
+    col = np.array([[0], [100]], np.uint8)
+    assert oracle.resize_linear(col, 4, 1, False)[:, 0].tolist() == [0, 25, 75, 100]
+    assert oracle.resize_area(col, 3, 1)[:, 0].tolist() == [0, 50, 100]
+    # one axis shrinks, the other enlarges: still the bilinear emulation for both axes
+    img = np.array([[0, 100, 200, 40], [80, 20, 60, 240]], np.uint8)
+    got = oracle.resize_area(img, 3, 2)
+    assert got.shape == (3, 2)
+    # x: 4 -> 2 in area mode: sx = 0, 2 and fx = 1 - 1*0.5 = 0.5, 2 - 3*0.5 = 0.5 -> mean of (0,1) and (2,3)
+    # y: 2 -> 3: fractions 0, 0.5, edge row -> rows [r0, (r0 + r1) / 2, r1]
+    assert got.tolist() == [[50, 120], [50, 135], [50, 150]]
+    # 3-channel interleaved data moves per channel
+    rgb = np.stack([row, row[:, ::-1], row], axis=2)
+    out = oracle.resize_linear(rgb, 1, 4, False)
+    assert out[0, :, 0].tolist() == [0, 25, 75, 100] and out[0, :, 1].tolist() == [100, 75, 25, 0]
+    # scale_self / shrink_to helpers (transfer.rs:66-126)
+    big = oracle.scale_self(np.arange(12, dtype=np.uint8).reshape(3, 4) * 20, 1.5)
+    assert big.shape == (4, 6)  # (3 * 1.5) as i32 = 4, (4 * 1.5) as i32 = 6
+    assert oracle.shrink_to(img, 100, 100).tolist() == img.tolist()  # never enlarges
+    assert oracle.shrink_to(img, 2, 0).shape == (1, 2)
