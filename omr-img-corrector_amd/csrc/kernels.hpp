@@ -156,10 +156,12 @@ hipError_t launch_erode3x_cross(const uint8_t *d_src, int64_t sstep, int rows, i
 hipError_t launch_resize_area_int_fast(const uint8_t *d_src, int64_t sstep, int srows, int scols, int cn,
                                        uint8_t *d_dst, int64_t dstep, int drows, int dcols, int kx, int ky,
                                        hipStream_t s);
-// 1-channel warpAffine, 4 px per lane; Minv is a HOST pointer (passed by value to the kernel).
-// Returns hipErrorInvalidValue when the destination is not 4-byte aligned (use the generic kernel).
-hipError_t launch_warp_c1_fast(const uint8_t *d_src, int64_t sstep, int srows, int scols, uint8_t *d_dst, int64_t dstep,
-                               int drows, int dcols, const double Minv[6], int interp, int border, hipStream_t s);
+// 1- / 3-channel warpAffine (NEAREST, LINEAR) with the source box of a 64x16 tile staged in LDS; Minv is a
+// HOST pointer (passed by value to the kernel).  Returns hipErrorInvalidValue for other channel counts (use the
+// generic kernel).
+hipError_t launch_warp_fast(const uint8_t *d_src, int64_t sstep, int srows, int scols, int cn, uint8_t *d_dst,
+                            int64_t dstep, int drows, int dcols, const double Minv[6], int interp, uint32_t border_rgba,
+                            hipStream_t s);
 // resize(INTER_LINEAR) (area_mode false) / INTER_AREA's bilinear emulation when an axis enlarges (true)
 hipError_t launch_resize_linear(const uint8_t *d_src, int64_t sstep, int srows, int scols, int cn, uint8_t *d_dst,
                                 int64_t dstep, int drows, int dcols, bool area_mode, hipStream_t s);

@@ -532,25 +532,23 @@ static int rotate_geometry(int rows, int cols, double angle_deg, double scale, i
     return OMR_OK;
 }
 
-// launch the warp of rotate_mat on device buffers (1 channel: 4 px / lane; otherwise generic)
+// launch the warp of rotate_mat on device buffers (1 / 3 channels: LDS-staged tiles; otherwise generic)
 static int rotate_launch(const uint8_t *d_src, int64_t sstep, int rows, int cols, int cn, const double M[6], int interp,
                          const uint8_t border_value[4], uint8_t *d_dst, int64_t dstep, int drows, int dcols,
                          hipStream_t s, DevBuf *keep)
 {
     double Minv[6];
     invert_affine(M, Minv);
-    if (cn == 1) {
-        hipError_t e = launch_warp_c1_fast(d_src, sstep, rows, cols, d_dst, dstep, drows, dcols, Minv, interp,
-                                           border_value[0], s);
+    uint32_t border = (uint32_t)border_value[0] | ((uint32_t)border_value[1] << 8) | ((uint32_t)border_value[2] << 16) |
+                      ((uint32_t)border_value[3] << 24);
+    if (cn == 1 || cn == 3) {
+        hipError_t e = launch_warp_fast(d_src, sstep, rows, cols, cn, d_dst, dstep, drows, dcols, Minv, interp, border, s);
         if (e == hipSuccess) return OMR_OK;
-        if (e != hipErrorInvalidValue) return fail_gpu("launch_warp_c1_fast", e);
-        (void)hipGetLastError();
+        return fail_gpu("launch_warp_fast", e);
     }
     OMR_HIP(keep->alloc(sizeof Minv));
     OMR_HIP(hipMemcpyAsync(keep->p, Minv, sizeof Minv, hipMemcpyHostToDevice, s));
     OMR_HIP(hipStreamSynchronize(s));  // Minv is a stack buffer
-    uint32_t border = (uint32_t)border_value[0] | ((uint32_t)border_value[1] << 8) | ((uint32_t)border_value[2] << 16) |
-                      ((uint32_t)border_value[3] << 24);
     if (interp == OMR_INTER_NEAREST)
         OMR_HIP(launch_warp_nn(d_src, sstep, rows, cols, cn, d_dst, dstep, drows, dcols, keep->as<double>(), border, s));
     else

@@ -91,9 +91,99 @@ __global__ __launch_bounds__(256) void erode3x_cross_kernel(const uint8_t *__res
     }
 }
 
+// The same filter at 4 pixels per lane.  Three passes of the 5-point minimum with a +inf border are one
+// minimum over the L1 ball of radius 3 (in-image points only):
+//     out(y, x) = min over dy in [-3, 3] of  h_{3 - |dy|}(y + dy, x),   h_r(y, x) = min over |dx| <= r of in(y, x + dx).
+// Tile = 256 x 64 output pixels; its source rows (+3 halo rows, +1 halo dword either side, 255 outside the
+// image) go to LDS with every load in flight at once.  A lane then owns one dword column (4 pixels) of a
+// 16-row strip and walks down its 22 source rows: the eight byte pairs (p_d, p_{d+2}), d = -3..4, come out of
+// the three dwords around the column with v_perm_b32 as zero-extended u16 pairs, so every minimum handles
+// two pixels (v_pk_min_u16): 12 for h_1..h_3 of the even and the odd pixels, 12 for the seven running
+// column minima that a source row feeds (row t closes output row t - 3).
+#define E4_TW 64  // dword columns per tile
+#define E4_SH 16  // output rows per strip
+#define E4_NS 4   // strips per tile
+#define E4_LW (E4_TW + 2)
+#define E4_LH (E4_SH * E4_NS + 6)
+
+__device__ __forceinline__ uint32_t pk_min(uint32_t a, uint32_t b)
+{
+    uint32_t r;
+    asm("v_pk_min_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+__global__ __launch_bounds__(256) void erode3x_cross_x4_kernel(const uint8_t *__restrict__ src, int64_t sstep, int rows,
+                                                               int cols, uint8_t *__restrict__ dst, int64_t dstep)
+{
+    __shared__ uint32_t tile[E4_LH][E4_LW + 1];
+    const int qx0 = blockIdx.x * E4_TW - 1;          // first dword column of the tile (halo)
+    const int y0 = blockIdx.y * (E4_SH * E4_NS) - 3;  // first source row of the tile (halo)
+    for (int i = threadIdx.x; i < E4_LH * E4_LW; i += 256) {
+        const int ly = i / E4_LW, lq = i - ly * E4_LW;
+        const int gy = y0 + ly, gx = (qx0 + lq) * 4;
+        uint32_t v = 0xffffffffu;
+        if ((unsigned)gy < (unsigned)rows && gx >= 0 && gx < cols) {
+            const uint8_t *S = src + (int64_t)gy * sstep + gx;
+            if (gx + 4 <= cols) {
+                v = *(const uint32_t *)S;
+            } else {  // the row ends inside this dword: pixels past the end stay +inf
+                for (int j = 0; gx + j < cols; j++) v = (v & ~(255u << (8 * j))) | ((uint32_t)S[j] << (8 * j));
+            }
+        }
+        tile[ly][lq] = v;
+    }
+    __syncthreads();
+    const int lq = threadIdx.x & (E4_TW - 1), strip = threadIdx.x / E4_TW;
+    const int gx = (qx0 + 1 + lq) * 4;
+    const int oy0 = blockIdx.y * (E4_SH * E4_NS) + strip * E4_SH;
+    if (gx >= cols || oy0 >= rows) return;
+    uint32_t aE[6], aO[6];  // running minima of output rows t - 2 .. t + 3 (t = source row being read)
+#pragma unroll
+    for (int i = 0; i < 6; i++) aE[i] = aO[i] = 0x00ff00ffu;
+#pragma unroll
+    for (int t = 0; t < E4_SH + 6; t++) {  // source row oy0 - 3 + t
+        const uint32_t *T = &tile[strip * E4_SH + t][lq];
+        const uint32_t L = T[0], C = T[1], R = T[2];
+        const uint32_t Pm3 = __builtin_amdgcn_perm(L, L, 0x0c030c01u), Pm2 = __builtin_amdgcn_perm(C, L, 0x0c040c02u);
+        const uint32_t Pm1 = __builtin_amdgcn_perm(C, L, 0x0c050c03u), P0 = C & 0x00ff00ffu;
+        const uint32_t P1 = __builtin_amdgcn_perm(C, C, 0x0c030c01u), P2 = __builtin_amdgcn_perm(R, C, 0x0c040c02u);
+        const uint32_t P3 = __builtin_amdgcn_perm(R, C, 0x0c050c03u), P4 = R & 0x00ff00ffu;
+        const uint32_t h1E = pk_min(pk_min(Pm1, P0), P1), h1O = pk_min(pk_min(P0, P1), P2);
+        const uint32_t h2E = pk_min(pk_min(h1E, Pm2), P2), h2O = pk_min(pk_min(h1O, Pm1), P3);
+        const uint32_t h3E = pk_min(pk_min(h2E, Pm3), P3), h3O = pk_min(pk_min(h2O, Pm2), P4);
+        // source row t feeds output rows t-3 (h0, closes it), t-2 (h1), t-1 (h2), t (h3), t+1 (h2), t+2 (h1), t+3 (h0)
+        const uint32_t oE = pk_min(aE[0], P0), oO = pk_min(aO[0], P1);
+        aE[0] = pk_min(aE[1], h1E), aO[0] = pk_min(aO[1], h1O);
+        aE[1] = pk_min(aE[2], h2E), aO[1] = pk_min(aO[2], h2O);
+        aE[2] = pk_min(aE[3], h3E), aO[2] = pk_min(aO[3], h3O);
+        aE[3] = pk_min(aE[4], h2E), aO[3] = pk_min(aO[4], h2O);
+        aE[4] = pk_min(aE[5], h1E), aO[4] = pk_min(aO[5], h1O);
+        aE[5] = P0, aO[5] = P1;
+        if (t >= 6) {
+            const int oy = oy0 + t - 6;
+            if (oy < rows) {
+                const uint32_t out = oE | (oO << 8);
+                uint8_t *D = dst + (int64_t)oy * dstep + gx;
+                if (gx + 4 <= cols && (((uintptr_t)D) & 3) == 0) {
+                    *(uint32_t *)D = out;
+                } else {
+                    for (int j = 0; gx + j < cols && j < 4; j++) D[j] = (uint8_t)(out >> (8 * j));
+                }
+            }
+        }
+    }
+}
+
 hipError_t launch_erode3x_cross(const uint8_t *d_src, int64_t sstep, int rows, int cols, uint8_t *d_dst, int64_t dstep,
                                 hipStream_t s)
 {
+    if ((sstep & 3) == 0 && ((uintptr_t)d_src & 3) == 0) {
+        hipLaunchKernelGGL(erode3x_cross_x4_kernel,
+                           dim3((cols + 4 * E4_TW - 1) / (4 * E4_TW), (rows + E4_SH * E4_NS - 1) / (E4_SH * E4_NS)), dim3(256),
+                           0, s, d_src, sstep, rows, cols, d_dst, dstep);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(erode3x_cross_kernel, dim3((cols + ER_TW - 1) / ER_TW, (rows + ER_TH - 1) / ER_TH), dim3(256), 0,
                        s, d_src, sstep, rows, cols, d_dst, dstep);
     return hipGetLastError();
@@ -144,11 +234,64 @@ __global__ __launch_bounds__(256) void resize_area_int_c1_kernel(const uint8_t *
     }
 }
 
+// The same reduction with the column sums taken first: a lane adds the k source rows of one dword column
+// straight from global memory (k coalesced dword loads in flight, 4 pixels each, byte pairs widened to
+// u16 with two masks and added with v_pk_add_u16), parks four u16 column sums in LDS, and after the
+// barrier a lane per output pixel adds k neighbouring column sums -- 2k LDS accesses per output pixel
+// instead of k*k byte reads, and no staging of the raw tile.
+#define RB_OW 64
+#define RB_OH 4
+#define RB_MAXK 16
+
+__global__ __launch_bounds__(256) void resize_area_int_colsum_kernel(const uint8_t *__restrict__ src, int64_t sstep,
+                                                                     uint8_t *__restrict__ dst, int64_t dstep, int drows,
+                                                                     int dcols, int k)
+{
+    __shared__ uint16_t colsum[RB_OH][RB_OW * RB_MAXK + 8];
+    const int ox0 = blockIdx.x * RB_OW, oy0 = blockIdx.y * RB_OH;
+    const int ow = min(RB_OW, dcols - ox0), oh = min(RB_OH, drows - oy0);
+    const int iw = ow * k, nq = (iw + 3) >> 2;  // source pixels / dword columns of the tile (iw may end inside a dword)
+    const uint8_t *S = src + (int64_t)oy0 * k * sstep + (int64_t)ox0 * k;  // 4-byte aligned: ox0 * k is a multiple of 64
+    for (int i = threadIdx.x; i < nq * oh; i += 256) {
+        const int ly = i / nq, q = i - ly * nq;
+        const uint8_t *P = S + (int64_t)ly * k * sstep + q * 4;
+        uint32_t e = 0, o = 0;  // (px0, px2) and (px1, px3) as u16 pairs
+        for (int yy = 0; yy < k; yy++) {
+            const uint32_t v = *(const uint32_t *)(P + (int64_t)yy * sstep);  // may read past iw inside the row pitch: unused
+            e += v & 0x00ff00ffu;
+            o += (v >> 8) & 0x00ff00ffu;
+        }
+        uint16_t *C = &colsum[ly][q * 4];
+        C[0] = (uint16_t)e;
+        C[1] = (uint16_t)o;
+        C[2] = (uint16_t)(e >> 16);
+        C[3] = (uint16_t)(o >> 16);
+    }
+    __syncthreads();
+    const int lx = threadIdx.x & (RB_OW - 1), ly = threadIdx.x / RB_OW;
+    if (lx < ow && ly < oh) {
+        int sum = 0;
+        for (int xx = 0; xx < k; xx++) sum += colsum[ly][lx * k + xx];
+        uint8_t out;
+        if (k == 2) out = (uint8_t)((sum + 2) >> 2);
+        else out = st_sat_u8((int)rintf((float)sum * (1.f / (float)(k * k))));
+        dst[(int64_t)(oy0 + ly) * dstep + ox0 + lx] = out;
+    }
+}
+
 hipError_t launch_resize_area_int_fast(const uint8_t *d_src, int64_t sstep, int srows, int scols, int cn,
                                        uint8_t *d_dst, int64_t dstep, int drows, int dcols, int kx, int ky,
                                        hipStream_t s)
 {
-    if (cn == 1 && kx == ky && kx >= 2 && kx <= RA_MAXK && drows * ky == srows && dcols * kx == scols) {
+    const bool full = cn == 1 && kx == ky && kx >= 2 && drows * ky == srows && dcols * kx == scols;
+    // the dword loads of the last column may run up to 3 bytes past the last source pixel of a row: the row pitch
+    // must cover them (always true for a pitch that is a multiple of 4)
+    if (full && kx <= RB_MAXK && (sstep & 3) == 0 && ((uintptr_t)d_src & 3) == 0) {
+        hipLaunchKernelGGL(resize_area_int_colsum_kernel, dim3((dcols + RB_OW - 1) / RB_OW, (drows + RB_OH - 1) / RB_OH),
+                           dim3(256), 0, s, d_src, sstep, d_dst, dstep, drows, dcols, kx);
+        return hipGetLastError();
+    }
+    if (full && kx <= RA_MAXK) {
         hipLaunchKernelGGL(resize_area_int_c1_kernel, dim3((dcols + RA_OW - 1) / RA_OW, (drows + RA_OH - 1) / RA_OH),
                            dim3(256), 0, s, d_src, sstep, d_dst, dstep, drows, dcols, kx);
         return hipGetLastError();
@@ -215,19 +358,145 @@ __global__ __launch_bounds__(256) void warp_c1_x4_kernel(const uint8_t *__restri
     }
 }
 
-hipError_t launch_warp_c1_fast(const uint8_t *d_src, int64_t sstep, int srows, int scols, uint8_t *d_dst, int64_t dstep,
-                               int drows, int dcols, const double Minv[6], int interp, int border, hipStream_t s)
+// The same warp with the source staged in LDS.  A workgroup owns a 64 x 16 destination tile; the affine map
+// takes it to a parallelogram whose bounding box (found from the four corner samples, one pixel of slack for
+// the rounding of the fixed-point tables, one more for the bilinear taps) is copied to LDS with row-contiguous
+// dword loads, border value outside the image -- so a tap is one LDS byte read with no bounds test, instead of
+// a byte gather through L1 along a slanted line (about 45 cache lines per wave).  A tile whose box does not
+// fit (strong magnification) takes its taps from global memory as before.
+#define WL_TW 64
+#define WL_TH 16
+#define WL_LDS 16384
+
+template <bool LINEAR>
+__device__ __forceinline__ int warp_tap_global(const uint8_t *__restrict__ src, int64_t sstep, int srows, int scols,
+                                               int cn, int Xf, int Yf, int border)
 {
+    if (!LINEAR) {
+        const int X = max(-32768, min(32767, Xf >> 10)), Y = max(-32768, min(32767, Yf >> 10));
+        return ((unsigned)X < (unsigned)scols && (unsigned)Y < (unsigned)srows) ? src[(int64_t)Y * sstep + (int64_t)X * cn] : border;
+    }
+    const int X = Xf >> 5, Y = Yf >> 5;
+    const int sx = max(-32768, min(32767, X >> 5)), sy = max(-32768, min(32767, Y >> 5));
+    const int fx = X & 31, fy = Y & 31;
+    if (sx >= scols || sx + 1 < 0 || sy >= srows || sy + 1 < 0) return border;
+    const bool in_x0 = sx >= 0 && sx < scols, in_x1 = sx + 1 >= 0 && sx + 1 < scols;
+    const bool in_y0 = sy >= 0 && sy < srows, in_y1 = sy + 1 >= 0 && sy + 1 < srows;
+    const int v0 = in_x0 && in_y0 ? src[(int64_t)sy * sstep + (int64_t)sx * cn] : border;
+    const int v1 = in_x1 && in_y0 ? src[(int64_t)sy * sstep + (int64_t)(sx + 1) * cn] : border;
+    const int v2 = in_x0 && in_y1 ? src[(int64_t)(sy + 1) * sstep + (int64_t)sx * cn] : border;
+    const int v3 = in_x1 && in_y1 ? src[(int64_t)(sy + 1) * sstep + (int64_t)(sx + 1) * cn] : border;
+    const int w0 = (32 - fy) * (32 - fx) * 32, w1 = (32 - fy) * fx * 32, w2 = fy * (32 - fx) * 32, w3 = fy * fx * 32;
+    return st_sat_u8((v0 * w0 + v1 * w1 + v2 * w2 + v3 * w3 + (1 << 14)) >> 15);
+}
+
+template <int CN, bool LINEAR>
+__global__ __launch_bounds__(256) void warp_lds_kernel(const uint8_t *__restrict__ src, int64_t sstep, int srows,
+                                                       int scols, uint8_t *__restrict__ dst, int64_t dstep, int drows,
+                                                       int dcols, const WarpM W, uint32_t border_rgba)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t box[WL_LDS];
+    const double *M = W.m;
+    const int rd = LINEAR ? 16 : 512;
+    const int tx0 = blockIdx.x * WL_TW, ty0 = blockIdx.y * WL_TH;
+    const int tx1 = min(dcols, tx0 + WL_TW) - 1, ty1 = min(drows, ty0 + WL_TH) - 1;
+    // fixed-point source coordinates (OpenCV's tables) of the tile's corner samples: wave-uniform.  X0(y) and
+    // adelta(x) are both monotone, so the four corners bound every sample of the tile.
+    auto FX = [&](int x, int y) { return (int)rint((M[1] * (double)y + M[2]) * 1024.0) + rd + (int)rint(M[0] * (double)x * 1024.0); };
+    auto FY = [&](int x, int y) { return (int)rint((M[4] * (double)y + M[5]) * 1024.0) + rd + (int)rint(M[3] * (double)x * 1024.0); };
+    const int cx[4] = {FX(tx0, ty0) >> 10, FX(tx1, ty0) >> 10, FX(tx0, ty1) >> 10, FX(tx1, ty1) >> 10};
+    const int cy[4] = {FY(tx0, ty0) >> 10, FY(tx1, ty0) >> 10, FY(tx0, ty1) >> 10, FY(tx1, ty1) >> 10};
+    const int bx0 = min(min(cx[0], cx[1]), min(cx[2], cx[3])) - 1;
+    const int bx1 = max(max(cx[0], cx[1]), max(cx[2], cx[3])) + 1 + (LINEAR ? 1 : 0);
+    const int by0 = min(min(cy[0], cy[1]), min(cy[2], cy[3])) - 1;
+    const int by1 = max(max(cy[0], cy[1]), max(cy[2], cy[3])) + 1 + (LINEAR ? 1 : 0);
+    // the box in BYTES of a source row, widened to whole dwords of the row
+    const int bb0 = (bx0 * CN) & ~3, bb1 = ((bx1 + 1) * CN + 3) & ~3;  // [bb0, bb1)
+    const int bwb = bb1 - bb0, bh = by1 - by0 + 1;
+    const bool staged = bwb > 0 && bh > 0 && (int64_t)bwb * bh <= WL_LDS && bx0 > -30000 && bx1 < 30000 &&
+                        by0 > -30000 && by1 < 30000;
+    const int rowb = scols * CN;  // bytes of a source row that hold pixels
+    if (staged) {
+        const int bq = bwb >> 2;
+        const bool aligned = ((sstep | (int64_t)(uintptr_t)src) & 3) == 0;
+        for (int i = threadIdx.x; i < bq * bh; i += 256) {
+            const int ly = i / bq, lq = i - ly * bq;
+            const int gy = by0 + ly, gb = bb0 + lq * 4;
+            uint32_t v;
+            if (aligned && (unsigned)gy < (unsigned)srows && gb >= 0 && gb + 4 <= rowb) {
+                v = *(const uint32_t *)(src + (int64_t)gy * sstep + gb);
+            } else {
+                v = 0;
+                for (int j = 0; j < 4; j++) {
+                    const int b = gb + j;  // byte b of row gy: pixel b / CN, channel b % CN (floor semantics for b < 0)
+                    const int ch = ((b % CN) + CN) % CN;
+                    uint32_t px = (border_rgba >> (8 * ch)) & 255u;
+                    if ((unsigned)gy < (unsigned)srows && b >= 0 && b < rowb) px = src[(int64_t)gy * sstep + b];
+                    v |= px << (8 * j);
+                }
+            }
+            *(uint32_t *)&box[ly * bwb + lq * 4] = v;
+        }
+    }
+    __syncthreads();
+    const int lx = (threadIdx.x & 15) * 4, ly = threadIdx.x >> 4;
+    const int x0 = tx0 + lx, y = ty0 + ly;
+    if (x0 >= dcols || y >= drows) return;
+    const int X0 = (int)rint((M[1] * (double)y + M[2]) * 1024.0) + rd;
+    const int Y0 = (int)rint((M[4] * (double)y + M[5]) * 1024.0) + rd;
+    uint8_t o[4 * CN];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int x = x0 + j;
+        const int Xf = X0 + (int)rint(M[0] * (double)x * 1024.0), Yf = Y0 + (int)rint(M[3] * (double)x * 1024.0);
+        if (!staged) {
+#pragma unroll
+            for (int c = 0; c < CN; c++)
+                o[j * CN + c] = (uint8_t)warp_tap_global<LINEAR>(src + c, sstep, srows, scols, CN, Xf, Yf, (border_rgba >> (8 * c)) & 255);
+        } else if (!LINEAR) {
+            const uint8_t *B = &box[((Yf >> 10) - by0) * bwb + (Xf >> 10) * CN - bb0];
+#pragma unroll
+            for (int c = 0; c < CN; c++) o[j * CN + c] = B[c];
+        } else {
+            const int X = Xf >> 5, Y = Yf >> 5;
+            const int fx = X & 31, fy = Y & 31;
+            const uint8_t *B = &box[((Y >> 5) - by0) * bwb + (X >> 5) * CN - bb0];
+            const int w0 = (32 - fy) * (32 - fx) * 32, w1 = (32 - fy) * fx * 32, w2 = fy * (32 - fx) * 32, w3 = fy * fx * 32;
+#pragma unroll
+            for (int c = 0; c < CN; c++)
+                o[j * CN + c] = st_sat_u8((B[c] * w0 + B[CN + c] * w1 + B[bwb + c] * w2 + B[bwb + CN + c] * w3 + (1 << 14)) >> 15);
+        }
+    }
+    uint8_t *D = dst + (int64_t)y * dstep + (int64_t)x0 * CN;
+    if (x0 + 4 <= dcols && ((uintptr_t)D & 3) == 0) {  // packed CONTAIN canvases have odd widths: rows start anywhere
+#pragma unroll
+        for (int q = 0; q < CN; q++)
+            ((uint32_t *)D)[q] = (uint32_t)o[4 * q] | ((uint32_t)o[4 * q + 1] << 8) | ((uint32_t)o[4 * q + 2] << 16) |
+                                 ((uint32_t)o[4 * q + 3] << 24);
+    } else {
+        for (int j = 0; j < 4 * CN && x0 * CN + j < dcols * CN; j++) D[j] = o[j];
+    }
+}
+
+// 1- and 3-channel warpAffine (NEAREST / LINEAR) through the LDS-staged kernel: the gray helpers and the final
+// deskew of the colour scan (omr.rs:408-445, core/src/main.rs:72-81).  Returns hipErrorInvalidValue for other
+// channel counts (the caller uses the generic kernel).
+hipError_t launch_warp_fast(const uint8_t *d_src, int64_t sstep, int srows, int scols, int cn, uint8_t *d_dst,
+                            int64_t dstep, int drows, int dcols, const double Minv[6], int interp, uint32_t border_rgba,
+                            hipStream_t s)
+{
+    if (cn != 1 && cn != 3) return hipErrorInvalidValue;
     WarpM W;
     for (int i = 0; i < 6; i++) W.m[i] = Minv[i];
-    if ((dstep & 3) != 0 || ((uintptr_t)d_dst & 3) != 0) return hipErrorInvalidValue;  // caller falls back
-    dim3 grid((dcols + 1023) / 1024, drows);
-    if (interp == 0)
-        hipLaunchKernelGGL((warp_c1_x4_kernel<false>), grid, dim3(256), 0, s, d_src, sstep, srows, scols, d_dst, dstep,
-                           drows, dcols, W, border);
-    else
-        hipLaunchKernelGGL((warp_c1_x4_kernel<true>), grid, dim3(256), 0, s, d_src, sstep, srows, scols, d_dst, dstep,
-                           drows, dcols, W, border);
+    dim3 grid((dcols + WL_TW - 1) / WL_TW, (drows + WL_TH - 1) / WL_TH);
+#define WARP_LAUNCH(CN_, LIN_)                                                                                         \
+    hipLaunchKernelGGL((warp_lds_kernel<CN_, LIN_>), grid, dim3(256), 0, s, d_src, sstep, srows, scols, d_dst, dstep, \
+                       drows, dcols, W, border_rgba)
+    if (cn == 1 && interp == 0) WARP_LAUNCH(1, false);
+    else if (cn == 1) WARP_LAUNCH(1, true);
+    else if (interp == 0) WARP_LAUNCH(3, false);
+    else WARP_LAUNCH(3, true);
+#undef WARP_LAUNCH
     return hipGetLastError();
 }
 

@@ -649,3 +649,28 @@ def test_resize_area_device_all_branches(oracle):
         torch.cuda.synchronize()
         exp = oracle.resize_area(img, dr, dc)
         assert (out.cpu().numpy() == exp).all(), (dr, dc)
+
+
+def test_fused_erode_fast_path_edges(oracle):
+    """erode3x_cross_x4_kernel (4 px per lane, packed 16-bit minima): widths that end inside a dword, padded
+    row pitch, heights that end inside a strip / tile, tiny images, all-black and checkerboard content."""
+    import torch
+    from oics._lib import check, lib
+    rng = np.random.Generator(np.random.PCG64(123))
+    for (rows, cols, pitch) in ((70, 259, 260), (64, 256, 256), (1, 4, 4), (5, 3, 4), (129, 1030, 1032), (200, 77, 80)):
+        for kind in ("rand", "sparse", "check"):
+            if kind == "rand":
+                img = rng.integers(0, 256, (rows, cols), dtype=np.uint8)
+            elif kind == "sparse":
+                img = np.where(rng.random((rows, cols)) < 0.02, 0, 255).astype(np.uint8)
+            else:
+                img = (((np.arange(rows)[:, None] // 3 + np.arange(cols)[None, :] // 5) & 1) * 200 + 20).astype(np.uint8)
+            buf = np.full((rows, pitch), 7, np.uint8)
+            buf[:, :cols] = img
+            d = torch.from_numpy(buf).to("cuda:0")
+            out = torch.full((rows, pitch), 9, dtype=torch.uint8, device="cuda:0")
+            check(lib().omr_erode3_device(d.data_ptr(), pitch, rows, cols, out.data_ptr(), pitch, None))
+            torch.cuda.synchronize()
+            got = out.cpu().numpy()
+            assert (got[:, :cols] == oracle.erode_cross3(img, 3)).all(), (rows, cols, kind)
+            assert (got[:, cols:] == 9).all()  # padding bytes of the destination stay untouched

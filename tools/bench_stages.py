@@ -61,4 +61,29 @@ for interp, nm in ((0, "NEAREST"), (1, "LINEAR")):
         timeit("deskew warp %s %s gray" % (nm, cn),
                lambda: check(L.omr_rotate_device(d_gray.data_ptr(), COLS, ROWS, COLS, 1, -th, 1.0, interp, white.ctypes.data_as(u8p), clip, d_out.data_ptr(), dc.value, dr.value, dc.value, None)),
                N + dr.value * dc.value)
+# the production final warp runs on the 3-channel (BGR) scan: omr.rs:408-445 (NEAREST, CONTAIN), core/src/main.rs:72-81 (LINEAR, CONTAIN)
+for interp, nm in ((0, "NEAREST"), (1, "LINEAR")):
+    dr, dc = C.c_int32(), C.c_int32()
+    check(L.omr_rotate_size(ROWS, COLS, -th, 1, C.byref(dr), C.byref(dc)))
+    d_out3 = torch.empty((dr.value, dc.value, 3), dtype=torch.uint8, device=dev)
+    timeit("deskew warp %s CONTAIN BGR" % nm,
+           lambda: check(L.omr_rotate_device(d_rgb.data_ptr(), COLS * 3, ROWS, COLS, 3, -th, 1.0, interp, white.ctypes.data_as(u8p), 1, d_out3.data_ptr(), dc.value * 3, dr.value, dc.value, None)),
+           3 * (N + dr.value * dc.value))
+# the same kernels on nine scans stacked into one 2480 x 31572 image (launch ramp and tail amortised: the
+# per-byte rate a batch pipeline sees)
+T = 9
+d_tall = d_gray.repeat(T, 1).contiguous()
+d_tall_o = torch.empty_like(d_tall)
+TR = ROWS * T
+timeit("[x9 tall] erode 3x3 cross x3", lambda: check(L.omr_erode3_device(d_tall.data_ptr(), COLS, TR, COLS, d_tall_o.data_ptr(), COLS, None)), 2 * N * T)
+timeit("[x9 tall] threshold(127,255)", lambda: check(L.omr_threshold_binary_device(d_tall.data_ptr(), COLS, TR, COLS, d_tall_o.data_ptr(), COLS, None)), 2 * N * T)
+TR5 = TR - TR % 5
+d_tall_s = torch.empty((TR5 // 5, C5 // 5), dtype=torch.uint8, device=dev)
+timeit("[x9 tall] resize INTER_AREA /5", lambda: check(L.omr_resize_area_device(d_tall.data_ptr(), COLS, TR5, C5, 1, d_tall_s.data_ptr(), C5 // 5, TR5 // 5, C5 // 5, None)), TR5 * C5 + TR5 * C5 // 25)
+dr, dc = C.c_int32(), C.c_int32()
+check(L.omr_rotate_size(TR, COLS, -1.0, 0, C.byref(dr), C.byref(dc)))
+for interp, nm in ((0, "NEAREST"), (1, "LINEAR")):
+    timeit("[x9 tall] warp %s DEFAULT gray (1 deg)" % nm,
+           lambda: check(L.omr_rotate_device(d_tall.data_ptr(), COLS, TR, COLS, 1, -1.0, 1.0, interp, white.ctypes.data_as(u8p), 0, d_tall_o.data_ptr(), COLS, TR, COLS, None)),
+           2 * N * T)
 print(json.dumps(out))
