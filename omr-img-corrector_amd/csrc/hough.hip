@@ -327,6 +327,32 @@ __device__ __forceinline__ void list_store(uint32_t *p, uint32_t v)
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+#ifdef OMR_RUNS_DEBUG
+// debug build only: wave 0 / lane 0 phase clocks of scan 0 [draw, vote+argmax, walk pass 1, pass 2 + un-vote,
+// re-test, served points, pass-1 rounds, pass-2 rounds]; read with omr_debug_ppht_stamps()
+__device__ unsigned long long g_ppht_stamps[8];
+#define PP_CLK(V)                                                                  \
+    unsigned long long V = 0;                                                      \
+    if (tid == 0 && scan == 0) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(V)::"memory");
+#define PP_ADD(I, T0, T1) \
+    if (tid == 0 && scan == 0) g_ppht_stamps[I] += (T1) - (T0);
+#define PP_CNT(I) \
+    if (tid == 0 && scan == 0) g_ppht_stamps[I] += 1;
+hipError_t debug_ppht_stamps(unsigned long long out[8], bool reset)
+{
+    hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ppht_stamps), 8 * sizeof(unsigned long long));
+    if (e == hipSuccess && reset) {
+        unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        e = hipMemcpyToSymbol(HIP_SYMBOL(g_ppht_stamps), z, sizeof z);
+    }
+    return e;
+}
+#else
+#define PP_CLK(V)
+#define PP_ADD(I, T0, T1)
+#define PP_CNT(I)
+#endif
+
 __global__ __launch_bounds__(OMR_PPHT_THREADS) void ppht_kernel(const PphtArgs a)
 {
     __shared__ PphtShared sh;
@@ -354,6 +380,7 @@ __global__ __launch_bounds__(OMR_PPHT_THREADS) void ppht_kernel(const PphtArgs a
     volatile uint32_t *shr = sh.r;
 
     for (;;) {
+        PP_CLK(c0)
         if (wave == 0) {
             while (pend == 0 && count > 0) {  // ---- a draw round
                 const int nd = min(64, count);
@@ -418,6 +445,9 @@ __global__ __launch_bounds__(OMR_PPHT_THREADS) void ppht_kernel(const PphtArgs a
         __syncthreads();
         const int pi = sh.i, pj = sh.j;
         if (pi < 0) break;
+        PP_CLK(c1)
+        PP_ADD(0, c0, c1)
+        PP_CNT(5)
         // ---- vote: r = cvRound(j * cos/rho + i * sin/rho) in float32, no contraction
         long long key = (long long)0x8000000000000000ull;
         if (voter) {
@@ -441,6 +471,8 @@ __global__ __launch_bounds__(OMR_PPHT_THREADS) void ppht_kernel(const PphtArgs a
             if ((long long)sh.key[w] > best) best = (long long)sh.key[w];
         const int max_val = (int)(best >> 32);
         const int max_n = 0x7fffffff - (int)(uint32_t)(best & 0xffffffffll);
+        PP_CLK(c2)
+        PP_ADD(1, c1, c2)
         if (max_val >= a.threshold) {  // with threshold 0 false only when un-votes drove the bins negative
             const PphtWalk wk = a.walk[max_n];
             int x0 = pj, y0 = pi;
@@ -451,6 +483,7 @@ __global__ __launch_bounds__(OMR_PPHT_THREADS) void ppht_kernel(const PphtArgs a
             // ---- first pass: the segment's two ends, both directions side by side
             bool on0 = false;  // this thread's position of round 0 holds a point
             for (int base = 0;; base += 128) {
+                PP_CNT(6)
                 const bool live = !sh.stop[dir];
                 bool out = false, on = false;
                 if (live) {
@@ -498,6 +531,8 @@ __global__ __launch_bounds__(OMR_PPHT_THREADS) void ppht_kernel(const PphtArgs a
                 __syncthreads();
                 if (sh.stop[0] && sh.stop[1]) break;
             }
+            PP_CLK(c3)
+            PP_ADD(2, c2, c3)
             // line ends and the length test
             int ex[2], ey[2];
             for (int k = 0; k < 2; k++) {
@@ -513,6 +548,7 @@ __global__ __launch_bounds__(OMR_PPHT_THREADS) void ppht_kernel(const PphtArgs a
             // Round 0 reuses the first pass's flags (the mask has not changed since).
             const int last = sh.end_t[dir], last_max = max(sh.end_t[0], sh.end_t[1]);
             for (int base = 0; base <= last_max; base += 128) {
+                PP_CNT(7)
                 const int t = base + slot;
                 bool on = false;
                 uint32_t ptw = 0;
@@ -566,18 +602,29 @@ __global__ __launch_bounds__(OMR_PPHT_THREADS) void ppht_kernel(const PphtArgs a
                                             c[i] += c[j];
                                             c[j] = 0;
                                         }
+                                if (a.latency_mode) {
+                                    // a single scan that is waited for: fire-and-forget RMW atomics -- nothing in this
+                                    // lane waits for the bins' old values (the load + store pairs below expose one
+                                    // memory round trip per chunk of eight points)
 #pragma unroll
-                                for (int i = 0; i < 8; i++)
-                                    if (c[i]) v[i] = __hip_atomic_load(row + bin[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                    for (int i = 0; i < 8; i++)
+                                        if (c[i]) __hip_atomic_fetch_sub(row + bin[i], c[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                } else {
 #pragma unroll
-                                for (int i = 0; i < 8; i++)
-                                    if (c[i])
-                                        __hip_atomic_store(row + bin[i], v[i] - c[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                    for (int i = 0; i < 8; i++)
+                                        if (c[i]) v[i] = __hip_atomic_load(row + bin[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                                    for (int i = 0; i < 8; i++)
+                                        if (c[i])
+                                            __hip_atomic_store(row + bin[i], v[i] - c[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                }
                             }
                         }
                     }
                 }
             }
+            PP_CLK(c4)
+            PP_ADD(3, c3, c4)
             if (tid == 0 && good) {
                 if (nl < a.cap) {
                     lines[4 * nl] = ex[0];
@@ -588,11 +635,14 @@ __global__ __launch_bounds__(OMR_PPHT_THREADS) void ppht_kernel(const PphtArgs a
                 nl++;
             }
         }
+        PP_CLK(c5)
         __syncthreads();  // erasures are complete: wave 0 re-tests the points it still holds
         if (wave == 0 && pend) {
             const bool on = ((pend >> lane) & 1ull) && mask_test(mask, (int)(pt >> 16), (int)(pt & 0xffffu), TX);
             pend = __ballot(on);
         }
+        PP_CLK(c6)
+        PP_ADD(4, c5, c6)
     }
     if (tid == 0) a.n_lines[scan] = nl;
 }

@@ -47,9 +47,13 @@ struct PphtArgs {
     int32_t *lines;           // n x cap x 4
     int32_t cap;
     int32_t *n_lines;         // [n]
+    int32_t latency_mode;     // 1: few scans, waited for (un-votes as no-return atomics); 0: batch throughput
 };
 #define OMR_PPHT_THREADS 256  // lane = accumulator angle; numangle <= 256
 hipError_t launch_ppht(const PphtArgs &a, int n, hipStream_t s);
+#ifdef OMR_RUNS_DEBUG
+hipError_t debug_ppht_stamps(unsigned long long out[8], bool reset);
+#endif
 
 // counts[i] = #{ j : |a[i] - a[j]| < 0.1 } in f32 (hough.rs:77-83) or in f64 on widened values
 // (omr.rs:278-284)

@@ -160,6 +160,7 @@ int ppht_device(uint8_t *d_edges, int32_t *d_rowcnt, int rows, int cols, int n, 
     a.lines = lines.as<int32_t>();
     a.cap = cap;
     a.n_lines = nlines.as<int32_t>();
+    a.latency_mode = n <= 4 ? 1 : 0;  // up to four scans cannot fill the chip anyway: favour their latency
     OMR_HIP(launch_ppht(a, n, s));
     std::vector<int32_t> nl((size_t)n);
     OMR_HIP(hipMemcpyAsync(nl.data(), nlines.p, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, s));
@@ -523,3 +524,11 @@ int omr_correct_default(const omr_image *src, uint16_t projection_max_angle, dou
 }
 
 }  // extern "C"
+
+#ifdef OMR_RUNS_DEBUG
+extern "C" int omr_debug_ppht_stamps(unsigned long long *out8, int reset)
+{
+    OMR_HIP(omr::debug_ppht_stamps(out8, reset != 0));
+    return OMR_OK;
+}
+#endif
