@@ -132,9 +132,51 @@ __global__ __launch_bounds__(FFT_THREADS) void fft_pass_kernel(const FftPass p)
     cfloat *P = fft_forward_lds(A, B, m, p.log2m, p.W, tid);
     cfloat *Q = P == A ? B : A;
     cfloat *dst = p.dst + line * p.line_stride;
+    // spectrum-picture mode (column pass): point k of this line is F(k, line); it lands at the quadrant-swapped
+    // position of the |F| image
+    const bool mag_mode = p.mag_dst != nullptr;
+    const int cxh = p.img_cols / 2, cyh = p.img_rows / 2;
+    const int sc = (int)line;
+    const int sc_sw = sc < cxh ? sc + cxh : sc - cxh;
+    float lo = __builtin_inff(), hi = -__builtin_inff();
+    auto emit = [&](int k, cfloat v) {
+        if (!mag_mode) {
+            dst[(int64_t)k * p.elem_stride] = v;
+            return;
+        }
+        // only points inside the four quadrants move; an odd last row / column keeps its place (fft.rs:69-74)
+        const bool inq = sc < 2 * cxh && k < 2 * cyh;
+        const int orow = inq ? (k < cyh ? k + cyh : k - cyh) : k, oc = inq ? sc_sw : sc;
+        const float mg = sqrtf(v.x * v.x + v.y * v.y);
+        p.mag_dst[(int64_t)orow * p.mag_pitch + oc] = mg;
+        lo = fminf(lo, mg);
+        hi = fmaxf(hi, mg);
+    };
+    auto finish = [&]() {  // per-workgroup extrema of |F| (8 waves)
+        if (!mag_mode) return;
+        for (int off = 32; off > 0; off >>= 1) {
+            lo = fminf(lo, __shfl_down(lo, off));
+            hi = fmaxf(hi, __shfl_down(hi, off));
+        }
+        __syncthreads();  // every wave is done with the LDS buffers
+        float *red = (float *)lds_raw;
+        if ((tid & 63) == 0) {
+            red[2 * (tid >> 6)] = lo;
+            red[2 * (tid >> 6) + 1] = hi;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            for (int w = 1; w < FFT_THREADS / 64; w++) {
+                lo = fminf(lo, red[2 * w]);
+                hi = fmaxf(hi, red[2 * w + 1]);
+            }
+            p.part[2 * blockIdx.x] = lo;
+            p.part[2 * blockIdx.x + 1] = hi;
+        }
+    };
     if (!blue) {
-        for (int k = tid; k < n; k += FFT_THREADS)
-            dst[(int64_t)k * p.elem_stride] = cfloat{P[k].x * p.out_scale, P[k].y * p.out_scale};
+        for (int k = tid; k < n; k += FFT_THREADS) emit(k, cfloat{P[k].x * p.out_scale, P[k].y * p.out_scale});
+        finish();
         return;
     }
     // convolution with the conjugate chirp: pointwise product, then an inverse FFT as conj(FFT(conj(.))) / m
@@ -146,8 +188,9 @@ __global__ __launch_bounds__(FFT_THREADS) void fft_pass_kernel(const FftPass p)
     const float inv_m = 1.0f / (float)m;
     for (int k = tid; k < n; k += FFT_THREADS) {
         const cfloat c = cmul(cfloat{R[k].x * inv_m, -R[k].y * inv_m}, p.chirp[k]);
-        dst[(int64_t)k * p.elem_stride] = cfloat{c.x * p.out_scale, c.y * p.out_scale};
+        emit(k, cfloat{c.x * p.out_scale, c.y * p.out_scale});
     }
+    finish();
 }
 
 hipError_t launch_fft_pass(const FftPass &p, hipStream_t s)
@@ -224,94 +267,64 @@ __global__ __launch_bounds__(1024) void minmax_final_kernel(const float *__restr
     }
 }
 
-// out(r, c) = |F(sr, sc)|: quadrants of cx x cy swapped diagonally, an odd last row / column untouched.
-// Block = 1024 consecutive pixels of one row (4 per thread), so source and destination are both runs.
-__global__ __launch_bounds__(256) void spec_magnitude_kernel(const cfloat *__restrict__ F, int rows, int cols, int pitch,
-                                                             float *__restrict__ mag, float *__restrict__ part)
+hipError_t launch_minmax_final(const float *d_part, int n, uint32_t *d_minmax, hipStream_t s)
 {
-    const int cx = cols / 2, cy = rows / 2;
-    const int r = blockIdx.y;
-    const int sr = r < 2 * cy ? (r < cy ? r + cy : r - cy) : r;
-    float lo = __builtin_inff(), hi = -__builtin_inff();
-#pragma unroll
-    for (int u = 0; u < 4; u++) {
-        const int c = blockIdx.x * 1024 + u * 256 + threadIdx.x;
-        if (c < cols) {
-            const int sc = (r < 2 * cy && c < 2 * cx) ? (c < cx ? c + cx : c - cx) : c;
-            const int srr = (c < 2 * cx) ? sr : r;  // the odd last column is outside every quadrant
-            const cfloat v = F[(int64_t)srr * pitch + sc];
-            const float m = sqrtf(v.x * v.x + v.y * v.y);
-            mag[(int64_t)r * cols + c] = m;
-            lo = fminf(lo, m);
-            hi = fmaxf(hi, m);
-        }
-    }
-    block_minmax(lo, hi, part, blockIdx.y * gridDim.x + blockIdx.x);
-}
-
-hipError_t launch_spec_magnitude(const cfloat *d_F, int rows, int cols, int pitch, float *d_mag, float *d_part, uint32_t *d_minmax,
-                                 hipStream_t s)
-{
-    const dim3 grid((cols + 1023) / 1024, rows);
-    hipLaunchKernelGGL(spec_magnitude_kernel, grid, dim3(256), 0, s, d_F, rows, cols, pitch, d_mag, d_part);
-    hipLaunchKernelGGL(minmax_final_kernel, dim3(1), dim3(1024), 0, s, d_part, (int)(grid.x * grid.y), d_minmax);
+    hipLaunchKernelGGL(minmax_final_kernel, dim3(1), dim3(1024), 0, s, d_part, n, d_minmax);
     return hipGetLastError();
 }
 
-// fft.rs:90-122 in float32, the double alpha / beta of convert_to cast to float as OpenCV does
-__global__ __launch_bounds__(256) void spec_normalise_kernel(const float *__restrict__ mag, int64_t total,
-                                                             const uint32_t *__restrict__ mm_in,
-                                                             uint8_t *__restrict__ mag_u8, float *__restrict__ lg,
-                                                             float *__restrict__ part)
+// fft.rs:90-122, :134-138 in float32, the double alpha / beta of convert_to cast to float as OpenCV does.
+// 4 pixels per lane along a row.
+__device__ __forceinline__ float spec_m3(float mg, float beta, float alpha)
 {
-    const double mn = (double)key2f(mm_in[0]), mx = (double)key2f(mm_in[1]);
-    const float beta = (float)(-mn), alpha = (float)(1.0 / (mx - mn));
-    float lo = __builtin_inff(), hi = -__builtin_inff();
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-        const float c1 = mag[i] * 1.0f + beta;
-        const float c2 = c1 * alpha + 0.0f;
-        const float m3 = c2 * 255.0f + 0.0f;                      // fft_magnitude
-        const float u = rintf(m3 * 255.0f + 0.0f);                // convert_to(CV_8UC1, 255)
-        mag_u8[i] = (uint8_t)fminf(fmaxf(u, 0.f), 255.f);
-        const float l = logf(m3 * 1.0f + (float)(1.0 / 255.0));  // fft_magnitude_log before its correction
-        lg[i] = l;
-        lo = fminf(lo, l);
-        hi = fmaxf(hi, l);
-    }
-    block_minmax(lo, hi, part, blockIdx.x);
+    const float c1 = mg * 1.0f + beta;
+    const float c2 = c1 * alpha + 0.0f;
+    return c2 * 255.0f + 0.0f;  // fft_magnitude
 }
+__device__ __forceinline__ float spec_log(float m3) { return logf(m3 * 1.0f + (float)(1.0 / 255.0)); }
 
-hipError_t launch_spec_normalise(const float *d_mag, int rows, int cols, const uint32_t *d_minmax_in, uint8_t *d_mag_u8,
-                                 float *d_log, float *d_part, uint32_t *d_minmax_out, hipStream_t s)
-{
-    const int64_t total = (int64_t)rows * cols;
-    int blocks = (int)((total + 1023) / 1024 < 8192 ? (total + 1023) / 1024 : 8192);
-    if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(spec_normalise_kernel, dim3(blocks), dim3(256), 0, s, d_mag, total, d_minmax_in, d_mag_u8, d_log,
-                       d_part);
-    hipLaunchKernelGGL(minmax_final_kernel, dim3(1), dim3(1024), 0, s, d_part, blocks, d_minmax_out);
-    return hipGetLastError();
-}
-
-__global__ __launch_bounds__(256) void spec_log_u8_kernel(const float *__restrict__ lg, int64_t total,
-                                                          const uint32_t *__restrict__ mm, uint8_t *__restrict__ out)
+__global__ __launch_bounds__(256) void spec_pictures_kernel(const float *__restrict__ mag, int rows, int cols, int mag_pitch,
+                                                            const uint32_t *__restrict__ mm, uint8_t *__restrict__ mag_u8,
+                                                            uint8_t *__restrict__ log_u8)
 {
     const double mn = (double)key2f(mm[0]), mx = (double)key2f(mm[1]);
     const float beta = (float)(-mn), alpha = (float)(1.0 / (mx - mn));
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-        const float c1 = lg[i] * 1.0f + beta;
-        const float c2 = c1 * alpha + 0.0f;
-        const float u = rintf(c2 * 255.0f + 0.0f);
-        out[i] = (uint8_t)fminf(fmaxf(u, 0.f), 255.f);
+    // extrema of the log picture = the log picture of the extrema (monotone float steps)
+    const double lmn = (double)spec_log(spec_m3((float)mn, beta, alpha)), lmx = (double)spec_log(spec_m3((float)mx, beta, alpha));
+    const float beta2 = (float)(-lmn), alpha2 = (float)(1.0 / (lmx - lmn));
+    const int r = blockIdx.y;
+    const int c0 = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (c0 >= cols) return;
+    const float *M = mag + (int64_t)r * mag_pitch + c0;
+    uint32_t om = 0, ol = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        if (c0 + j < cols) {
+            const float m3 = spec_m3(M[j], beta, alpha);
+            const float u = rintf(m3 * 255.0f + 0.0f);  // convert_to(CV_8UC1, 255)
+            om |= (uint32_t)fminf(fmaxf(u, 0.f), 255.f) << (8 * j);
+            const float l = spec_log(m3);
+            const float v = rintf(((l * 1.0f + beta2) * alpha2 + 0.0f) * 255.0f + 0.0f);
+            ol |= (uint32_t)fminf(fmaxf(v, 0.f), 255.f) << (8 * j);
+        }
+    }
+    const int64_t o = (int64_t)r * cols + c0;
+    if (c0 + 4 <= cols && (o & 3) == 0) {
+        if (mag_u8) *(uint32_t *)(mag_u8 + o) = om;
+        if (log_u8) *(uint32_t *)(log_u8 + o) = ol;
+    } else {
+        for (int j = 0; j < 4 && c0 + j < cols; j++) {
+            if (mag_u8) mag_u8[o + j] = (uint8_t)(om >> (8 * j));
+            if (log_u8) log_u8[o + j] = (uint8_t)(ol >> (8 * j));
+        }
     }
 }
 
-hipError_t launch_spec_log_u8(const float *d_log, int rows, int cols, const uint32_t *d_minmax, uint8_t *d_log_u8,
-                              hipStream_t s)
+hipError_t launch_spec_pictures(const float *d_mag, int rows, int cols, int mag_pitch, const uint32_t *d_minmax,
+                                uint8_t *d_mag_u8, uint8_t *d_log_u8, hipStream_t s)
 {
-    const int64_t total = (int64_t)rows * cols;
-    const int blocks = (int)((total + 1023) / 1024 < 8192 ? (total + 1023) / 1024 : 8192);
-    hipLaunchKernelGGL(spec_log_u8_kernel, dim3(blocks > 0 ? blocks : 1), dim3(256), 0, s, d_log, total, d_minmax, d_log_u8);
+    hipLaunchKernelGGL(spec_pictures_kernel, dim3((cols + 1023) / 1024, rows), dim3(256), 0, s, d_mag, rows, cols,
+                       mag_pitch, d_minmax, d_mag_u8, d_log_u8);
     return hipGetLastError();
 }
 

@@ -27,6 +27,12 @@ struct FftPass {
     const cfloat *chirp;    // n: exp(-i pi k^2 / n); NULL for the direct transform
     const cfloat *Bf;       // m: FFT_m of the padded conjugate chirp (Bluestein)
     float out_scale;
+    // Column pass of the spectrum pictures: when mag_dst is set the pass writes |F| (float) instead of F,
+    // already quadrant-swapped (fft_shift, fft.rs:67-86: an odd last row / column stays put), and the
+    // per-workgroup extrema of |F| to part[2 * line .. + 1] -- no complex spectrum is ever written.
+    float *mag_dst;         // img_rows x mag_pitch floats, or NULL
+    int32_t mag_pitch, img_rows, img_cols;
+    float *part;
 };
 #define OMR_FFT_MAX_M 8192
 hipError_t launch_fft_pass(const FftPass &p, hipStream_t s);
@@ -38,15 +44,13 @@ inline size_t spec_part_floats(int rows, int cols)
     const size_t a = (size_t)((cols + 1023) / 1024) * (size_t)rows, b = 8192;
     return 2 * (a > b ? a : b);
 }
-// |F| of the quadrant-swapped spectrum (fft.rs:68-88, :108-110) and its min / max
-hipError_t launch_spec_magnitude(const cfloat *d_F, int rows, int cols, int pitch, float *d_mag, float *d_part, uint32_t *d_minmax,
-                                 hipStream_t s);
-// correction(|F|) * 255 -> 8-bit "magnitude_image" (x 255 again, fft.rs:134) and log(. + 1/255) with its
-// min / max (fft.rs:113-119)
-hipError_t launch_spec_normalise(const float *d_mag, int rows, int cols, const uint32_t *d_minmax_in,
-                                 uint8_t *d_mag_u8, float *d_log, float *d_part, uint32_t *d_minmax_out, hipStream_t s);
-// correction(log) -> 8-bit "magnitude_log_image" (fft.rs:136-138)
-hipError_t launch_spec_log_u8(const float *d_log, int rows, int cols, const uint32_t *d_minmax, uint8_t *d_log_u8,
-                              hipStream_t s);
+// fold n per-workgroup (min, max) pairs into d_minmax[0..1] (ordered-uint keys)
+hipError_t launch_minmax_final(const float *d_part, int n, uint32_t *d_minmax, hipStream_t s);
+// Both 8-bit pictures from |F| (pitched) in one pass: correction(|F|) * 255 -> "magnitude_image" (x 255 again,
+// fft.rs:134) and log(. + 1/255) -> correction -> "magnitude_log_image" (fft.rs:113-119, :136-138).  The
+// extrema of the log picture are the images of the extrema of |F| under the same float expressions (every
+// step is monotone), so no second reduction pass and no float log array are needed.
+hipError_t launch_spec_pictures(const float *d_mag, int rows, int cols, int mag_pitch, const uint32_t *d_minmax,
+                                uint8_t *d_mag_u8, uint8_t *d_log_u8, hipStream_t s);
 
 }  // namespace omr

@@ -109,7 +109,8 @@ struct FftWork {
     int rows = 0, cols = 0, pitch = 0;  // pitch: elements per row of the complex arrays (cols + 8: a column's
                                         // points then spread over the memory channels instead of aliasing)
     AxisTables ax_cols, ax_rows;  // transforms along a row (length cols) / along a column (length rows)
-    DevBuf c0, c1, mag, lg, mm, part;
+    int mag_pitch = 0;  // floats per row of |F| (cols + 16: same reason, 4-byte elements)
+    DevBuf c0, mag, mm, part;
     int create(int r, int c, hipStream_t s)
     {
         rows = r;
@@ -118,13 +119,11 @@ struct FftWork {
         if ((rc = ax_cols.build(c, s))) return rc;
         if ((rc = ax_rows.build(r, s))) return rc;
         pitch = c + 8;  // measured at 4096^2: +8 2184 scans/s, +32 (a 256-byte multiple) 1754, unpadded 1780
-        const size_t px = (size_t)r * c;
+        mag_pitch = c + 16;
         OMR_HIP(c0.alloc(sizeof(cfloat) * (size_t)r * pitch));
-        OMR_HIP(c1.alloc(sizeof(cfloat) * (size_t)r * pitch));
-        OMR_HIP(mag.alloc(sizeof(float) * px));
-        OMR_HIP(lg.alloc(sizeof(float) * px));
+        OMR_HIP(mag.alloc(sizeof(float) * (size_t)r * mag_pitch));
         OMR_HIP(mm.alloc(sizeof(uint32_t) * 4));
-        OMR_HIP(part.alloc(sizeof(float) * spec_part_floats(r, c)));
+        OMR_HIP(part.alloc(sizeof(float) * 2 * (size_t)c));
         return OMR_OK;
     }
     // fft.rs:124-141 for one device-resident 8-bit scan -> the two 8-bit pictures (device, packed)
@@ -150,7 +149,12 @@ struct FftWork {
         // along columns, in place in the row-major array (strided lines, see fft_pass_kernel), with DFT_SCALE
         FftPass q{};
         q.src_c = c0.as<cfloat>();
-        q.dst = c1.as<cfloat>();
+        q.dst = nullptr;  // spectrum-picture mode: |F|, quadrant-swapped, straight from the column pass
+        q.mag_dst = mag.as<float>();
+        q.mag_pitch = mag_pitch;
+        q.img_rows = rows;
+        q.img_cols = cols;
+        q.part = part.as<float>();
         q.line_stride = 1;
         q.elem_stride = pitch;
         q.n = rows;
@@ -162,11 +166,8 @@ struct FftWork {
         q.Bf = ax_rows.blue ? ax_rows.Bf.as<cfloat>() : nullptr;
         q.out_scale = (float)(1.0 / ((double)rows * (double)cols));
         OMR_HIP(launch_fft_pass(q, s));
-        OMR_HIP(launch_spec_magnitude(c1.as<cfloat>(), rows, cols, pitch, mag.as<float>(), part.as<float>(), mm.as<uint32_t>(),
-                                      s));
-        OMR_HIP(launch_spec_normalise(mag.as<float>(), rows, cols, mm.as<uint32_t>(), d_mag_u8, lg.as<float>(),
-                                      part.as<float>(), mm.as<uint32_t>() + 2, s));
-        OMR_HIP(launch_spec_log_u8(lg.as<float>(), rows, cols, mm.as<uint32_t>() + 2, d_log_u8, s));
+        OMR_HIP(launch_minmax_final(part.as<float>(), cols, mm.as<uint32_t>(), s));
+        OMR_HIP(launch_spec_pictures(mag.as<float>(), rows, cols, mag_pitch, mm.as<uint32_t>(), d_mag_u8, d_log_u8, s));
         return OMR_OK;
     }
 };
