@@ -120,11 +120,18 @@ __global__ __launch_bounds__(FFT_THREADS) void fft_pass_kernel(const FftPass p)
         if ((int)blockIdx.x < body) line = (int64_t)(blockIdx.x % 8) * per + blockIdx.x / 8;
     }
     const bool blue = p.chirp != nullptr;
+    const bool pairs = p.real_pairs != 0;
+    const bool second = pairs && 2 * line + 1 < p.src_rows;
+    if (pairs) line *= 2;
     for (int k = tid; k < m; k += FFT_THREADS) {
         cfloat v{0.f, 0.f};
         if (k < n) {
-            if (p.src_u8) v.x = (float)p.src_u8[line * p.src_step + k] * p.in_scale + 0.0f;
-            else v = p.src_c[line * p.line_stride + (int64_t)k * p.elem_stride];
+            if (p.src_u8) {
+                v.x = (float)p.src_u8[line * p.src_step + k] * p.in_scale + 0.0f;
+                if (second) v.y = (float)p.src_u8[(line + 1) * p.src_step + k] * p.in_scale + 0.0f;
+            } else {
+                v = p.src_c[line * p.line_stride + (int64_t)k * p.elem_stride];
+            }
             if (blue) v = cmul(v, p.chirp[k]);
         }
         A[k] = v;
@@ -149,6 +156,16 @@ __global__ __launch_bounds__(FFT_THREADS) void fft_pass_kernel(const FftPass p)
         const int orow = inq ? (k < cyh ? k + cyh : k - cyh) : k, oc = inq ? sc_sw : sc;
         const float mg = sqrtf(v.x * v.x + v.y * v.y);
         p.mag_dst[(int64_t)orow * p.mag_pitch + oc] = mg;
+        if (p.half_mirror) {  // the conjugate-symmetric point of a real image's spectrum
+            const int mc = sc == 0 ? 0 : p.img_cols - sc;
+            if (mc != sc) {
+                const int mk = k == 0 ? 0 : p.img_rows - k;
+                const bool minq = mc < 2 * cxh && mk < 2 * cyh;
+                const int mrow = minq ? (mk < cyh ? mk + cyh : mk - cyh) : mk;
+                const int mcol = minq ? (mc < cxh ? mc + cxh : mc - cxh) : mc;
+                p.mag_dst[(int64_t)mrow * p.mag_pitch + mcol] = mg;
+            }
+        }
         lo = fminf(lo, mg);
         hi = fmaxf(hi, mg);
     };
@@ -174,7 +191,20 @@ __global__ __launch_bounds__(FFT_THREADS) void fft_pass_kernel(const FftPass p)
             p.part[2 * blockIdx.x + 1] = hi;
         }
     };
+    // two real rows per workgroup: split Z = FFT(a + i b) into FFT(a) and FFT(b), columns 0 .. n / 2
+    auto emit_pair = [&](const cfloat *Z) {
+        cfloat *d0 = p.dst + line * p.line_stride, *d1 = d0 + p.line_stride;
+        for (int k = tid; k <= n / 2; k += FFT_THREADS) {
+            const cfloat zk = Z[k], zn = Z[k == 0 ? 0 : n - k];
+            d0[k] = cfloat{(0.5f * (zk.x + zn.x)) * p.out_scale, (0.5f * (zk.y - zn.y)) * p.out_scale};
+            if (second) d1[k] = cfloat{(0.5f * (zk.y + zn.y)) * p.out_scale, (-0.5f * (zk.x - zn.x)) * p.out_scale};
+        }
+    };
     if (!blue) {
+        if (pairs) {
+            emit_pair(P);
+            return;
+        }
         for (int k = tid; k < n; k += FFT_THREADS) emit(k, cfloat{P[k].x * p.out_scale, P[k].y * p.out_scale});
         finish();
         return;
@@ -186,6 +216,13 @@ __global__ __launch_bounds__(FFT_THREADS) void fft_pass_kernel(const FftPass p)
     }
     cfloat *R = fft_forward_lds(P, Q, m, p.log2m, p.W, tid);
     const float inv_m = 1.0f / (float)m;
+    if (pairs) {  // the line's spectrum must be complete in LDS before the two rows can be separated
+        cfloat *Z = R == A ? B : A;
+        for (int k = tid; k < n; k += FFT_THREADS) Z[k] = cmul(cfloat{R[k].x * inv_m, -R[k].y * inv_m}, p.chirp[k]);
+        __syncthreads();
+        emit_pair(Z);
+        return;
+    }
     for (int k = tid; k < n; k += FFT_THREADS) {
         const cfloat c = cmul(cfloat{R[k].x * inv_m, -R[k].y * inv_m}, p.chirp[k]);
         emit(k, cfloat{c.x * p.out_scale, c.y * p.out_scale});
@@ -200,7 +237,7 @@ hipError_t launch_fft_pass(const FftPass &p, hipStream_t s)
     const size_t lds = 2 * sizeof(cfloat) * (size_t)p.m;
     hipError_t e = hipFuncSetAttribute((const void *)fft_pass_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(fft_pass_kernel, dim3(p.lines), dim3(FFT_THREADS), lds, s, p);
+    hipLaunchKernelGGL(fft_pass_kernel, dim3(p.real_pairs ? (p.lines + 1) / 2 : p.lines), dim3(FFT_THREADS), lds, s, p);
     return hipGetLastError();
 }
 

@@ -33,6 +33,14 @@ struct FftPass {
     float *mag_dst;         // img_rows x mag_pitch floats, or NULL
     int32_t mag_pitch, img_rows, img_cols;
     float *part;
+    // The input is REAL (an 8-bit scan), which halves both passes:
+    // real_pairs (row pass, src_u8): a workgroup transforms rows 2b and 2b + 1 together as the real and the
+    //   imaginary part of one complex line and separates the two spectra by Hermitian symmetry,
+    //   A[k] = (Z[k] + conj Z[n-k]) / 2, B[k] = (Z[k] - conj Z[n-k]) / 2i; only columns 0 .. n/2 are written
+    //   (the rest is their mirror image).  src_rows = number of rows (an odd last row goes alone).
+    // half_mirror (column pass in picture mode): lines = img_cols / 2 + 1; |F(k, c)| is also stored at the
+    //   mirrored point ((R - k) % R, (C - c) % C), F(-k, -c) = conj F(k, c), unless the column is its own mirror.
+    int32_t real_pairs, src_rows, half_mirror;
 };
 #define OMR_FFT_MAX_M 8192
 hipError_t launch_fft_pass(const FftPass &p, hipStream_t s);

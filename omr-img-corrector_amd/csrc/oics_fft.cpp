@@ -145,6 +145,8 @@ struct FftWork {
         p.out_scale = 1.0f;
         p.line_stride = pitch;
         p.elem_stride = 1;
+        p.real_pairs = 1;  // two real rows per workgroup, columns 0 .. cols / 2 written
+        p.src_rows = rows;
         OMR_HIP(launch_fft_pass(p, s));
         // along columns, in place in the row-major array (strided lines, see fft_pass_kernel), with DFT_SCALE
         FftPass q{};
@@ -160,13 +162,14 @@ struct FftWork {
         q.n = rows;
         q.m = ax_rows.m;
         q.log2m = ax_rows.log2m;
-        q.lines = cols;
+        q.lines = cols / 2 + 1;  // the other columns are mirror images (real input)
+        q.half_mirror = 1;
         q.W = ax_rows.W.as<cfloat>();
         q.chirp = ax_rows.blue ? ax_rows.chirp.as<cfloat>() : nullptr;
         q.Bf = ax_rows.blue ? ax_rows.Bf.as<cfloat>() : nullptr;
         q.out_scale = (float)(1.0 / ((double)rows * (double)cols));
         OMR_HIP(launch_fft_pass(q, s));
-        OMR_HIP(launch_minmax_final(part.as<float>(), cols, mm.as<uint32_t>(), s));
+        OMR_HIP(launch_minmax_final(part.as<float>(), cols / 2 + 1, mm.as<uint32_t>(), s));
         OMR_HIP(launch_spec_pictures(mag.as<float>(), rows, cols, mag_pitch, mm.as<uint32_t>(), d_mag_u8, d_log_u8, s));
         return OMR_OK;
     }
