@@ -106,9 +106,17 @@ __device__ cfloat *fft_forward_lds(cfloat *in, cfloat *out, const int m, const i
     return in;
 }
 
-__global__ __launch_bounds__(FFT_THREADS) void fft_pass_kernel(const FftPass p)
+__global__ __launch_bounds__(FFT_THREADS) void fft_pass_kernel(FftPass p)
 {
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
+    {  // scan of the launch
+        const int64_t z = blockIdx.y;
+        if (p.src_u8) p.src_u8 += z * p.src_u8_scan_stride;
+        if (p.src_c) p.src_c += z * p.c_scan_stride;
+        if (p.dst) p.dst += z * p.c_scan_stride;
+        if (p.mag_dst) p.mag_dst += z * p.mag_scan_stride;
+        if (p.part) p.part += z * p.part_scan_stride;
+    }
     cfloat *A = (cfloat *)lds_raw, *B = A + p.m;
     const int tid = threadIdx.x, n = p.n, m = p.m;
     // Column passes (elem_stride > 1) touch 8 bytes per 64-byte sector: the eight columns that share a
@@ -237,7 +245,8 @@ hipError_t launch_fft_pass(const FftPass &p, hipStream_t s)
     const size_t lds = 2 * sizeof(cfloat) * (size_t)p.m;
     hipError_t e = hipFuncSetAttribute((const void *)fft_pass_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(fft_pass_kernel, dim3(p.real_pairs ? (p.lines + 1) / 2 : p.lines), dim3(FFT_THREADS), lds, s, p);
+    hipLaunchKernelGGL(fft_pass_kernel, dim3(p.real_pairs ? (p.lines + 1) / 2 : p.lines, p.scans > 0 ? p.scans : 1),
+                       dim3(FFT_THREADS), lds, s, p);
     return hipGetLastError();
 }
 
@@ -277,8 +286,11 @@ __device__ __forceinline__ void block_minmax(float lo, float hi, float *part, in
     }
 }
 
-__global__ __launch_bounds__(1024) void minmax_final_kernel(const float *__restrict__ part, int n, uint32_t *mm)
+__global__ __launch_bounds__(1024) void minmax_final_kernel(const float *__restrict__ part, int n, uint32_t *mm,
+                                                            int64_t part_scan_stride)
 {
+    part += (int64_t)blockIdx.x * part_scan_stride;
+    mm += 4 * blockIdx.x;
     __shared__ float s_lo[16], s_hi[16];
     float lo = __builtin_inff(), hi = -__builtin_inff();
     for (int i = threadIdx.x; i < n; i += 1024) {
@@ -304,9 +316,10 @@ __global__ __launch_bounds__(1024) void minmax_final_kernel(const float *__restr
     }
 }
 
-hipError_t launch_minmax_final(const float *d_part, int n, uint32_t *d_minmax, hipStream_t s)
+hipError_t launch_minmax_final(const float *d_part, int n, uint32_t *d_minmax, hipStream_t s, int scans,
+                               int64_t part_scan_stride)
 {
-    hipLaunchKernelGGL(minmax_final_kernel, dim3(1), dim3(1024), 0, s, d_part, n, d_minmax);
+    hipLaunchKernelGGL(minmax_final_kernel, dim3(scans), dim3(1024), 0, s, d_part, n, d_minmax, part_scan_stride);
     return hipGetLastError();
 }
 
@@ -322,8 +335,12 @@ __device__ __forceinline__ float spec_log(float m3) { return logf(m3 * 1.0f + (f
 
 __global__ __launch_bounds__(256) void spec_pictures_kernel(const float *__restrict__ mag, int rows, int cols, int mag_pitch,
                                                             const uint32_t *__restrict__ mm, uint8_t *__restrict__ mag_u8,
-                                                            uint8_t *__restrict__ log_u8)
+                                                            uint8_t *__restrict__ log_u8, int64_t mag_scan_stride)
 {
+    mag += (int64_t)blockIdx.z * mag_scan_stride;
+    mm += 4 * blockIdx.z;
+    if (mag_u8) mag_u8 += (int64_t)blockIdx.z * rows * cols;
+    if (log_u8) log_u8 += (int64_t)blockIdx.z * rows * cols;
     const double mn = (double)key2f(mm[0]), mx = (double)key2f(mm[1]);
     const float beta = (float)(-mn), alpha = (float)(1.0 / (mx - mn));
     // extrema of the log picture = the log picture of the extrema (monotone float steps)
@@ -358,10 +375,10 @@ __global__ __launch_bounds__(256) void spec_pictures_kernel(const float *__restr
 }
 
 hipError_t launch_spec_pictures(const float *d_mag, int rows, int cols, int mag_pitch, const uint32_t *d_minmax,
-                                uint8_t *d_mag_u8, uint8_t *d_log_u8, hipStream_t s)
+                                uint8_t *d_mag_u8, uint8_t *d_log_u8, hipStream_t s, int scans, int64_t mag_scan_stride)
 {
-    hipLaunchKernelGGL(spec_pictures_kernel, dim3((cols + 1023) / 1024, rows), dim3(256), 0, s, d_mag, rows, cols,
-                       mag_pitch, d_minmax, d_mag_u8, d_log_u8);
+    hipLaunchKernelGGL(spec_pictures_kernel, dim3((cols + 1023) / 1024, rows, scans), dim3(256), 0, s, d_mag, rows, cols,
+                       mag_pitch, d_minmax, d_mag_u8, d_log_u8, mag_scan_stride);
     return hipGetLastError();
 }
 

@@ -41,6 +41,11 @@ struct FftPass {
     // half_mirror (column pass in picture mode): lines = img_cols / 2 + 1; |F(k, c)| is also stored at the
     //   mirrored point ((R - k) % R, (C - c) % C), F(-k, -c) = conj F(k, c), unless the column is its own mirror.
     int32_t real_pairs, src_rows, half_mirror;
+    // several scans per launch (blockIdx.y = scan): strides of the per-scan arrays; 0 / 1 scan by default
+    int32_t scans;
+    int64_t src_u8_scan_stride;                  // bytes
+    int64_t c_scan_stride;                       // elements of src_c / dst
+    int64_t mag_scan_stride, part_scan_stride;   // floats
 };
 #define OMR_FFT_MAX_M 8192
 hipError_t launch_fft_pass(const FftPass &p, hipStream_t s);
@@ -53,12 +58,14 @@ inline size_t spec_part_floats(int rows, int cols)
     return 2 * (a > b ? a : b);
 }
 // fold n per-workgroup (min, max) pairs into d_minmax[0..1] (ordered-uint keys)
-hipError_t launch_minmax_final(const float *d_part, int n, uint32_t *d_minmax, hipStream_t s);
+hipError_t launch_minmax_final(const float *d_part, int n, uint32_t *d_minmax, hipStream_t s, int scans = 1,
+                               int64_t part_scan_stride = 0);  // scan z: d_part + z * stride -> d_minmax + 4 z
 // Both 8-bit pictures from |F| (pitched) in one pass: correction(|F|) * 255 -> "magnitude_image" (x 255 again,
 // fft.rs:134) and log(. + 1/255) -> correction -> "magnitude_log_image" (fft.rs:113-119, :136-138).  The
 // extrema of the log picture are the images of the extrema of |F| under the same float expressions (every
 // step is monotone), so no second reduction pass and no float log array are needed.
 hipError_t launch_spec_pictures(const float *d_mag, int rows, int cols, int mag_pitch, const uint32_t *d_minmax,
-                                uint8_t *d_mag_u8, uint8_t *d_log_u8, hipStream_t s);
+                                uint8_t *d_mag_u8, uint8_t *d_log_u8, hipStream_t s, int scans = 1,
+                                int64_t mag_scan_stride = 0);  // pictures of scan z: + z * rows * cols; minmax + 4 z
 
 }  // namespace omr

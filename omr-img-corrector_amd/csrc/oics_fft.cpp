@@ -13,6 +13,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <complex>
 #include <vector>
 
@@ -111,25 +112,33 @@ struct FftWork {
     AxisTables ax_cols, ax_rows;  // transforms along a row (length cols) / along a column (length rows)
     int mag_pitch = 0;  // floats per row of |F| (cols + 16: same reason, 4-byte elements)
     DevBuf c0, mag, mm, part;
-    int create(int r, int c, hipStream_t s)
+    int group = 1;  // scans carried by one launch of each kernel (every per-scan array holds that many)
+    int create(int r, int c, hipStream_t s, int scans_per_launch = 1)
     {
         rows = r;
         cols = c;
+        group = scans_per_launch < 1 ? 1 : scans_per_launch;
         int rc;
         if ((rc = ax_cols.build(c, s))) return rc;
         if ((rc = ax_rows.build(r, s))) return rc;
         pitch = c + 8;  // measured at 4096^2: +8 2184 scans/s, +32 (a 256-byte multiple) 1754, unpadded 1780
         mag_pitch = c + 16;
-        OMR_HIP(c0.alloc(sizeof(cfloat) * (size_t)r * pitch));
-        OMR_HIP(mag.alloc(sizeof(float) * (size_t)r * mag_pitch));
-        OMR_HIP(mm.alloc(sizeof(uint32_t) * 4));
-        OMR_HIP(part.alloc(sizeof(float) * 2 * (size_t)c));
+        OMR_HIP(c0.alloc(sizeof(cfloat) * (size_t)r * pitch * group));
+        OMR_HIP(mag.alloc(sizeof(float) * (size_t)r * mag_pitch * group));
+        OMR_HIP(mm.alloc(sizeof(uint32_t) * 4 * group));
+        OMR_HIP(part.alloc(sizeof(float) * 2 * (size_t)c * group));
         return OMR_OK;
     }
     // fft.rs:124-141 for one device-resident 8-bit scan -> the two 8-bit pictures (device, packed)
-    int run(const uint8_t *d_gray, int64_t step, uint8_t *d_mag_u8, uint8_t *d_log_u8, hipStream_t s)
+    // `scans` (<= group) scans, scan_stride bytes apart; pictures packed one after the other
+    int run(const uint8_t *d_gray, int64_t step, uint8_t *d_mag_u8, uint8_t *d_log_u8, hipStream_t s, int scans = 1,
+            int64_t scan_stride = 0)
     {
+        if (scans < 1 || scans > group) return fail(OMR_ERR_BADARG, "FFT launch group of %d scans, workspace holds %d", scans, group);
         FftPass p{};
+        p.scans = scans;
+        p.src_u8_scan_stride = scan_stride;
+        p.c_scan_stride = (int64_t)rows * pitch;
         // along rows: u8 * (1 / 255) -> complex spectrum lines
         p.src_u8 = d_gray;
         p.src_step = step;
@@ -150,6 +159,10 @@ struct FftWork {
         OMR_HIP(launch_fft_pass(p, s));
         // along columns, in place in the row-major array (strided lines, see fft_pass_kernel), with DFT_SCALE
         FftPass q{};
+        q.scans = scans;
+        q.c_scan_stride = (int64_t)rows * pitch;
+        q.mag_scan_stride = (int64_t)rows * mag_pitch;
+        q.part_scan_stride = 2 * (int64_t)cols;
         q.src_c = c0.as<cfloat>();
         q.dst = nullptr;  // spectrum-picture mode: |F|, quadrant-swapped, straight from the column pass
         q.mag_dst = mag.as<float>();
@@ -169,8 +182,9 @@ struct FftWork {
         q.Bf = ax_rows.blue ? ax_rows.Bf.as<cfloat>() : nullptr;
         q.out_scale = (float)(1.0 / ((double)rows * (double)cols));
         OMR_HIP(launch_fft_pass(q, s));
-        OMR_HIP(launch_minmax_final(part.as<float>(), cols / 2 + 1, mm.as<uint32_t>(), s));
-        OMR_HIP(launch_spec_pictures(mag.as<float>(), rows, cols, mag_pitch, mm.as<uint32_t>(), d_mag_u8, d_log_u8, s));
+        OMR_HIP(launch_minmax_final(part.as<float>(), cols / 2 + 1, mm.as<uint32_t>(), s, scans, 2 * (int64_t)cols));
+        OMR_HIP(launch_spec_pictures(mag.as<float>(), rows, cols, mag_pitch, mm.as<uint32_t>(), d_mag_u8, d_log_u8, s, scans,
+                                     (int64_t)rows * mag_pitch));
         return OMR_OK;
     }
 };
@@ -241,15 +255,19 @@ int omr_fft_image_batch_device(const uint8_t *d_scans, int32_t n, int64_t scan_s
     int rc = have_device();
     if (rc) return rc;
     hipStream_t s = (hipStream_t)stream;
-    FftWork w;
-    if ((rc = w.create(rows, cols, s))) return rc;
-    DevBuf m8;
+    // several scans per launch of each kernel: the fixed cost between dependent launches (tens of microseconds, as
+    // for the sweep) is paid once per group; the workspace holds <= 1 GiB of spectra
     const size_t px = (size_t)rows * cols;
-    OMR_HIP(m8.alloc(px));
-    for (int i = 0; i < n; i++)
-        if ((rc = w.run(d_scans + (int64_t)i * scan_stride_bytes, step_bytes, m8.as<uint8_t>(), d_magnitude_log + (size_t)i * px,
-                        s)))
+    int G = (int)std::min<size_t>((size_t)n, std::max<size_t>(1, ((size_t)1 << 30) / (sizeof(cfloat) * (size_t)rows * (cols + 8))));
+    G = std::min(G, 8);
+    FftWork w;
+    if ((rc = w.create(rows, cols, s, G))) return rc;
+    for (int i = 0; i < n; i += G) {
+        const int g = std::min(G, n - i);
+        if ((rc = w.run(d_scans + (int64_t)i * scan_stride_bytes, step_bytes, nullptr, d_magnitude_log + (size_t)i * px, s, g,
+                        scan_stride_bytes)))
             return rc;
+    }
     OMR_HIP(hipStreamSynchronize(s));  // the workspace is released on return
     return OMR_OK;
 }
