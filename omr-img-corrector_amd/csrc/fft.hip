@@ -23,6 +23,10 @@ __device__ __forceinline__ cfloat cmul(const cfloat a, const cfloat b)
 }
 
 #define FFT_THREADS 512
+// LDS lines are skewed by one element every 32: the Stockham stores of the first stages go to addresses
+// 8 j + q (stride 64 bytes between lanes: a 16-way bank conflict on ds_write_b64 without the skew).
+#define FPAD(i) ((i) + ((i) >> 5))
+#define FFT_LDS_ELEMS(m) ((m) + ((m) >> 5))
 
 // forward FFT of length m = 2^log2m, Stockham autosort.  Stages are radix 8 (three radix-2 levels in
 // registers per LDS round trip) with one leading radix-2 or radix-4 stage when log2m is not a multiple of
@@ -33,17 +37,18 @@ __device__ __forceinline__ cfloat csub(const cfloat a, const cfloat b) { return 
 __device__ __forceinline__ cfloat cmul_mi(const cfloat a) { return cfloat{a.y, -a.x}; }  // a * (-i)
 
 __device__ cfloat *fft_forward_lds(cfloat *in, cfloat *out, const int m, const int log2m,
-                                   const cfloat *__restrict__ W, const int tid)
+                                   const cfloat *__restrict__ Wst, const int tid)
 {
     int s = 0;
     const int lead = log2m % 3;
+    const int Ns0 = 1 << lead;  // Ns of the first radix-8 stage
     if (lead == 1) {  // radix 2, Ns = 1: no twiddles
         const int half = m >> 1;
         __syncthreads();
         for (int j = tid; j < half; j += FFT_THREADS) {
-            const cfloat u0 = in[j], u1 = in[j + half];
-            out[2 * j] = cadd(u0, u1);
-            out[2 * j + 1] = csub(u0, u1);
+            const cfloat u0 = in[FPAD(j)], u1 = in[FPAD(j + half)];
+            out[FPAD(2 * j)] = cadd(u0, u1);
+            out[FPAD(2 * j + 1)] = csub(u0, u1);
         }
         cfloat *t = in;
         in = out;
@@ -53,12 +58,12 @@ __device__ cfloat *fft_forward_lds(cfloat *in, cfloat *out, const int m, const i
         const int quarter = m >> 2;
         __syncthreads();
         for (int j = tid; j < quarter; j += FFT_THREADS) {
-            const cfloat u0 = in[j], u1 = in[j + quarter], u2 = in[j + 2 * quarter], u3 = in[j + 3 * quarter];
+            const cfloat u0 = in[FPAD(j)], u1 = in[FPAD(j + quarter)], u2 = in[FPAD(j + 2 * quarter)], u3 = in[FPAD(j + 3 * quarter)];
             const cfloat a = cadd(u0, u2), b = csub(u0, u2), c = cadd(u1, u3), d = cmul_mi(csub(u1, u3));
-            out[4 * j] = cadd(a, c);
-            out[4 * j + 1] = cadd(b, d);
-            out[4 * j + 2] = csub(a, c);
-            out[4 * j + 3] = csub(b, d);
+            out[FPAD(4 * j)] = cadd(a, c);
+            out[FPAD(4 * j + 1)] = cadd(b, d);
+            out[FPAD(4 * j + 2)] = csub(a, c);
+            out[FPAD(4 * j + 3)] = csub(b, d);
         }
         cfloat *t = in;
         in = out;
@@ -72,11 +77,21 @@ __device__ cfloat *fft_forward_lds(cfloat *in, cfloat *out, const int m, const i
         __syncthreads();
         for (int j = tid; j < eighth; j += FFT_THREADS) {
             const int k = j & (Ns - 1);
-            const int tw = k << (log2m - 3 - s);  // exp(-2 pi i k / (8 Ns)) = W[tw]
+            // one twiddle load per butterfly, from the stage's own contiguous table (lanes read neighbouring
+            // entries), its powers by complex multiplication: the seven scattered loads W[q * tw] of the plain
+            // form touched up to 64 cache lines per wave-instruction
+            const cfloat w1 = Wst[(Ns - Ns0) / 7 + k];  // exp(-2 pi i k / (8 Ns))
+            const cfloat w2 = cmul(w1, w1), w3 = cmul(w2, w1), w4 = cmul(w2, w2);
+            const cfloat w5 = cmul(w4, w1), w6 = cmul(w3, w3), w7 = cmul(w4, w3);
             cfloat u[8];
-            u[0] = in[j];
-#pragma unroll
-            for (int q = 1; q < 8; q++) u[q] = cmul(in[j + q * eighth], W[q * tw]);
+            u[0] = in[FPAD(j)];
+            u[1] = cmul(in[FPAD(j + eighth)], w1);
+            u[2] = cmul(in[FPAD(j + 2 * eighth)], w2);
+            u[3] = cmul(in[FPAD(j + 3 * eighth)], w3);
+            u[4] = cmul(in[FPAD(j + 4 * eighth)], w4);
+            u[5] = cmul(in[FPAD(j + 5 * eighth)], w5);
+            u[6] = cmul(in[FPAD(j + 6 * eighth)], w6);
+            u[7] = cmul(in[FPAD(j + 7 * eighth)], w7);
             // radix-8 butterfly: y[q] = sum_p u[p] exp(-2 pi i p q / 8)
             const cfloat a0 = cadd(u[0], u[4]), a1 = csub(u[0], u[4]);
             const cfloat a2 = cadd(u[2], u[6]), a3 = cmul_mi(csub(u[2], u[6]));
@@ -89,14 +104,14 @@ __device__ cfloat *fft_forward_lds(cfloat *in, cfloat *out, const int m, const i
             const cfloat b5 = cfloat{(t5.x + t5.y) * r2, (t5.y - t5.x) * r2};    // t5 * exp(-i pi / 4)
             const cfloat b7 = cfloat{(-t7.x + t7.y) * r2, (-t7.y - t7.x) * r2};  // t7 * exp(-3 i pi / 4)
             const int j0 = ((j - k) << 3) + k;
-            out[j0] = cadd(b0, b4);
-            out[j0 + Ns] = cadd(b1, b5);
-            out[j0 + 2 * Ns] = cadd(b2, b6);
-            out[j0 + 3 * Ns] = cadd(b3, b7);
-            out[j0 + 4 * Ns] = csub(b0, b4);
-            out[j0 + 5 * Ns] = csub(b1, b5);
-            out[j0 + 6 * Ns] = csub(b2, b6);
-            out[j0 + 7 * Ns] = csub(b3, b7);
+            out[FPAD(j0)] = cadd(b0, b4);
+            out[FPAD(j0 + Ns)] = cadd(b1, b5);
+            out[FPAD(j0 + 2 * Ns)] = cadd(b2, b6);
+            out[FPAD(j0 + 3 * Ns)] = cadd(b3, b7);
+            out[FPAD(j0 + 4 * Ns)] = csub(b0, b4);
+            out[FPAD(j0 + 5 * Ns)] = csub(b1, b5);
+            out[FPAD(j0 + 6 * Ns)] = csub(b2, b6);
+            out[FPAD(j0 + 7 * Ns)] = csub(b3, b7);
         }
         cfloat *t = in;
         in = out;
@@ -117,7 +132,7 @@ __global__ __launch_bounds__(FFT_THREADS) void fft_pass_kernel(FftPass p)
         if (p.mag_dst) p.mag_dst += z * p.mag_scan_stride;
         if (p.part) p.part += z * p.part_scan_stride;
     }
-    cfloat *A = (cfloat *)lds_raw, *B = A + p.m;
+    cfloat *A = (cfloat *)lds_raw, *B = A + FFT_LDS_ELEMS(p.m);
     const int tid = threadIdx.x, n = p.n, m = p.m;
     // Column passes (elem_stride > 1) touch 8 bytes per 64-byte sector: the eight columns that share a
     // sector must meet in one XCD's L2.  Workgroups go round-robin to the 8 XCDs, so XCD x takes the
@@ -142,7 +157,7 @@ __global__ __launch_bounds__(FFT_THREADS) void fft_pass_kernel(FftPass p)
             }
             if (blue) v = cmul(v, p.chirp[k]);
         }
-        A[k] = v;
+        A[FPAD(k)] = v;
     }
     cfloat *P = fft_forward_lds(A, B, m, p.log2m, p.W, tid);
     cfloat *Q = P == A ? B : A;
@@ -203,7 +218,7 @@ __global__ __launch_bounds__(FFT_THREADS) void fft_pass_kernel(FftPass p)
     auto emit_pair = [&](const cfloat *Z) {
         cfloat *d0 = p.dst + line * p.line_stride, *d1 = d0 + p.line_stride;
         for (int k = tid; k <= n / 2; k += FFT_THREADS) {
-            const cfloat zk = Z[k], zn = Z[k == 0 ? 0 : n - k];
+            const cfloat zk = Z[FPAD(k)], zn = Z[FPAD(k == 0 ? 0 : n - k)];
             d0[k] = cfloat{(0.5f * (zk.x + zn.x)) * p.out_scale, (0.5f * (zk.y - zn.y)) * p.out_scale};
             if (second) d1[k] = cfloat{(0.5f * (zk.y + zn.y)) * p.out_scale, (-0.5f * (zk.x - zn.x)) * p.out_scale};
         }
@@ -213,26 +228,26 @@ __global__ __launch_bounds__(FFT_THREADS) void fft_pass_kernel(FftPass p)
             emit_pair(P);
             return;
         }
-        for (int k = tid; k < n; k += FFT_THREADS) emit(k, cfloat{P[k].x * p.out_scale, P[k].y * p.out_scale});
+        for (int k = tid; k < n; k += FFT_THREADS) emit(k, cfloat{P[FPAD(k)].x * p.out_scale, P[FPAD(k)].y * p.out_scale});
         finish();
         return;
     }
     // convolution with the conjugate chirp: pointwise product, then an inverse FFT as conj(FFT(conj(.))) / m
     for (int k = tid; k < m; k += FFT_THREADS) {
-        const cfloat c = cmul(P[k], p.Bf[k]);
-        P[k] = cfloat{c.x, -c.y};
+        const cfloat c = cmul(P[FPAD(k)], p.Bf[k]);
+        P[FPAD(k)] = cfloat{c.x, -c.y};
     }
     cfloat *R = fft_forward_lds(P, Q, m, p.log2m, p.W, tid);
     const float inv_m = 1.0f / (float)m;
     if (pairs) {  // the line's spectrum must be complete in LDS before the two rows can be separated
         cfloat *Z = R == A ? B : A;
-        for (int k = tid; k < n; k += FFT_THREADS) Z[k] = cmul(cfloat{R[k].x * inv_m, -R[k].y * inv_m}, p.chirp[k]);
+        for (int k = tid; k < n; k += FFT_THREADS) Z[FPAD(k)] = cmul(cfloat{R[FPAD(k)].x * inv_m, -R[FPAD(k)].y * inv_m}, p.chirp[k]);
         __syncthreads();
         emit_pair(Z);
         return;
     }
     for (int k = tid; k < n; k += FFT_THREADS) {
-        const cfloat c = cmul(cfloat{R[k].x * inv_m, -R[k].y * inv_m}, p.chirp[k]);
+        const cfloat c = cmul(cfloat{R[FPAD(k)].x * inv_m, -R[FPAD(k)].y * inv_m}, p.chirp[k]);
         emit(k, cfloat{c.x * p.out_scale, c.y * p.out_scale});
     }
     finish();
@@ -242,7 +257,7 @@ hipError_t launch_fft_pass(const FftPass &p, hipStream_t s)
 {
     if (p.lines <= 0) return hipSuccess;
     if (p.m > OMR_FFT_MAX_M || (1 << p.log2m) != p.m) return hipErrorInvalidValue;
-    const size_t lds = 2 * sizeof(cfloat) * (size_t)p.m;
+    const size_t lds = 2 * sizeof(cfloat) * (size_t)FFT_LDS_ELEMS(p.m);
     hipError_t e = hipFuncSetAttribute((const void *)fft_pass_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(fft_pass_kernel, dim3(p.real_pairs ? (p.lines + 1) / 2 : p.lines, p.scans > 0 ? p.scans : 1),

@@ -23,7 +23,8 @@ struct FftPass {
     int64_t line_stride;    // elements between consecutive lines of src_c and dst (n for packed rows, 1 for columns)
     int64_t elem_stride;    // elements between consecutive points of a line (1 for rows, the row pitch for columns)
     int32_t n, m, log2m, lines;
-    const cfloat *W;        // m twiddles exp(-2 pi i t / m)
+    const cfloat *W;        // per-stage twiddle tables of the radix-8 stages, concatenated: stage Ns holds
+                            // exp(-2 pi i k / (8 Ns)), k < Ns, at offset (Ns - Ns0) / 7, Ns0 = 2^(log2m % 3)
     const cfloat *chirp;    // n: exp(-i pi k^2 / n); NULL for the direct transform
     const cfloat *Bf;       // m: FFT_m of the padded conjugate chirp (Bluestein)
     float out_scale;

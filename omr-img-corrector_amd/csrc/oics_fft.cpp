@@ -72,11 +72,14 @@ struct AxisTables {
         if (m > OMR_FFT_MAX_M)
             return fail(OMR_ERR_NOTIMPL, "DFT length %d needs a transform of %d points; the kernel holds at most %d in LDS", n,
                         m, OMR_FFT_MAX_M);
-        std::vector<cfloat> w((size_t)m);
-        for (int t = 0; t < m; t++) {
-            const double ang = -2.0 * kPi * (double)t / (double)m;
-            w[t] = cfloat{(float)cos(ang), (float)sin(ang)};
-        }
+        // twiddles of the radix-8 stages, one contiguous table per stage (Ns = Ns0, 8 Ns0, ... < m)
+        std::vector<cfloat> w;
+        for (int Ns = 1 << (log2m % 3); Ns < m; Ns *= 8)
+            for (int k = 0; k < Ns; k++) {
+                const double ang = -2.0 * kPi * (double)k / (8.0 * (double)Ns);
+                w.push_back(cfloat{(float)cos(ang), (float)sin(ang)});
+            }
+        if (w.empty()) w.push_back(cfloat{1.f, 0.f});
         OMR_HIP(W.alloc(sizeof(cfloat) * w.size()));
         OMR_HIP(hipMemcpyAsync(W.p, w.data(), sizeof(cfloat) * w.size(), hipMemcpyHostToDevice, s));
         if (blue) {
