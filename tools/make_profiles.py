@@ -1,6 +1,6 @@
-"""Turn gpurun_out/<tag>/ (written by tools/profile_round.sh) into the committed summaries under
-profiles/: <tag>_bench_line.json, <tag>_rocprofv3_kernel_stats_bench.{md,csv}, <tag>_pmc_sweep.md and
-hbm_traffic.json (read by bench.py for roofline.traffic).  Usage: python tools/make_profiles.py r01"""
+"""Turn gpurun_out/<tag>/ (written on the GPU box by tools/profile_round.sh) into the committed summaries under
+profiles/<tag>_*.  Every file names the commit it measured (gpurun_out/<tag>/COMMIT, written just before the
+gpurun call).  Usage: python tools/make_profiles.py r02"""
 import csv
 import glob
 import json
@@ -8,117 +8,163 @@ import os
 import shutil
 import statistics
 import sys
-from collections import defaultdict
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+sys.path.insert(0, os.path.join(ROOT, "omr-img-corrector_amd"))
+from oics import pmc  # noqa: E402
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 src = os.path.join(ROOT, "gpurun_out", tag)
 dst = os.path.join(ROOT, "profiles")
 os.makedirs(dst, exist_ok=True)
+commit = open(os.path.join(src, "COMMIT")).read().strip() if os.path.exists(os.path.join(src, "COMMIT")) else "unknown"
+STAMP = "Measured at commit `%s` on one MI355X (gpurun box), `bash tools/profile_round.sh %s`.\n\n" % (commit, tag)
 
 
-def short(name):
-    n = name.split("(")[0].strip()
-    if n.startswith("void "):
-        n = n[5:]
-    return n
+def read(name):
+    p = os.path.join(src, name)
+    return open(p).read() if os.path.exists(p) else ""
 
 
-def find(sub, pat):
-    r = glob.glob(os.path.join(src, sub, "**", pat), recursive=True)
-    return max(r, key=os.path.getmtime) if r else None  # gpurun merges runs: take the newest
+def last_json(text):
+    for ln in reversed(text.splitlines()):
+        if ln.startswith("{"):
+            try:
+                return json.loads(ln)
+            except Exception:  # noqa: BLE001
+                pass
+    return None
 
 
-def counters(sub):
-    f = find(sub, "*counter_collection.csv")
-    out = defaultdict(lambda: defaultdict(list))
-    if f:
-        for r in csv.DictReader(open(f)):
-            out[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
-    return out
-
-
-def durations(sub):
-    f = find(sub, "*kernel_trace.csv")
-    out = defaultdict(list)
-    if f:
-        for r in csv.DictReader(open(f)):
-            out[short(r["Kernel_Name"])].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
-    return out
-
-
-line = json.loads(open(os.path.join(src, "bench_line.json")).read().strip().splitlines()[-1])
-json.dump(line, open(os.path.join(dst, tag + "_bench_line.json"), "w"), indent=1)
-
-# ---- kernel stats
-ks = find("stats", "*kernel_stats.csv")
-rows = list(csv.DictReader(open(ks)))
-shutil.copy(ks, os.path.join(dst, tag + "_rocprofv3_kernel_stats_bench.csv"))
-with open(os.path.join(dst, tag + "_rocprofv3_kernel_stats_bench.md"), "w") as f:
-    f.write("# %s -- `rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu-baseline` (1x MI355X)\n\n" % tag)
-    f.write("Command (GPU box, from tools/profile_round.sh): `cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT && "
-            "rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/%s/stats -- python bench.py --no-cpu-baseline`\n" % tag)
-    f.write("(default bench: %d scans per step, 1 sweep stream + 1 post stream; `runtab_kernel` / `runblk_kernel` / `tables_kernel` "
-            "are plan creation, once; one extra `runs_kernel` launch is the plan's dry run).\n\n" % line["config"]["scans_per_gpu_per_step"])
+def stats_table(sub, f, top=12):
+    ks = glob.glob(os.path.join(src, sub, "**", "*kernel_stats.csv"), recursive=True)
+    if not ks:
+        f.write("(no kernel stats found)\n")
+        return []
+    rows = list(csv.DictReader(open(max(ks, key=os.path.getmtime))))
     f.write("| kernel | calls | total ms | avg us | min us | max us | % |\n|---|---|---|---|---|---|---|\n")
-    for r in rows:
+    for r in rows[:top]:
         f.write("| `%s` | %s | %.3f | %.1f | %.1f | %.1f | %s |\n" % (
-            short(r["Name"]), r["Calls"], float(r["TotalDurationNs"]) / 1e6, float(r["AverageNs"]) / 1e3,
+            pmc.short(r["Name"])[:90], r["Calls"], float(r["TotalDurationNs"]) / 1e6, float(r["AverageNs"]) / 1e3,
             float(r["MinNs"]) / 1e3, float(r["MaxNs"]) / 1e3, r["Percentage"]))
-    rl = line["roofline"]
-    f.write("\nUn-profiled bench line of the same build (`profiles/%s_bench_line.json`): **%.0f images/s**, "
-            "`roofline.kernel_ms` %.4f ms (HIP events on the launch stream, mean over %d launches), `roofline.frac` %.3f, "
-            "`cpu_baseline` %.2f images/s on %d cores (single thread %.3f), parity_vs_gpu %s.\n\n" % (
-                tag, line["value"], rl["kernel_ms"], rl["launch_groups_timed"], rl["frac"], line["cpu_baseline"]["value"],
-                line["cpu_baseline"]["cores"], line["cpu_baseline"]["single_thread_value"],
-                line["cpu_baseline"]["parity_vs_gpu"]))
-    f.write("`omr::runs_kernel` is launched once per scan; its rocprof average agrees with `roofline.kernel_ms` up to the "
-            "profiler's clock effect (MI355X_MICROARCH.md, DVFS item 2). `stddev_kernel`, `fold_parts_kernel` and "
-            "`argmax_path1_kernel` run on the post stream, overlapped with the next scan's sweep.\n")
+    return rows
 
-# ---- HBM traffic
-fe, wr = counters("pmc_fetch"), counters("pmc_write")
-sweep = [k for k in fe if "runs_kernel" in k]
+
+def counter_table(sub, needle, f):
+    c, d = pmc.read_counters(os.path.join(src, sub)), pmc.read_durations(os.path.join(src, sub))
+    out = {}
+    for k in sorted(c):
+        if needle not in k:
+            continue
+        vals = {n: pmc.mean(v[1:] if len(v) > 2 else v) for n, v in c[k].items()}
+        f.write("\n`%s` (%s; %d dispatches, mean duration %.1f us under the profiler)\n\n| counter | per launch |\n|---|---|\n" % (
+            k, sub, len(next(iter(c[k].values()))), pmc.mean(d.get(k, []))))
+        for n in sorted(vals):
+            f.write("| %s | %.4g |\n" % (n, vals[n]))
+        out[k] = (vals, pmc.mean(d.get(k, [])))
+    return out
+
+
+# ---- bench line + kernel stats
+line = last_json(read("bench_line.json"))
+json.dump(line, open(os.path.join(dst, tag + "_bench_line.json"), "w"), indent=1)
+with open(os.path.join(dst, tag + "_rocprofv3_kernel_stats_bench.md"), "w") as f:
+    f.write("# %s -- `rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline --no-pmc`\n\n" % tag + STAMP)
+    f.write("Default bench: %d scans per GPU per step (%d distinct cards), %d scans per kernel launch, 1 sweep stream + 1 post "
+            "stream; `runtab_kernel` / `runblk_kernel` / `tables_kernel` are plan creation, one extra `runs_kernel` launch is the "
+            "plan's dry run.\n\n" % (line["config"]["scans_per_gpu_per_step"], line["config"]["distinct_cards_per_gpu"],
+                                      line["config"]["scans_per_kernel_launch"]))
+    rows = stats_table("stats", f)
+    ks = glob.glob(os.path.join(src, "stats", "**", "*kernel_stats.csv"), recursive=True)
+    if ks:
+        shutil.copy(max(ks, key=os.path.getmtime), os.path.join(dst, tag + "_rocprofv3_kernel_stats_bench.csv"))
+    rl = line["roofline"]
+    f.write("\nUn-profiled bench line of the same build (`profiles/%s_bench_line.json`): **%.0f images/s**, `roofline.kernel_ms` "
+            "%.4f ms per launch of %d scans (HIP events on the launch stream, %d launches), bound `%s` frac %.3f; VALU issue %.3f, "
+            "LDS busy %.3f (conflict share %.3f), HBM %.3f of 8 TB/s from the run's own FETCH_SIZE / WRITE_SIZE passes.\n" % (
+                tag, line["value"], rl["kernel_ms"], rl["scans_per_launch"], rl["launch_groups_timed"], rl.get("bound"),
+                rl.get("frac") or float("nan"), rl.get("valu_issue_frac", float("nan")), rl.get("lds_busy_frac", float("nan")),
+                rl.get("lds_conflict_frac", float("nan")), rl.get("hbm_frac", float("nan"))))
+    run = [r for r in rows if "runs_kernel" in r["Name"]]
+    if run:
+        f.write("The profiler's average for `omr::runs_kernel` (%.1f us) must agree with `roofline.kernel_ms` (%.1f us) up to the "
+                "profiler's clock effect.\n" % (float(run[0]["AverageNs"]) / 1e3, rl["kernel_ms"] * 1e3))
+
+# ---- sweep counters
 with open(os.path.join(dst, tag + "_pmc_sweep.md"), "w") as f:
-    f.write("# %s -- rocprofv3 --pmc passes (C2: 2480x3508, A=400)\n\n" % tag)
-    f.write("Commands: tools/profile_round.sh -- FETCH_SIZE and WRITE_SIZE each in their own pass over `bench.py "
-            "--no-cpu-baseline --steps 3`; two SQ passes over `tools/kbench.py 3` (one scan at a time, one stream).\n\n")
-    f.write("## HBM-side traffic (TCC EA counters), median per launch\n\n| kernel | FETCH_SIZE KB | WRITE_SIZE KB |\n|---|---|---|\n")
-    for k in sorted(set(fe) | set(wr)):
-        a = statistics.median(fe[k]["FETCH_SIZE"]) if k in fe and fe[k]["FETCH_SIZE"] else 0
-        b = statistics.median(wr[k]["WRITE_SIZE"]) if k in wr and wr[k]["WRITE_SIZE"] else 0
-        f.write("| `%s` | %.0f | %.0f |\n" % (k, a, b))
-    if sweep:
-        k = sweep[0]
-        a = statistics.median(fe[k]["FETCH_SIZE"])
-        b = statistics.median(wr[k]["WRITE_SIZE"]) if k in wr else 0.0
-        corrected = (2 * a + b) * 1024
-        f.write("\n`%s`: (2 x FETCH_SIZE + WRITE_SIZE) x 1024 = %.0f MB per launch (raw %.0f MB) against %.0f MB of "
-                "algorithmic bytes: the scan is bit-packed (1.09 MB, L2-resident), so the kernel's real HBM traffic is its "
-                "run tables (read once per launch), the u16 row-count partials and the column counts.\n" % (
-                    k, corrected / 1e6, (a + b) * 1024 / 1e6, line["roofline"]["algorithmic_bytes_per_launch"] / 1e6))
-        json.dump({
-            "kernel": k, "FETCH_SIZE_KB_per_launch": a, "WRITE_SIZE_KB_per_launch": b,
-            "correction": "gfx950: FETCH_SIZE x2 (MI355X_MICROARCH.md HBM section), WRITE_SIZE as is, x1024 B",
-            "sweep_kernel_hbm_bytes_per_launch": corrected, "raw_bytes_per_launch": (a + b) * 1024,
-            "algorithmic_bytes_per_launch": line["roofline"]["algorithmic_bytes_per_launch"],
-            "note": "separate rocprofv3 --pmc passes (FETCH_SIZE, then WRITE_SIZE) of `python bench.py --no-cpu-baseline "
-                    "--steps 3`; median over launches. The x2 on FETCH_SIZE is calibrated for wide coalesced streams; this "
-                    "kernel's fetches are 16-byte table / window loads, so the true value lies between the raw and the "
-                    "corrected figure.",
-        }, open(os.path.join(dst, "hbm_traffic.json"), "w"), indent=1)
+    f.write("# %s -- counters of the sweep kernel (C2: 2480x3508, A = 400)\n\n" % tag + STAMP)
+    f.write("## HBM-side traffic and SQ counters measured INSIDE the bench run (bench.py's child passes, 8 scans per launch)\n")
+    for sub in ("bench_pmc/fetch", "bench_pmc/write", "bench_pmc/sq"):
+        counter_table(sub, "runs_kernel", f)
+    if line and line["roofline"].get("traffic"):
+        rl = line["roofline"]
+        f.write("\n(2 x FETCH_SIZE + WRITE_SIZE) x 1024 = **%.0f MB per launch of %d scans** = %.0f GB/s = %.3f of the 8 TB/s HBM peak, "
+                "against %.0f MB of compulsory traffic (bit images + outputs) and %.0f MB of SURVEY-8(d) algorithmic bytes.\n" % (
+                    rl["traffic"] / 1e6, rl["scans_per_launch"], rl["hbm_measured_GBps"], rl["hbm_frac"],
+                    rl["compulsory_bytes_per_launch"] / 1e6, rl["algorithmic_bytes_per_launch"] / 1e6))
+        json.dump({"kernel": rl["kernel"], "measured_at": "commit %s, %s" % (commit, tag),
+                   "FETCH_SIZE_KB_per_launch": rl["hbm_counters_KB"]["FETCH_SIZE"], "WRITE_SIZE_KB_per_launch": rl["hbm_counters_KB"]["WRITE_SIZE"],
+                   "sweep_kernel_hbm_bytes_per_launch": rl["traffic"], "scans_per_launch": rl["scans_per_launch"],
+                   "correction": "gfx950: FETCH_SIZE x2 (MI355X_MICROARCH.md HBM section), WRITE_SIZE as is, x1024 B"},
+                  open(os.path.join(dst, "hbm_traffic.json"), "w"), indent=1)
+    f.write("\n## Single-scan launches (tools/kbench.py), two SQ passes\n")
     for sub in ("pmc_sq1", "pmc_sq2"):
-        c, d = counters(sub), durations(sub)
-        for k in sorted(c):
-            if "runs_kernel" not in k and "sweep_" not in k:
-                continue
-            f.write("\n## %s (%s), median duration %.1f us under the profiler\n\n| counter | per launch |\n|---|---|\n" % (
-                k, sub, statistics.median(d[k]) if d[k] else float("nan")))
-            for n in sorted(c[k]):
-                f.write("| %s | %.4g |\n" % (n, statistics.median(c[k][n])))
-    kb = os.path.join(src, "kbench.log")
-    if os.path.exists(kb):
-        f.write("\n## tools/kbench.py (un-profiled, HIP events around the sweep kernel, one scan at a time)\n\n```\n")
-        f.write("".join(l for l in open(kb) if "sweep kernel" in l))
-        f.write("```\n")
-print("profiles written for", tag)
+        counter_table(sub, "runs_kernel", f)
+    f.write("\n## Un-profiled kernel timings\n\n```\n%s```\n" % read("kbench.log").replace("/opt/amdgpu/share/libdrm/amdgpu.ids: No such file or directory\n", ""))
+    f.write("\n## Phase clocks of wave 0 (debug library, tools/kstamps.py)\n\n```\n%s```\n" % read("kstamps.log").replace("/opt/amdgpu/share/libdrm/amdgpu.ids: No such file or directory\n", ""))
+    f.write("\n## Ablation (debug library, tools/kdbg.py; OMR_RUNS_DBG bit 1 = no compute, 2 = no window fetch/commit, 4 = no flush)\n\n```\n%s```\n" % read("kdbg.log"))
+
+# ---- issue costs / LDS micro-benchmarks
+with open(os.path.join(dst, tag + "_valu_issue.md"), "w") as f:
+    f.write("# %s -- instruction issue cost and LDS micro-benchmarks behind DESIGN.md section 4.1\n\n" % tag + STAMP)
+    for t, what in (("valu_issue", "tools/valu_issue.hip: cycles a wave64 VALU instruction holds a SIMD-32, by resident waves per SIMD"),
+                    ("valu_ops", "tools/valu_ops.hip (generated by tools/gen_valu_ops.py): the same per opcode"),
+                    ("lds_unaligned", "tools/lds_unaligned.hip: ds_read_b64 at 4-byte-aligned addresses vs ds_read2_b32"),
+                    ("lds_bytes", "tools/lds_bytes.hip: sub-dword and tuple read patterns")):
+        f.write("## %s\n\n```\n%s```\n\n" % (what, read(t + ".log")))
+
+# ---- stages / fft / hough / calls
+with open(os.path.join(dst, tag + "_stages.md"), "w") as f:
+    f.write("# %s -- stage kernels either side of the sweep (SURVEY.md 8f rows 1-2)\n\n" % tag + STAMP)
+    f.write("`python3 tools/bench_stages.py 30`: device-resident 2480x3508 scans, HIP events around single launches, median of 30; "
+            "GB/s = compulsory bytes (input once + output once) / time.  The `[x9 tall]` rows run the same kernels on nine scans "
+            "stacked into one image, i.e. with the launch ramp and tail amortised.\n\n```\n%s```\n" % "\n".join(
+                l for l in read("stages.log").splitlines() if not l.startswith("{") and "amdgpu.ids" not in l))
+with open(os.path.join(dst, tag + "_fft.md"), "w") as f:
+    f.write("# %s -- FFT path (BASELINE config 5)\n\n" % tag + STAMP)
+    j = last_json(read("fft.log"))
+    if j:
+        f.write("| case | scans/s | ms/scan | algorithmic GB/s | of 8 TB/s | picture max abs diff vs numpy oracle | identical |\n|---|---|---|---|---|---|---|\n")
+        for k, v in j.items():
+            f.write("| %s (batch %d) | %.0f | %.3f | %.0f | %.3f | %d | %.5f |\n" % (k, v["batch"], v["scans_per_s"], v["ms_per_scan"],
+                    v["algorithmic_GBps"], v["algorithmic_GBps"] / 8000, v["picture_max_abs_diff"], v["picture_identical_fraction"]))
+    f.write("\nKernel stats of the same script (`rocprofv3 --kernel-trace --stats -- python3 tools/bench_fft.py`):\n\n")
+    stats_table("fft_stats", f, 6)
+with open(os.path.join(dst, tag + "_hough.md"), "w") as f:
+    f.write("# %s -- Hough-line path (BASELINE config 4)\n\n" % tag + STAMP)
+    j = last_json(read("hough.log"))
+    if j:
+        f.write("`python3 tools/bench_hough.py 256 8 2`:\n\n```\n%s\n```\n\n" % json.dumps(j, indent=1))
+    f.write("Phase clocks of one scan's sequential stage (debug library, tools/hstamps.py):\n\n```\n%s%s```\n\n" % (
+        read("hstamps_a4.log").replace("/opt/amdgpu/share/libdrm/amdgpu.ids: No such file or directory\n", ""),
+        read("hstamps_half.log").replace("/opt/amdgpu/share/libdrm/amdgpu.ids: No such file or directory\n", "")))
+    f.write("Kernel stats, 64 resident scans (`rocprofv3 --kernel-trace --stats -- python3 tools/hough_run.py 64 4 1`):\n\n")
+    stats_table("hough_stats", f, 8)
+    f.write("\nCounters of `ppht_kernel` (separate passes: FETCH_SIZE alone, WRITE_SIZE alone, eight SQ counters):\n")
+    res = {}
+    for sub in ("hough_fetch", "hough_write", "hough_sq"):
+        res.update({sub: counter_table(sub, "ppht_kernel", f)})
+    try:
+        fe = list(res["hough_fetch"].values())[0]
+        wr = list(res["hough_write"].values())[0]
+        b = pmc.hbm_bytes(fe[0]["FETCH_SIZE"], wr[0]["WRITE_SIZE"])
+        f.write("\nHBM-side traffic of the 64-scan `ppht_kernel` launch: (2 x FETCH_SIZE + WRITE_SIZE) x 1024 = %.2f GB in %.1f ms "
+                "= %.0f GB/s = %.3f of 8 TB/s.\n" % (b / 1e9, fe[1] / 1e3, b / (fe[1] * 1e-6) / 1e9, b / (fe[1] * 1e-6) / 1e9 / 8000))
+    except Exception as e:  # noqa: BLE001
+        f.write("\n(HBM traffic not computed: %r)\n" % (e,))
+with open(os.path.join(dst, tag + "_calls.md"), "w") as f:
+    f.write("# %s -- per-call latency of the host-image drivers and the host-memory batch\n\n" % tag + STAMP)
+    f.write("`python3 tools/bench_calls.py`:\n\n```\n%s```\n\n`python3 tools/bench_host.py`:\n\n```\n%s```\n" % (
+        "\n".join(l for l in read("calls.log").splitlines() if "amdgpu.ids" not in l) + "\n",
+        "\n".join(l for l in read("host.log").splitlines() if "amdgpu.ids" not in l) + "\n"))
+print("profiles written for", tag, "commit", commit)
