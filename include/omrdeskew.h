@@ -327,7 +327,7 @@ int omr_correct_default(const omr_image *src_bgr, uint16_t projection_max_angle,
  * OpenCV's (radix-2 Stockham / Bluestein chirp-z in LDS), so the 8-bit spectrum pictures agree with
  * the CPU restatement to about one grey level, not bit for bit.  Everything after the picture
  * (Canny, HoughLinesP, votes) is the exact chain of the Hough-line path.  Each axis length must be a
- * power of two <= 8192 or any length <= 4096 (-213 otherwise). */
+ * power of two <= 16384 or any length <= 8192 (-213 otherwise): a 600-dpi A4 scan (4960 x 7016) fits. */
 
 /* oics::fft::get_fft_image(&TransformableMatrix) -> Result<(Mat, Mat)> (fft.rs:124-141):
  * (magnitude_image, magnitude_log_image), both 8-bit single channel.  Either output may be NULL. */

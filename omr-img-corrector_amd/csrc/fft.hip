@@ -121,6 +121,25 @@ __device__ cfloat *fft_forward_lds(cfloat *in, cfloat *out, const int m, const i
     return in;
 }
 
+// In-place forward FFT for lengths whose two ping-pong buffers would not fit LDS (m = 16384): radix-2
+// decimation in time on BIT-REVERSED input, natural-order output.  Wf: m / 2 twiddles exp(-2 pi i t / m).
+__device__ void fft_inplace_lds(cfloat *buf, const int m, const int log2m, const cfloat *__restrict__ Wf, const int tid)
+{
+    for (int s = 0; s < log2m; s++) {
+        const int half = 1 << s;
+        __syncthreads();
+        for (int j = tid; j < (m >> 1); j += FFT_THREADS) {
+            const int pos = j & (half - 1);
+            const int i0 = ((j - pos) << 1) + pos, i1 = i0 + half;
+            const cfloat w = Wf[pos << (log2m - 1 - s)];
+            const cfloat a = buf[FPAD(i0)], t = cmul(buf[FPAD(i1)], w);
+            buf[FPAD(i0)] = cadd(a, t);
+            buf[FPAD(i1)] = csub(a, t);
+        }
+    }
+    __syncthreads();
+}
+
 __global__ __launch_bounds__(FFT_THREADS) void fft_pass_kernel(FftPass p)
 {
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
@@ -132,8 +151,10 @@ __global__ __launch_bounds__(FFT_THREADS) void fft_pass_kernel(FftPass p)
         if (p.mag_dst) p.mag_dst += z * p.mag_scan_stride;
         if (p.part) p.part += z * p.part_scan_stride;
     }
-    cfloat *A = (cfloat *)lds_raw, *B = A + FFT_LDS_ELEMS(p.m);
+    cfloat *A = (cfloat *)lds_raw, *B = A + FFT_LDS_ELEMS(p.m);  // B is not allocated (nor used) on the in-place path
     const int tid = threadIdx.x, n = p.n, m = p.m;
+    const bool inplace = m > OMR_FFT_MAX_PINGPONG;
+    const int rshift = 32 - p.log2m;
     // Column passes (elem_stride > 1) touch 8 bytes per 64-byte sector: the eight columns that share a
     // sector must meet in one XCD's L2.  Workgroups go round-robin to the 8 XCDs, so XCD x takes the
     // lines [x * lines / 8, (x + 1) * lines / 8) in order instead of every eighth line.
@@ -157,9 +178,12 @@ __global__ __launch_bounds__(FFT_THREADS) void fft_pass_kernel(FftPass p)
             }
             if (blue) v = cmul(v, p.chirp[k]);
         }
-        A[FPAD(k)] = v;
+        const int at = inplace ? (int)(__brev((unsigned)k) >> rshift) : k;
+        A[FPAD(at)] = v;
     }
-    cfloat *P = fft_forward_lds(A, B, m, p.log2m, p.W, tid);
+    cfloat *P = A;
+    if (inplace) fft_inplace_lds(A, m, p.log2m, p.Wfull, tid);
+    else P = fft_forward_lds(A, B, m, p.log2m, p.W, tid);
     cfloat *Q = P == A ? B : A;
     cfloat *dst = p.dst + line * p.line_stride;
     // spectrum-picture mode (column pass): point k of this line is F(k, line); it lands at the quadrant-swapped
@@ -237,10 +261,24 @@ __global__ __launch_bounds__(FFT_THREADS) void fft_pass_kernel(FftPass p)
         const cfloat c = cmul(P[FPAD(k)], p.Bf[k]);
         P[FPAD(k)] = cfloat{c.x, -c.y};
     }
-    cfloat *R = fft_forward_lds(P, Q, m, p.log2m, p.W, tid);
+    cfloat *R = P;
+    if (inplace) {  // bit-reverse in place (pairs swap), then the second transform in the same buffer
+        __syncthreads();
+        for (int k = tid; k < m; k += FFT_THREADS) {
+            const int r = (int)(__brev((unsigned)k) >> rshift);
+            if (k < r) {
+                const cfloat t = P[FPAD(k)];
+                P[FPAD(k)] = P[FPAD(r)];
+                P[FPAD(r)] = t;
+            }
+        }
+        fft_inplace_lds(P, m, p.log2m, p.Wfull, tid);
+    } else {
+        R = fft_forward_lds(P, Q, m, p.log2m, p.W, tid);
+    }
     const float inv_m = 1.0f / (float)m;
     if (pairs) {  // the line's spectrum must be complete in LDS before the two rows can be separated
-        cfloat *Z = R == A ? B : A;
+        cfloat *Z = inplace ? R : (R == A ? B : A);  // element-wise, so in place is fine
         for (int k = tid; k < n; k += FFT_THREADS) Z[FPAD(k)] = cmul(cfloat{R[FPAD(k)].x * inv_m, -R[FPAD(k)].y * inv_m}, p.chirp[k]);
         __syncthreads();
         emit_pair(Z);
@@ -257,7 +295,8 @@ hipError_t launch_fft_pass(const FftPass &p, hipStream_t s)
 {
     if (p.lines <= 0) return hipSuccess;
     if (p.m > OMR_FFT_MAX_M || (1 << p.log2m) != p.m) return hipErrorInvalidValue;
-    const size_t lds = 2 * sizeof(cfloat) * (size_t)FFT_LDS_ELEMS(p.m);
+    const size_t lds = (p.m > OMR_FFT_MAX_PINGPONG ? 1 : 2) * sizeof(cfloat) * (size_t)FFT_LDS_ELEMS(p.m);
+    if (p.m > OMR_FFT_MAX_PINGPONG && !p.Wfull) return hipErrorInvalidValue;
     hipError_t e = hipFuncSetAttribute((const void *)fft_pass_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(fft_pass_kernel, dim3(p.real_pairs ? (p.lines + 1) / 2 : p.lines, p.scans > 0 ? p.scans : 1),

@@ -13,7 +13,8 @@ struct cfloat {
 
 // One pass of 1-D transforms over `lines` lines of length n, a whole line per workgroup in LDS:
 // a radix-4 / radix-2 Stockham FFT when n is a power of two (m = n), else Bluestein's chirp-z through two
-// FFTs of length m = the power of two >= 2n - 1.  m <= 8192 (2 x 64 KiB of LDS).
+// FFTs of length m = the power of two >= 2n - 1.  m <= 8192 ping-pongs between two LDS buffers (radix 8);
+// m = 16384 (lines of 4097 .. 8192 points, e.g. a 600-dpi A4 scan) runs in place in one buffer (radix 2).
 struct FftPass {
     const uint8_t *src_u8;  // real 8-bit input (im = 0), x = (float)v * in_scale; or NULL
     int64_t src_step;       // bytes between lines of src_u8
@@ -43,12 +44,14 @@ struct FftPass {
     //   mirrored point ((R - k) % R, (C - c) % C), F(-k, -c) = conj F(k, c), unless the column is its own mirror.
     int32_t real_pairs, src_rows, half_mirror;
     // several scans per launch (blockIdx.y = scan): strides of the per-scan arrays; 0 / 1 scan by default
+    const cfloat *Wfull;    // in-place path (m > OMR_FFT_MAX_PINGPONG): m / 2 twiddles exp(-2 pi i t / m)
     int32_t scans;
     int64_t src_u8_scan_stride;                  // bytes
     int64_t c_scan_stride;                       // elements of src_c / dst
     int64_t mag_scan_stride, part_scan_stride;   // floats
 };
-#define OMR_FFT_MAX_M 8192
+#define OMR_FFT_MAX_M 16384    // transforms of 16384 points run in place (one 128 KiB LDS buffer, radix 2)
+#define OMR_FFT_MAX_PINGPONG 8192
 hipError_t launch_fft_pass(const FftPass &p, hipStream_t s);
 
 // d_minmax: 4 ordered-uint words {min |F|, max |F|, min log, max log}; d_part: scratch for per-block

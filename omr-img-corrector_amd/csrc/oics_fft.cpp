@@ -57,7 +57,7 @@ void fft_host(std::vector<cd> &a)  // iterative radix-2, in place, forward
 struct AxisTables {
     int n = 0, m = 0, log2m = 0;
     bool blue = false;
-    DevBuf W, chirp, Bf;
+    DevBuf W, Wfull, chirp, Bf;
     int build(int len, hipStream_t s)
     {
         n = len;
@@ -80,6 +80,15 @@ struct AxisTables {
                 w.push_back(cfloat{(float)cos(ang), (float)sin(ang)});
             }
         if (w.empty()) w.push_back(cfloat{1.f, 0.f});
+        if (m > OMR_FFT_MAX_PINGPONG) {  // the in-place radix-2 path reads one full table
+            std::vector<cfloat> wf((size_t)m / 2);
+            for (int t = 0; t < m / 2; t++) {
+                const double ang = -2.0 * kPi * (double)t / (double)m;
+                wf[t] = cfloat{(float)cos(ang), (float)sin(ang)};
+            }
+            OMR_HIP(Wfull.alloc(sizeof(cfloat) * wf.size()));
+            OMR_HIP(hipMemcpy(Wfull.p, wf.data(), sizeof(cfloat) * wf.size(), hipMemcpyHostToDevice));
+        }
         OMR_HIP(W.alloc(sizeof(cfloat) * w.size()));
         OMR_HIP(hipMemcpyAsync(W.p, w.data(), sizeof(cfloat) * w.size(), hipMemcpyHostToDevice, s));
         if (blue) {
@@ -152,6 +161,7 @@ struct FftWork {
         p.log2m = ax_cols.log2m;
         p.lines = rows;
         p.W = ax_cols.W.as<cfloat>();
+        p.Wfull = ax_cols.Wfull.as<cfloat>();
         p.chirp = ax_cols.blue ? ax_cols.chirp.as<cfloat>() : nullptr;
         p.Bf = ax_cols.blue ? ax_cols.Bf.as<cfloat>() : nullptr;
         p.out_scale = 1.0f;
@@ -181,6 +191,7 @@ struct FftWork {
         q.lines = cols / 2 + 1;  // the other columns are mirror images (real input)
         q.half_mirror = 1;
         q.W = ax_rows.W.as<cfloat>();
+        q.Wfull = ax_rows.Wfull.as<cfloat>();
         q.chirp = ax_rows.blue ? ax_rows.chirp.as<cfloat>() : nullptr;
         q.Bf = ax_rows.blue ? ax_rows.Bf.as<cfloat>() : nullptr;
         q.out_scale = (float)(1.0 / ((double)rows * (double)cols));
