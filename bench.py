@@ -71,6 +71,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pmc", action="store_true", help="skip the in-run rocprofv3 counter passes")
     ap.add_argument("--dry-run", action="store_true", help="CPU rehearsal of the N-rank launch (gloo, no GPU work)")
+    ap.add_argument("--share-gpus", action="store_true",
+                    help="rehearsal on a box with fewer GPUs than ranks: rank r computes on device r %% device_count and the "
+                         "result gather runs over gloo (RCCL refuses two ranks on one device); never used for reported numbers")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--cards", default=None, help=argparse.SUPPRESS)  # .npy of pre-generated cards (PMC children)
     return ap.parse_args(argv)
@@ -312,11 +315,14 @@ def main():
     from oics import projection
     import oics
 
-    rank, local_rank, world = odist.init()
+    rank, local_rank, world = odist.init(backend="gloo" if args.share_gpus else None)
     if not torch.cuda.is_available() or oics.lib().omr_device_count() < 1:
         raise SystemExit("bench.py needs a HIP device: the product has no CPU path")
+    if args.share_gpus:
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    xdev = torch.device("cpu") if args.share_gpus else dev  # where the (tiny) exchanged tensors live
 
     N, A = projection.candidate_count(MAX_ANGLE, STEP)
     scans = torch.from_numpy(cards).to(dev)
@@ -346,7 +352,7 @@ def main():
     for _ in range(args.steps):
         step()
     fence()
-    elapsed = odist.barrier_max_seconds(time.perf_counter() - t0, dev)
+    elapsed = odist.barrier_max_seconds(time.perf_counter() - t0, xdev)
 
     if args.pmc_child:
         batch.close()
@@ -355,7 +361,7 @@ def main():
 
     # the path's only exchange: gather of the per-scan results (outside the per-step loop, as in
     # a real batch job where it happens once)
-    all_best = odist.gather_results(best, B * world, rank, world)
+    all_best = odist.gather_results(best.to(xdev), B * world, rank, world)
 
     # roofline leg: duration of the sweep stage of a launch group (G scans) from HIP events recorded on
     # the stream the kernels are launched on, over min(K, 50) more steps.  The stage is `launches` kernel
@@ -452,6 +458,8 @@ def main():
         else:
             roof.update(bound="hbm", achieved=None, peak=HBM_PEAK_GBPS, unit="GB/s", frac=None)
         out["roofline"] = roof
+        if args.share_gpus:
+            out["rehearsal"] = "--share-gpus: %d ranks on %d device(s), gloo gather; not a scaling measurement" % (world, torch.cuda.device_count())
         out["accuracy_ok"] = acc_ok
         out["gathered_results"] = int(all_best.numel())
         if not args.no_cpu_baseline and world == 1:  # reported at N = 1 only
