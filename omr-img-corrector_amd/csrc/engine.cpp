@@ -66,6 +66,63 @@ size_t round_block(size_t n)
 }
 }  // namespace
 
+namespace {
+struct PinnedStage {  // grow-only, one per host thread, never freed (a thread_local destructor could outlive the runtime)
+    void *p = nullptr;
+    size_t cap = 0;
+};
+thread_local PinnedStage t_stage;
+const size_t kStageMax = (size_t)64 << 20;  // larger results go in pieces
+int stage_reserve(size_t n)
+{
+    n = n > kStageMax ? kStageMax : n;
+    if (t_stage.cap >= n) return 0;
+    if (t_stage.p) (void)hipHostFree(t_stage.p);
+    t_stage.p = nullptr;
+    t_stage.cap = 0;
+    const size_t want = (n + ((size_t)1 << 20) - 1) & ~(((size_t)1 << 20) - 1);
+    hipError_t e = hipHostMalloc(&t_stage.p, want, hipHostMallocDefault);
+    if (e != hipSuccess) return fail_gpu("hipHostMalloc (download staging)", e);
+    t_stage.cap = want;
+    return 0;
+}
+}  // namespace
+
+int staged_d2h(void *dst, const void *d_src, size_t bytes, hipStream_t s)
+{
+    if (bytes < ((size_t)256 << 10)) {  // small results: the direct copy is as fast
+        OMR_HIP(hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, s));
+        OMR_HIP(hipStreamSynchronize(s));
+        return 0;
+    }
+    int rc = stage_reserve(bytes);
+    if (rc) return rc;
+    for (size_t off = 0; off < bytes; off += t_stage.cap) {
+        const size_t n = bytes - off < t_stage.cap ? bytes - off : t_stage.cap;
+        OMR_HIP(hipMemcpyAsync(t_stage.p, (const char *)d_src + off, n, hipMemcpyDeviceToHost, s));
+        OMR_HIP(hipStreamSynchronize(s));
+        memcpy((char *)dst + off, t_stage.p, n);
+    }
+    return 0;
+}
+
+int staged_d2h_2d(void *dst, size_t dst_step, const void *d_src, size_t row_bytes, size_t rows, hipStream_t s)
+{
+    if (dst_step == row_bytes) return staged_d2h(dst, d_src, row_bytes * rows, s);
+    if (row_bytes == 0 || rows == 0) return 0;
+    int rc = stage_reserve(row_bytes * rows);
+    if (rc) return rc;
+    const size_t per = t_stage.cap / row_bytes > 0 ? t_stage.cap / row_bytes : 1;  // rows per piece
+    if (per * row_bytes > t_stage.cap && (rc = stage_reserve(row_bytes))) return rc;
+    for (size_t r0 = 0; r0 < rows; r0 += per) {
+        const size_t nr = rows - r0 < per ? rows - r0 : per;
+        OMR_HIP(hipMemcpyAsync(t_stage.p, (const char *)d_src + r0 * row_bytes, nr * row_bytes, hipMemcpyDeviceToHost, s));
+        OMR_HIP(hipStreamSynchronize(s));
+        for (size_t r = 0; r < nr; r++) memcpy((char *)dst + (r0 + r) * dst_step, (const char *)t_stage.p + r * row_bytes, row_bytes);
+    }
+    return 0;
+}
+
 PoolScope::PoolScope(hipStream_t stream) : prev_(t_pool_stream), prev_on_(t_pool_on)
 {
     t_pool_stream = stream;

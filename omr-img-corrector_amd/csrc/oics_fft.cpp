@@ -219,13 +219,9 @@ int download_owned(const uint8_t *d, int rows, int cols, omr_image_owned *out, h
     out->step_bytes = cols;
     out->data = (uint8_t *)malloc((size_t)rows * cols);
     if (!out->data) return fail(OMR_ERR_NOMEM, "out of host memory");
-    hipError_t e = hipMemcpyAsync(out->data, d, (size_t)rows * cols, hipMemcpyDeviceToHost, s);
-    if (e == hipSuccess) e = hipStreamSynchronize(s);
-    if (e != hipSuccess) {
-        omr_image_free(out);
-        return fail_gpu("download picture", e);
-    }
-    return OMR_OK;
+    int rc = staged_d2h(out->data, d, (size_t)rows * cols, s);
+    if (rc) omr_image_free(out);
+    return rc;
 }
 
 }  // namespace

@@ -77,13 +77,9 @@ struct DevImage {
     }
     int download(uint8_t *dst, int64_t dstep, hipStream_t s) const
     {
-        if (dstep == step())
-            OMR_HIP(hipMemcpyAsync(dst, buf.p, (size_t)step() * rows, hipMemcpyDeviceToHost, s));
-        else
-            OMR_HIP(hipMemcpy2DAsync(dst, (size_t)dstep, buf.p, (size_t)step(), (size_t)step(), (size_t)rows,
-                                     hipMemcpyDeviceToHost, s));
-        OMR_HIP(hipStreamSynchronize(s));
-        return OMR_OK;
+        // through the calling thread's pinned staging buffer (engine.cpp: a direct copy into pageable memory is
+        // an order of magnitude slower for image-sized results)
+        return staged_d2h_2d(dst, (size_t)dstep, buf.p, (size_t)step(), (size_t)rows, s);
     }
 };
 

@@ -310,13 +310,9 @@ int omr_canny(const omr_image *src, double low_thresh, double high_thresh, omr_i
     edges->step_bytes = src->cols;
     edges->data = (uint8_t *)malloc((size_t)src->rows * src->cols);
     if (!edges->data) return fail(OMR_ERR_NOMEM, "out of host memory");
-    hipError_t e = hipMemcpyAsync(edges->data, map.p, (size_t)src->rows * src->cols, hipMemcpyDeviceToHost, st.s);
-    if (e == hipSuccess) e = hipStreamSynchronize(st.s);
-    if (e != hipSuccess) {
-        omr_image_free(edges);
-        return fail_gpu("download edges", e);
-    }
-    return OMR_OK;
+    rc = staged_d2h(edges->data, map.p, (size_t)src->rows * src->cols, st.s);
+    if (rc) omr_image_free(edges);
+    return rc;
 }
 
 int omr_hough_lines_p(const omr_image *edges, double rho, double theta, int32_t threshold, double min_line_length,

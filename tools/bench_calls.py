@@ -39,4 +39,19 @@ out["get_angle_with_projections 2480x3508 3-channel (10, 0.05, scale 1) ms"] = t
 out["rotate_mat CONTAIN NEAREST 2480x3508 ms"] = timeit(
     lambda: transfer.rotate_mat(g2, 3.3, 1.0, 0, 0, (255, 255, 255, 0), transfer.RotateClipStrategy.CONTAIN), 5)
 out["canny 2480x3508 ms"] = timeit(lambda: hough.canny(g2), 5)
+# the Tauri host runs correct_default on a pool of OS threads, one file each (thread_pool.rs:41-88): files/s with
+# T host threads calling the re-entrant entry point at once (dataset-sized sheets; ctypes releases the GIL)
+from concurrent.futures import ThreadPoolExecutor
+sheets = []
+for i in range(8):
+    gi, _ = synth.make_card(1150, 1240, 40 + i)
+    sheets.append(np.stack([gi, gi, gi], axis=2))
+for T in (1, 4, 16):
+    n = 64 * T if T > 1 else 64
+    with ThreadPoolExecutor(T) as ex:
+        list(ex.map(lambda k: omr.correct_default(sheets[k % 8], 45, 0.2, 248, 230, 150.0, 50.0), range(T)))  # warm-up
+        t0 = time.perf_counter()
+        list(ex.map(lambda k: omr.correct_default(sheets[k % 8], 45, 0.2, 248, 230, 150.0, 50.0), range(n)))
+        dt = time.perf_counter() - t0
+    out["correct_default 1240x1150 bgr, %d host thread(s): files/s" % T] = n / dt
 print(json.dumps(out, indent=1))
