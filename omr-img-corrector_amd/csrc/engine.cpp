@@ -88,6 +88,17 @@ int stage_reserve(size_t n)
 }
 }  // namespace
 
+int thread_stream(hipStream_t *out)
+{
+    thread_local hipStream_t streams[16] = {};
+    int dev = 0;
+    OMR_HIP(hipGetDevice(&dev));
+    hipStream_t &s = streams[dev & 15];
+    if (!s) OMR_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    *out = s;
+    return 0;
+}
+
 int staged_d2h(void *dst, const void *d_src, size_t bytes, hipStream_t s)
 {
     if (bytes < ((size_t)256 << 10)) {  // small results: the direct copy is as fast

@@ -68,6 +68,11 @@ struct NoPoolScope {
     bool prev_on_;
 };
 
+// The calling thread's stream for per-call work on the current device: created on first use and kept for the
+// thread's lifetime (hipStreamCreate / hipStreamDestroy per call cost more than a 248x230 sweep and serialise in
+// the runtime when the host's worker pool, thread_pool.rs:41-88, calls in from many threads).  Non-blocking.
+int thread_stream(hipStream_t *out);
+
 // Device -> pageable host memory through a per-thread pinned staging buffer.  A direct hipMemcpy into a freshly
 // malloc'ed result image makes the runtime pin the destination pages on the fly: 13 ms for the 5 MB rotated sheet
 // of correct_default (72 files/s) against 0.6 ms through the staging buffer.  Synchronises `s`.

@@ -86,14 +86,11 @@ struct DevImage {
 struct Stream {
     hipStream_t s = nullptr;
     std::unique_ptr<PoolScope> pool;  // the call's device buffers come from / return to the block cache
-    ~Stream()
-    {
-        pool.reset();
-        if (s) (void)hipStreamDestroy(s);
-    }
+    ~Stream() { pool.reset(); }  // the stream belongs to the thread (engine.cpp thread_stream), not to the call
     int create()
     {
-        OMR_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+        int rc = thread_stream(&s);
+        if (rc) return rc;
         pool.reset(new PoolScope(s));
         return OMR_OK;
     }

@@ -31,15 +31,12 @@ namespace hh {
 
 int HStream::create()
 {
-    OMR_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    int rc = thread_stream(&s);  // the calling thread's stream, kept across calls
+    if (rc) return rc;
     pool.reset(new PoolScope(s));
     return OMR_OK;
 }
-HStream::~HStream()
-{
-    pool.reset();
-    if (s) (void)hipStreamDestroy(s);
-}
+HStream::~HStream() { pool.reset(); }
 
 int have_device()
 {
