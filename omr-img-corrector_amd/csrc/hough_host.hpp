@@ -44,4 +44,11 @@ int select_omr_rs(const std::vector<float> &ang, const std::vector<int32_t> &cnt
                   double *candidates, int32_t cand_cap, int32_t *cand_len);
 
 }  // namespace hh
+// defined in oics_host.cpp: path 2's projection result (omr.rs:52-229) and rotate_mat (transfer.rs:459-523) on a
+// packed image that is already on the device -- correct_default uploads its sheet once
+int result_from_projection_device(const uint8_t *d_src, int rows, int cols, int cn, uint16_t max_angle, double step,
+                                  int32_t max_w, int32_t max_h, hipStream_t s, double *angle, int32_t *status,
+                                  double *candidates, int32_t cand_cap, int32_t *cand_len);
+int rotate_device_to_host(const uint8_t *d_src, int rows, int cols, int cn, double angle_deg, double scale, int interp,
+                          const uint8_t border_value[4], int clip, hipStream_t s, omr_image_owned *dst);
 }  // namespace omr

@@ -311,6 +311,12 @@ int argmax_path1(const double *v, const double *h, int n)
 
 }  // namespace
 
+namespace omr {
+int result_from_projection_device(const uint8_t *d_src, int rows, int cols, int cn, uint16_t max_angle, double step,
+                                  int32_t max_w, int32_t max_h, hipStream_t s, double *angle, int32_t *status,
+                                  double *candidates, int32_t cand_cap, int32_t *cand_len);
+}
+
 extern "C" {
 
 void omr_image_free(omr_image_owned *img)
@@ -441,29 +447,12 @@ int omr_get_result_from_projection(const omr_image *src, uint16_t max_angle, dou
     if (rc) return rc;
     if (!angle || !status) return fail(OMR_ERR_BADARG, "null output");
     if (src->channels == 2) return fail(OMR_ERR_ASSERT, "RGB2GRAY needs 3 or 4 channels");
-    // :60-82
-    double width_scale = max_w <= 0 ? 1.0 : (double)max_w / (double)src->cols;
-    double height_scale = max_h <= 0 ? 1.0 : (double)max_h / (double)src->rows;
-    double scale = width_scale < height_scale ? width_scale : height_scale;
-    int dev;
-    if ((rc = current_device(&dev))) return rc;
     Stream st;
     if ((rc = st.create())) return rc;
-    DevImage in, gray, e1, scaled;
+    DevImage in;
     if ((rc = in.upload(src, st.s))) return rc;
-    if ((rc = to_gray(in, &gray, st.s))) return rc;  // :88-92
-    // :98-112 erode(3x3 cross, iterations = 3)
-    if ((rc = e1.alloc(gray.rows, gray.cols, 1))) return rc;
-    OMR_HIP(launch_erode3x_cross(gray.ptr(), gray.step(), gray.rows, gray.cols, e1.ptr(), e1.step(), st.s));
-    // :114-126
-    int dc = (int)((double)src->cols * scale), dr = (int)((double)src->rows * scale);
-    if ((rc = resize_area(e1, dr, dc, &scaled, st.s))) return rc;
-    // :129-139 threshold fused into the pack; :153-208 sweep with matrix scale = resize scale (quirk B4)
-    std::vector<double> vs, hs;
-    int N = 0;
-    if ((rc = sweep_scores(scaled, 127, max_angle, step, scale, dev, st.s, &vs, &hs, &N))) return rc;
-    return omr_select_projection_result(vs.data(), hs.data(), (int32_t)vs.size(), N, step, angle, status, candidates,
-                                        cand_cap, cand_len);
+    return omr::result_from_projection_device(in.ptr(), in.rows, in.cols, in.cn, max_angle, step, max_w, max_h, st.s, angle,
+                                              status, candidates, cand_cap, cand_len);
 }
 
 // ---- per-image helpers ------------------------------------------------------------------------
@@ -922,3 +911,56 @@ int omr_sweep_batch(const omr_image *scans, int32_t n, uint16_t max_angle, doubl
 }
 
 }  // extern "C"
+
+// omr.rs:52-229 on a packed device-resident image (the host-image driver and correct_default both end here, so
+// a sheet that is already on the device is not uploaded again)
+namespace omr {
+int result_from_projection_device(const uint8_t *d_src, int rows, int cols, int cn, uint16_t max_angle, double step,
+                                  int32_t max_w, int32_t max_h, hipStream_t s, double *angle, int32_t *status,
+                                  double *candidates, int32_t cand_cap, int32_t *cand_len)
+{
+    // :60-82
+    const double width_scale = max_w <= 0 ? 1.0 : (double)max_w / (double)cols;
+    const double height_scale = max_h <= 0 ? 1.0 : (double)max_h / (double)rows;
+    const double scale = width_scale < height_scale ? width_scale : height_scale;
+    int dev, rc;
+    if ((rc = current_device(&dev))) return rc;
+    DevImage gray, e1, scaled;
+    if ((rc = gray.alloc(rows, cols, 1))) return rc;
+    if (cn == 1) {  // the reference's cvtColor would raise on a 1-channel Mat; accepted here as a convenience
+        OMR_HIP(hipMemcpyAsync(gray.buf.p, d_src, (size_t)rows * cols, hipMemcpyDeviceToDevice, s));
+    } else if (cn == 3 || cn == 4) {
+        OMR_HIP(launch_rgb2gray_fast(d_src, (int64_t)cols * cn, rows, cols, cn, gray.ptr(), gray.step(), s));  // :88-92
+    } else {
+        return fail(OMR_ERR_ASSERT, "RGB2GRAY needs 3 or 4 channels, got %d", cn);
+    }
+    // :98-112 erode(3x3 cross, iterations = 3)
+    if ((rc = e1.alloc(rows, cols, 1))) return rc;
+    OMR_HIP(launch_erode3x_cross(gray.ptr(), gray.step(), rows, cols, e1.ptr(), e1.step(), s));
+    // :114-126
+    const int dc = (int)((double)cols * scale), dr = (int)((double)rows * scale);
+    if ((rc = resize_area(e1, dr, dc, &scaled, s))) return rc;
+    // :129-139 threshold fused into the pack; :153-208 sweep with matrix scale = resize scale (quirk B4)
+    std::vector<double> vs, hs;
+    int N = 0;
+    if ((rc = sweep_scores(scaled, 127, max_angle, step, scale, dev, s, &vs, &hs, &N))) return rc;
+    return omr_select_projection_result(vs.data(), hs.data(), (int32_t)vs.size(), N, step, angle, status, candidates,
+                                        cand_cap, cand_len);
+}
+
+// rotate_mat (transfer.rs:459-523) of a packed device-resident image into a new host image
+int rotate_device_to_host(const uint8_t *d_src, int rows, int cols, int cn, double angle_deg, double scale, int interp,
+                          const uint8_t border_value[4], int clip, hipStream_t s, omr_image_owned *dst)
+{
+    double M[6];
+    int drows, dcols, rc;
+    if ((rc = rotate_geometry(rows, cols, angle_deg, scale, clip, M, &drows, &dcols))) return rc;
+    DevImage out;
+    DevBuf keep;
+    if ((rc = out.alloc(drows, dcols, cn))) return rc;
+    if ((rc = rotate_launch(d_src, (int64_t)cols * cn, rows, cols, cn, M, interp, border_value, out.ptr(), out.step(), drows,
+                            dcols, s, &keep)))
+        return rc;
+    return give_owned(out, dst, s);
+}
+}  // namespace omr

@@ -495,23 +495,43 @@ int omr_correct_default(const omr_image *src, uint16_t projection_max_angle, dou
     const int n_cand = omr_candidate_count(projection_max_angle, projection_angle_step, &n_half);  // candidates <= sweep angles
     if (n_cand <= 0) return fail(OMR_ERR_BADARG, "empty candidate range");
     std::vector<double> pc((size_t)n_cand + 1);
-    rc = omr_get_result_from_projection(src, projection_max_angle, projection_angle_step, projection_max_width,
-                                        projection_max_height, &pa, &pst, pc.data(), (int32_t)pc.size(), &pn);
+    if (src->channels == 2) return fail(OMR_ERR_ASSERT, "RGB2GRAY needs 3 or 4 channels");
+    if ((rc = have_device())) return rc;
+    // the sheet goes to the device once; projection, the Hough fallback and the final warp all read that copy
+    HStream st;
+    if ((rc = st.create())) return rc;
+    DevBuf in;
+    if ((rc = upload(src, &in, st.s))) return rc;
+    const uint8_t *d_src = in.as<uint8_t>();
+    rc = omr::result_from_projection_device(d_src, src->rows, src->cols, src->channels, projection_max_angle,
+                                            projection_angle_step, projection_max_width, projection_max_height, st.s, &pa,
+                                            &pst, pc.data(), (int32_t)pc.size(), &pn);
     if (rc) return rc;
     if (pst == OMR_STATUS_BELIEVED) {
         *rotate_angle = pa;
         *need_check = 0;
-    } else {
+    } else {  // omr.rs:361-402
+        HoughParams hp;
+        hp.min_line_length = hough_min_line_length;
+        hp.max_line_gap = hough_max_line_gap;
+        std::vector<std::vector<int32_t>> lines;
+        if ((rc = edges_lines_device(d_src, 0, (int64_t)src->cols * src->channels, src->rows, src->cols, src->channels, 1, hp,
+                                     st.s, &lines)))
+            return rc;
+        std::vector<float> ang;
+        std::vector<int32_t> cnt;
+        line_angles(lines[0], &ang);
+        if ((rc = vote_counts(ang, true, st.s, &cnt))) return rc;
         double ea = 0;
         int32_t est = 0, en = 0;
-        rc = omr_get_result_from_edges_detection(src, hough_min_line_length, hough_max_line_gap, &ea, &est, nullptr, 0, &en);
-        if (rc) return rc;
+        if ((rc = select_omr_rs(ang, cnt, &ea, &est, nullptr, 0, &en))) return rc;
         omr_correct_default_decision(pa, pst, pc.data(), std::min<int32_t>(pn, (int32_t)pc.size()), ea, rotate_angle,
                                      need_check);
     }
     if (rotated) {  // omr.rs:404-445: CONTAIN canvas, nearest neighbour, white border, scale 1
         const uint8_t white[4] = {255, 255, 255, 0};
-        rc = omr_rotate(src, *rotate_angle, 1.0, OMR_INTER_NEAREST, white, OMR_CLIP_CONTAIN, rotated);
+        rc = omr::rotate_device_to_host(d_src, src->rows, src->cols, src->channels, *rotate_angle, 1.0, OMR_INTER_NEAREST, white,
+                                        OMR_CLIP_CONTAIN, st.s, rotated);
     }
     return rc;
 }
