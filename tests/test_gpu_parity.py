@@ -674,3 +674,19 @@ def test_fused_erode_fast_path_edges(oracle):
             got = out.cpu().numpy()
             assert (got[:, :cols] == oracle.erode_cross3(img, 3)).all(), (rows, cols, kind)
             assert (got[:, cols:] == 9).all()  # padding bytes of the destination stay untouched
+
+
+def test_large_results_through_the_staging_buffer(oracle):
+    """Image-sized results leave the device through a per-thread pinned staging buffer (engine.cpp staged_d2h):
+    packed and strided destinations, sizes around the 256 KB switch and above one staging piece."""
+    import ctypes as C
+    from oics._lib import check, lib, u8p
+    from oics.transfer import as_image
+    rng = np.random.Generator(np.random.PCG64(321))
+    for (rows, cols, pitch) in ((600, 700, 700), (600, 700, 768), (300, 800, 801), (20, 30, 64), (9000, 8000, 8000)):
+        g = rng.integers(0, 256, (rows, cols), dtype=np.uint8)
+        a, im = as_image(g)
+        out = np.full((rows, pitch), 7, np.uint8)
+        check(lib().omr_threshold_binary(C.byref(im), out.ctypes.data_as(u8p), pitch))
+        assert (out[:, :cols] == np.where(g > 127, 255, 0)).all(), (rows, cols, pitch)
+        assert (out[:, cols:] == 7).all()
