@@ -282,67 +282,76 @@ hipError_t launch_edges_compact(const uint8_t *d_edges, int rows, int cols, int 
 }
 
 // ------------------------------------------------------------------------------------------
-// HoughLinesProbabilistic, one workgroup (4 waves) per scan.
-//   wave 0       : the draw stage.  The draw order does not depend on the image (RNG + swap-remove
-//                  on the point list), so 64 draws are made per round: lane 0 steps the RNG 64 times,
-//                  every lane takes one draw (index, the point, the element swapped in), the swaps
-//                  are committed together when no two draws of the round touch the same list slot
-//                  (else lane 0 replays the round one by one), and the 64 mask tests are one memory
-//                  round trip.  Points still set are then served lowest lane first; after every
-//                  walk the remaining ones are re-tested (the walk may have erased them).
-//   lane = angle : the 180 accumulator increments of a served point and their arg-max; the
-//                  decrements ("un-votes") of an accepted segment's points (fire-and-forget atomics)
-//   lane = step  : the two walks along the chosen line run side by side (threads 0-127 one way,
-//                  128-255 the other, 128 positions per round); the sequential gap rule is applied
-//                  to the rounds' ballots by threads 0 and 128
-// Row n of the accumulator is only ever touched by lane n, so its updates are ordered; mask bytes
-// and list slots are read and written with device-scope (L2) accesses between barriers.
-struct PphtShared {
-    int i, j;                      // served point (i = row, j = column), i < 0: list exhausted
-    unsigned long long key[4];     // per-wave (value, angle) maxima
-    unsigned long long nzb[4];     // walk round: non-zero ballots
-    unsigned long long oob[4];     // walk round: out-of-image ballots
-    int stop[2], gap[2], end_t[2]; // walk state of both directions
-    uint32_t r[64];                // draw round: raw RNG outputs (replay: the drawn points)
-    int pts[OMR_PPHT_THREADS];     // points to un-vote in this round (y << 16 | x)
+// HoughLinesProbabilistic, one workgroup of TWO waves per scan and no workgroup barrier.
+//
+// The algorithm is a dependent chain over the drawn points (every point sees the accumulator and the mask left
+// by all points before it), so a scan's time is (points served) x (latency of one step).  The step is cut down
+// to two memory round trips -- the vote's accumulator reads and the walk's mask reads:
+//
+//   wave 1, the draw stage, runs AHEAD of the rest: the draw order does not depend on the image (cv::RNG and
+//     swap-remove on the point list), so this wave turns the list into the sequence of drawn points, 64 draws
+//     per round -- lane 0 steps the RNG, every lane takes one draw (index, its slot, the slot swapped in), the
+//     64 sequential swap-removes are replayed on those registers (v_readlane of draw t, compare, select) and
+//     written back -- and publishes its progress in LDS (release / acquire at workgroup scope: both waves
+//     run on one CU and share its L1).
+//   wave 0 takes 64 drawn points at a time, tests them against the mask in one round trip and serves those
+//     still set, lowest first:
+//       vote     lane = accumulator angle (three per lane): load, +1, store; arg-max by DPP (larger value,
+//                then the LOWER angle: "if (max_val < val)" keeps the first maximum);
+//       walk     lane = step: 128 steps of both directions per round (four mask words per lane in flight); the
+//                sequential gap rule runs on the ballots (scalar code);
+//       pass 2   erases the segment's points (atomic AND, nothing waits) from the flags pass 1 already holds and,
+//                for an accepted segment, un-votes them: lane = angle, fire-and-forget atomic decrements.  Row n
+//                of the accumulator is only touched by lane n % 64, so a bin's updates stay in program order;
+//       pending points are re-tested WITHOUT memory: a point that was set is erased by the walk exactly when it
+//                is one of the walked positions up to the segment's end -- integer arithmetic on registers.
+//
+// The accumulator rows are stored compactly (row n holds only the rho range an image of this size can reach:
+// 2.8 MB instead of 8.6 MB at A4, so that it stays in the XCD's L2 next to the 1.1 MB mask).
+struct alignas(16) PphtShared {
+    float4 ang[OMR_PPHT_MAX_ANGLES];     // (cos / rho, sin / rho, byte offset of the row's bin rho = 0 [bits], -)
+    PphtWalk walk[OMR_PPHT_MAX_ANGLES];  // 16 bytes each
+    uint32_t pts[1024];                  // points of an accepted segment waiting for their un-votes (y << 16 | x)
+    uint32_t r[64];                      // draw round: raw RNG outputs
+    int produced;                        // draws whose points are in order[]
+    int job_seq, job_npts, job_done;     // un-vote jobs: wave 0 -> the helper waves and back
 };
 
-// device-scope accesses: served by L2, so a wave sees what other waves did before the last barrier
-__device__ __forceinline__ bool mask_test(const unsigned long long *mask, int y, int x, int tx)
+#define PP_WG __HIP_MEMORY_SCOPE_WORKGROUP
+__device__ __forceinline__ uint32_t list_load(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, PP_WG); }
+__device__ __forceinline__ void list_store(uint32_t *p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, PP_WG); }
+
+// maximum over the 64 lanes (all active), returned uniform
+__device__ __forceinline__ int wave_max_i32(int v)
 {
-    const unsigned long long w = __hip_atomic_load(mask + mask_word(y, x, tx), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return (w >> mask_bit(y, x)) & 1ull;
-}
-__device__ __forceinline__ void mask_clear(unsigned long long *mask, int y, int x, int tx)
-{
-    // several lanes may clear bits of one word: atomic AND, no return value
-    __hip_atomic_fetch_and(mask + mask_word(y, x, tx), ~(1ull << mask_bit(y, x)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ uint32_t list_load(const uint32_t *p)
-{
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ void list_store(uint32_t *p, uint32_t v)
-{
-    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    v = max(v, __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xf, 0xf, false));   // quad_perm [1,0,3,2]
+    v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xf, 0xf, false));   // quad_perm [2,3,0,1]
+    v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x141, 0xf, 0xf, false));  // row_half_mirror
+    v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x140, 0xf, 0xf, false));  // row_mirror
+    const int a = __builtin_amdgcn_readlane(v, 0), b = __builtin_amdgcn_readlane(v, 16);
+    const int c = __builtin_amdgcn_readlane(v, 32), d = __builtin_amdgcn_readlane(v, 48);
+    return max(max(a, b), max(c, d));
 }
 
 #ifdef OMR_RUNS_DEBUG
 // debug build only: wave 0 / lane 0 phase clocks of scan 0 [draw, vote+argmax, walk pass 1, pass 2 + un-vote,
-// re-test, served points, pass-1 rounds, pass-2 rounds]; read with omr_debug_ppht_stamps()
-__device__ unsigned long long g_ppht_stamps[8];
+// re-test, served points, pass-1 rounds, pass-2 rounds, un-voted points, accepted segments, un-vote clocks, -];
+// read with omr_debug_ppht_stamps()
+__device__ unsigned long long g_ppht_stamps[12];
 #define PP_CLK(V)                                                                  \
     unsigned long long V = 0;                                                      \
-    if (tid == 0 && scan == 0) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(V)::"memory");
-#define PP_ADD(I, T0, T1) \
-    if (tid == 0 && scan == 0) g_ppht_stamps[I] += (T1) - (T0);
-#define PP_CNT(I) \
-    if (tid == 0 && scan == 0) g_ppht_stamps[I] += 1;
-hipError_t debug_ppht_stamps(unsigned long long out[8], bool reset)
+    if (lane == 0 && scan == 0) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(V)::"memory");
+#define PP_ADD(I, T0, T1) pp_acc[I] += (T1) - (T0);  // accumulated in registers, stored once at the end
+#define PP_CNT(I) pp_acc[I] += 1;
+#define PP_DECL unsigned long long pp_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#define PP_FLUSH                          \
+    if (lane == 0 && scan == 0)           \
+        for (int i_ = 0; i_ < 12; i_++) g_ppht_stamps[i_] += pp_acc[i_];
+hipError_t debug_ppht_stamps(unsigned long long out[12], bool reset)
 {
-    hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ppht_stamps), 8 * sizeof(unsigned long long));
+    hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ppht_stamps), 12 * sizeof(unsigned long long));
     if (e == hipSuccess && reset) {
-        unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        unsigned long long z[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         e = hipMemcpyToSymbol(HIP_SYMBOL(g_ppht_stamps), z, sizeof z);
     }
     return e;
@@ -351,306 +360,440 @@ hipError_t debug_ppht_stamps(unsigned long long out[8], bool reset)
 #define PP_CLK(V)
 #define PP_ADD(I, T0, T1)
 #define PP_CNT(I)
+#define PP_DECL
+#define PP_FLUSH
 #endif
+
+// ---- wave 1: the list -> the sequence of drawn points
+__device__ __forceinline__ void ppht_draw(const PphtArgs &a, PphtShared &sh, int scan, int lane)
+{
+    uint32_t *nz = a.nz + a.scan_off[scan];
+    uint32_t *order = a.order + a.scan_off[scan];
+    int count = a.count[scan], k0 = 0;
+    unsigned long long rng = ~0ull;  // cv::RNG((uint64)-1), stepped by lane 0
+    volatile uint32_t *shr = sh.r;
+    while (count > 0) {
+        const int nd = min(64, count);
+        if (lane == 0) {
+            for (int t = 0; t < nd; t++) {
+                rng = (unsigned long long)(uint32_t)rng * 4164903690u + (uint32_t)(rng >> 32);
+                shr[t] = (uint32_t)rng;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();  // same wave: LDS operations complete in order
+        const bool act = lane < nd;
+        const uint32_t c = (uint32_t)(count - lane);  // list length at this lane's draw
+        uint32_t idx = 0xffffffffu, last = 0xfffffffeu, pv = 0, qv = 0, res = 0;
+        if (act) {
+            idx = shr[lane] % c;
+            last = c - 1;
+            pv = list_load(nz + idx);
+            qv = list_load(nz + last);
+        }
+        // draw t takes the point in slot idx_t and moves the list's last point (slot c_t - 1) there: replayed in
+        // order on the registers of the lanes that hold those slots
+        for (int t = 0; t < nd; t++) {
+            const uint32_t it = (uint32_t)__builtin_amdgcn_readlane((int)idx, t);
+            const uint32_t q = (uint32_t)__builtin_amdgcn_readlane((int)qv, t);
+            if (lane == t) res = pv;
+            if (idx == it) pv = q;
+            if (last == it) qv = q;
+        }
+        if (act) {
+            list_store(nz + idx, pv);  // lanes that share a slot hold the same value; slots past the new end are dead
+            list_store(order + k0 + lane, res);
+        }
+        count -= nd;
+        k0 += nd;
+        // the stores above are complete (and the next round's loads see them) before the progress is published
+        __hip_atomic_store(&sh.produced, k0, __ATOMIC_RELEASE, PP_WG);
+    }
+}
+
+// ---- un-votes of an accepted segment: sh.pts[0 .. npts), angles n0 .. n1 - 1.  Lane = point, one angle after the
+// other: the decrements of an instruction fall into a few cache lines of one accumulator row.  A no-return atomic
+// costs a wave 70-230 cycles to issue whatever its lanes do, and a segment needs 180 x ceil(points / 64) of them, so
+// the angles are split between wave 0 and the helper waves (an accepted segment is rare -- 4 % of the served
+// points -- but its un-votes were a fifth of a scan's time on one wave).
+__device__ __forceinline__ void unvote_points(PphtShared &sh, int32_t *accum, int npts, int n0, int n1, int lane)
+{
+    for (int g = 0; g < npts; g += 64) {
+        if (g + lane < npts) {
+            const uint32_t q = sh.pts[g + lane];
+            const float fj = (float)(q & 0xffffu), fi = (float)(q >> 16);
+#pragma unroll 4
+            for (int n = n0; n < n1; n++) {
+                const float4 t = sh.ang[n];  // (cos, sin, byte offset of the row's bin 0, -): LDS broadcast
+                const uint32_t o = __float_as_uint(t.z) + 4u * (uint32_t)__float2int_rn(__fadd_rn(__fmul_rn(fj, t.x), __fmul_rn(fi, t.y)));
+                __hip_atomic_fetch_sub((int32_t *)((char *)accum + o), 1, __ATOMIC_RELAXED, PP_WG);
+            }
+        }
+    }
+}
+#define OMR_PPHT_HELPERS 3  // waves 2 .. 4
+__device__ __forceinline__ void angle_share(int numangle, int part, int &n0, int &n1)  // part 0 = wave 0
+{
+    const int per = (numangle + OMR_PPHT_HELPERS) / (OMR_PPHT_HELPERS + 1);
+    n0 = min(numangle, part * per);
+    n1 = min(numangle, n0 + per);
+}
+__device__ __forceinline__ void ppht_help(const PphtArgs &a, PphtShared &sh, int scan, int lane, int part)
+{
+    int32_t *accum = a.accum + (int64_t)scan * a.accum_stride;
+    int n0, n1;
+    angle_share(a.numangle, part, n0, n1);
+    for (int seen = 0;;) {
+        int seq;
+        while ((seq = __hip_atomic_load(&sh.job_seq, __ATOMIC_ACQUIRE, PP_WG)) == seen) __builtin_amdgcn_s_sleep(2);
+        if (seq < 0) break;  // the scan is finished
+        seen = seq;
+        unvote_points(sh, accum, sh.job_npts, n0, n1, lane);
+        // release: the decrements are performed before wave 0 reads the accumulator again
+        if (lane == 0) __hip_atomic_fetch_add(&sh.job_done, 1, __ATOMIC_RELEASE, PP_WG);
+    }
+}
+
+// ---- wave 0: votes, walks, segments.  A single wave's instruction stream is the critical path here (about five
+// cycles per instruction), so the code below counts instructions: 32-bit byte offsets from uniform bases, 24-bit
+// multiplies, no loops over set bits, no predicated loads (a load inside a divergent branch is waited for before
+// the next one is issued).
+struct PphtPos {
+    uint32_t off;  // byte offset of the mask word
+    int bit, i1, j1;
+    bool inside;
+};
+struct PphtLine {  // uniform description of the walk of one served point
+    int x0, y0, dx0, dy0, shx, shy;
+};
+__device__ __forceinline__ PphtPos walk_pos(const PphtLine &ln, int d, int t, int W, int H, int TX)
+{
+    PphtPos p;
+    p.j1 = (ln.x0 + __mul24(t, d ? -ln.dx0 : ln.dx0)) >> ln.shx;
+    p.i1 = (ln.y0 + __mul24(t, d ? -ln.dy0 : ln.dy0)) >> ln.shy;
+    p.inside = (uint32_t)p.j1 < (uint32_t)W && (uint32_t)p.i1 < (uint32_t)H;
+    p.off = (uint32_t)(__mul24(p.i1 >> 3, TX) + (p.j1 >> 3)) << 3;
+    p.bit = ((p.i1 & 7) << 3) | (p.j1 & 7);
+    return p;
+}
+__device__ __forceinline__ unsigned long long mask_at(const unsigned long long *mask, uint32_t off)
+{
+    return __hip_atomic_load((const unsigned long long *)((const char *)mask + off), __ATOMIC_RELAXED, PP_WG);
+}
+
+// The sequential gap rule of one direction over the 128 steps of a round (hough.cpp's first pass: a set point
+// resets the gap and moves the line end, every other step adds one, "++gap > lineGap" or the border ends the walk)
+// without a loop: a set point is unreachable when the run of zeros before it is longer than the gap, the walk ends
+// at the first unreachable one.  n0 / n1: set points of steps base .. +63 / +64 .. +127; o0 / o1: steps outside
+// the image.  gap, end_t, stop: the direction's state (in / out).
+__device__ __forceinline__ void gap_rule(unsigned long long n0, unsigned long long n1, unsigned long long o0, unsigned long long o1,
+                                         int base, int line_gap, int lane, int &gap, int &end_t, bool &stop)
+{
+    const int valid0 = o0 ? __ffsll((long long)o0) - 1 : 64;  // steps before the border
+    const int valid1 = valid0 < 64 ? 0 : (o1 ? __ffsll((long long)o1) - 1 : 64);
+    if (valid0 < 64) n0 &= (1ull << valid0) - 1ull;
+    if (valid1 < 64) n1 &= (1ull << valid1) - 1ull;
+    const int valid = valid0 + valid1;
+    const int top0 = n0 ? 63 - __clzll((long long)n0) : -1 - gap;  // last set step of the first half (or the state's)
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    const unsigned long long b0 = n0 & lt, b1 = n1 & lt;
+    const int z0 = b0 ? lane - (63 - __clzll((long long)b0)) - 1 : lane + gap;        // zeros before step lane
+    const int z1 = b1 ? lane - (63 - __clzll((long long)b1)) - 1 : 63 + lane - top0;  // zeros before step 64 + lane
+    const unsigned long long bad0 = __ballot(((n0 >> lane) & 1ull) && z0 > line_gap);
+    const unsigned long long bad1 = __ballot(((n1 >> lane) & 1ull) && z1 > line_gap);
+    unsigned long long k0 = n0, k1 = n1;  // the set points the walk reaches
+    bool st = false;
+    if (bad0) {
+        k0 = n0 & ((bad0 & (0ull - bad0)) - 1ull);
+        k1 = 0;
+        st = true;
+    } else if (bad1) {
+        k1 = n1 & ((bad1 & (0ull - bad1)) - 1ull);
+        st = true;
+    }
+    if (k1) end_t = base + 127 - __clzll((long long)k1);
+    else if (k0) end_t = base + 63 - __clzll((long long)k0);
+    if (!st) {
+        int g;
+        if (n1) g = valid - (127 - __clzll((long long)n1)) - 1;
+        else if (n0) g = valid - (63 - __clzll((long long)n0)) - 1;
+        else g = gap + valid;
+        gap = g;
+        st = g > line_gap || valid < 128;
+    }
+    stop = st;
+}
+
+#define OMR_PPHT_PTS 1024  // LDS list of a segment's points waiting for their un-votes
+template <int NPL>         // accumulator angles per lane
+__device__ __forceinline__ void ppht_serve(const PphtArgs &a, PphtShared &sh, int scan, int lane)
+{
+    const int W = a.width, H = a.height;
+    unsigned long long *mask = (unsigned long long *)a.mask + (int64_t)scan * (ppht_mask_bytes(H, W) / 8);
+    const int TX = ppht_tiles_x(W);
+    const uint32_t *order = a.order + a.scan_off[scan];
+    int32_t *accum = a.accum + (int64_t)scan * a.accum_stride;
+    int32_t *lines = a.lines + (int64_t)scan * a.cap * 4;
+    const int N = a.count[scan];
+    // Lanes without an angle (numangle is 180: lanes 52-63 of the third set) vote for a scratch bin of their own
+    // behind the scan's rows: no predication around the loads, stores and atomics.
+    float tc[NPL], ts[NPL];
+    uint32_t rowb[NPL];  // byte offset of the bin rho = 0 of this lane's rows
+    bool voter[NPL];
+#pragma unroll
+    for (int v = 0; v < NPL; v++) {
+        const int n = lane + 64 * v;
+        voter[v] = n < a.numangle;
+        tc[v] = voter[v] ? a.ttab[2 * n] : 0.f;
+        ts[v] = voter[v] ? a.ttab[2 * n + 1] : 0.f;
+        rowb[v] = 4u * (uint32_t)(voter[v] ? (int64_t)a.row_base[n] : a.accum_stride - 64 + lane);
+    }
+    auto bin_off = [&](int v, float fj, float fi) -> uint32_t {
+        return rowb[v] + 4u * (uint32_t)__float2int_rn(__fadd_rn(__fmul_rn(fj, tc[v]), __fmul_rn(fi, ts[v])));
+    };
+    auto bin_ptr = [&](uint32_t off) -> int32_t * { return (int32_t *)((char *)accum + off); };
+    int k0 = 0, nl = 0, jobs = 0;
+    PP_DECL
+    uint32_t pt = 0;              // this lane's drawn point of the current round
+    unsigned long long pend = 0;  // lanes whose point is still set and not served yet
+    // the bins of the point served next, read ahead while the current point walks
+    bool ahead = false;
+    int ahead_lane = 0;
+    uint32_t aoff[NPL];
+    int aval[NPL];
+#pragma unroll
+    for (int v = 0; v < NPL; v++) {
+        aoff[v] = 0;
+        aval[v] = 0;
+    }
+
+    for (;;) {
+        PP_CLK(c0)
+        while (pend == 0 && k0 < N) {  // ---- the next 64 drawn points
+            const int nd = min(64, N - k0);
+            while (__hip_atomic_load(&sh.produced, __ATOMIC_ACQUIRE, PP_WG) < k0 + nd) __builtin_amdgcn_s_sleep(1);
+            bool on = false;
+            if (lane < nd) {
+                pt = list_load(order + k0 + lane);
+                const int y = (int)(pt >> 16), x = (int)(pt & 0xffffu);
+                on = (mask_at(mask, (uint32_t)(__mul24(y >> 3, TX) + (x >> 3)) << 3) >> (((y & 7) << 3) | (x & 7))) & 1ull;
+            }
+            pend = __ballot(on);
+            k0 += nd;
+            ahead = false;
+        }
+        if (pend == 0) break;
+        const int tsel = __ffsll((long long)pend) - 1;
+        pend &= pend - 1;
+        const uint32_t p = (uint32_t)__builtin_amdgcn_readlane((int)pt, tsel);
+        const int pi = (int)(p >> 16), pj = (int)(p & 0xffffu);
+        PP_CLK(c1)
+        PP_ADD(0, c0, c1)
+        PP_CNT(5)
+        // ---- vote: r = cvRound(j * cos/rho + i * sin/rho) in float32, no contraction.  Load + store pairs, not
+        // RMW atomics: a row is only ever touched by this lane.
+        uint32_t off[NPL];
+        int val[NPL];
+        if (ahead && ahead_lane == tsel) {
+#pragma unroll
+            for (int v = 0; v < NPL; v++) {
+                off[v] = aoff[v];
+                val[v] = aval[v];
+            }
+        } else {
+            const float fj = (float)pj, fi = (float)pi;
+#pragma unroll
+            for (int v = 0; v < NPL; v++) {
+                off[v] = bin_off(v, fj, fi);
+                val[v] = __hip_atomic_load(bin_ptr(off[v]), __ATOMIC_RELAXED, PP_WG);
+            }
+        }
+        int key = (int)0x80000000;
+#pragma unroll
+        for (int v = 0; v < NPL; v++) {
+            val[v] += 1;
+            __hip_atomic_store(bin_ptr(off[v]), val[v], __ATOMIC_RELAXED, PP_WG);
+            const int k = (int)(((uint32_t)val[v] << 8) | (uint32_t)(255 - (lane + 64 * v)));
+            key = voter[v] ? max(key, k) : key;
+        }
+        // read ahead: the bins of the next pending point, after this point's stores (same lane, same address: in order)
+        ahead = pend != 0;
+        if (ahead) {
+            ahead_lane = __ffsll((long long)pend) - 1;
+            const uint32_t q = (uint32_t)__builtin_amdgcn_readlane((int)pt, ahead_lane);
+            const float fj = (float)(q & 0xffffu), fi = (float)(q >> 16);
+#pragma unroll
+            for (int v = 0; v < NPL; v++) {
+                aoff[v] = bin_off(v, fj, fi);
+                aval[v] = __hip_atomic_load(bin_ptr(aoff[v]), __ATOMIC_RELAXED, PP_WG);
+            }
+        }
+        key = wave_max_i32(key);
+        const int max_val = key >> 8, max_n = 255 - (key & 255);
+        PP_CLK(c2)
+        PP_ADD(1, c1, c2)
+        if (max_val < a.threshold) continue;  // with threshold 0 only when un-votes drove the bins negative
+
+        PphtLine ln;
+        {
+            const int4 wk = *(const int4 *)&sh.walk[max_n];  // one LDS broadcast read
+            const int xflag = __builtin_amdgcn_readfirstlane(wk.x);
+            ln.dx0 = __builtin_amdgcn_readfirstlane(wk.y);
+            ln.dy0 = __builtin_amdgcn_readfirstlane(wk.z);
+            ln.x0 = xflag ? pj : (pj << 16) + (1 << 15);
+            ln.y0 = xflag ? (pi << 16) + (1 << 15) : pi;
+            ln.shx = xflag ? 0 : 16;
+            ln.shy = xflag ? 16 : 0;
+        }
+
+        // ---- first pass: the segment's two ends.  Slot s = 2 * dir + half: steps base + 64 * half + lane.
+        int gap[2] = {0, 0}, end_t[2] = {0, 0};  // step 0 is the served point itself: non-zero
+        bool stop[2] = {false, false};
+        unsigned long long on0[4];  // round 0's flags and positions, kept for the second pass
+        PphtPos ps0[4];
+        auto walk_round = [&](int base, PphtPos (&ps)[4], unsigned long long (&bn)[4]) {
+            PP_CNT(6)
+            unsigned long long word[4], bo[4];
+#pragma unroll
+            for (int s = 0; s < 4; s++) {
+                ps[s] = walk_pos(ln, s >> 1, base + 64 * (s & 1) + lane, W, H, TX);
+                word[s] = mask_at(mask, ps[s].inside ? ps[s].off : 0u);  // (a stopped direction's reads are ignored)
+            }
+#pragma unroll
+            for (int s = 0; s < 4; s++) {
+                bn[s] = __ballot(ps[s].inside && ((word[s] >> ps[s].bit) & 1ull));
+                bo[s] = __ballot(!ps[s].inside);
+            }
+#pragma unroll
+            for (int d = 0; d < 2; d++)
+                if (!stop[d]) gap_rule(bn[2 * d], bn[2 * d + 1], bo[2 * d], bo[2 * d + 1], base, a.line_gap, lane, gap[d], end_t[d], stop[d]);
+        };
+        walk_round(0, ps0, on0);
+        for (int base = 128; !(stop[0] && stop[1]); base += 128) {
+            PphtPos ps[4];
+            unsigned long long bn[4];
+            walk_round(base, ps, bn);
+        }
+        PP_CLK(c3)
+        PP_ADD(2, c2, c3)
+        // line ends and the length test
+        int ex[2], ey[2];
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            ex[k] = (ln.x0 + end_t[k] * (k ? -ln.dx0 : ln.dx0)) >> ln.shx;
+            ey[k] = (ln.y0 + end_t[k] * (k ? -ln.dy0 : ln.dy0)) >> ln.shy;
+        }
+        const bool good = abs(ex[1] - ex[0]) >= a.line_length || abs(ey[1] - ey[0]) >= a.line_length;
+
+        // ---- second pass: erase the segment's points; un-vote them when the segment is accepted.  Round 0 uses
+        // the first pass's flags and positions (the mask has not changed since); later rounds read the mask again.
+        // The points of an accepted segment are collected in LDS and un-voted together.
+        int npts = 0;
+        auto unvote = [&]() {
+            PP_CLK(u0)
+            int n0, n1;
+            angle_share(a.numangle, 0, n0, n1);
+            sh.job_npts = npts;
+            __hip_atomic_store(&sh.job_seq, ++jobs, __ATOMIC_RELEASE, PP_WG);  // the points are in LDS before the helpers start
+            unvote_points(sh, accum, npts, n0, n1, lane);
+            while (__hip_atomic_load(&sh.job_done, __ATOMIC_ACQUIRE, PP_WG) != OMR_PPHT_HELPERS * jobs) __builtin_amdgcn_s_sleep(1);
+            PP_CLK(u1)
+            PP_ADD(10, u0, u1)
+            npts = 0;
+        };
+        auto erase_round = [&](int base, const PphtPos (&ps)[4], unsigned long long (&m)[4]) {
+            PP_CNT(7)
+#pragma unroll
+            for (int s = 0; s < 4; s++) {
+                const int d = s >> 1, lo = base + 64 * (s & 1);
+                const int cnt = end_t[d] - lo + 1;  // steps of this slot that belong to the segment
+                if (cnt <= 0) m[s] = 0;
+                else if (cnt < 64) m[s] &= (1ull << cnt) - 1ull;
+                if (d == 1 && lo == 0) m[s] &= ~1ull;  // step 0 belongs to direction 0
+                if (m[s] == 0) continue;
+                if ((m[s] >> lane) & 1ull) {
+                    // several lanes may clear bits of one word: atomic AND, no return value
+                    __hip_atomic_fetch_and((unsigned long long *)((char *)mask + ps[s].off), ~(1ull << ps[s].bit), __ATOMIC_RELAXED, PP_WG);
+                    if (good) {
+                        const int k = npts + __builtin_amdgcn_mbcnt_hi((uint32_t)(m[s] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m[s], 0));
+                        sh.pts[k] = ((uint32_t)ps[s].i1 << 16) | (uint32_t)ps[s].j1;
+                        PP_CNT(8)
+                    }
+                }
+                npts += good ? __popcll(m[s]) : 0;
+            }
+        };
+        erase_round(0, ps0, on0);
+        const int last_max = max(end_t[0], end_t[1]);
+        for (int base = 128; base <= last_max; base += 128) {
+            unsigned long long m[4], word[4];
+            PphtPos ps[4];
+#pragma unroll
+            for (int s = 0; s < 4; s++) {
+                ps[s] = walk_pos(ln, s >> 1, base + 64 * (s & 1) + lane, W, H, TX);
+                word[s] = mask_at(mask, ps[s].inside ? ps[s].off : 0u);
+            }
+#pragma unroll
+            for (int s = 0; s < 4; s++) m[s] = __ballot(ps[s].inside && ((word[s] >> ps[s].bit) & 1ull));
+            if (good && npts > OMR_PPHT_PTS - 256) unvote();
+            erase_round(base, ps, m);
+        }
+        if (good) {
+            unvote();
+            ahead = false;  // the bins read ahead may have been decremented
+            PP_CNT(9)
+            if (lane == 0 && nl < a.cap) {
+                lines[4 * nl] = ex[0];
+                lines[4 * nl + 1] = ey[0];
+                lines[4 * nl + 2] = ex[1];
+                lines[4 * nl + 3] = ey[1];
+            }
+            nl++;
+        }
+        PP_CLK(c4)
+        PP_ADD(3, c3, c4)
+        // ---- the points this wave still holds: one of them is erased exactly when it is a walked position of the
+        // segment (it was set before the walk, and the second pass clears every set position up to the ends)
+        if (pend) {
+            const int ci = (int)(pt >> 16), cj = (int)(pt & 0xffffu);
+            const int dd = ln.shx ? (ci - pi) * ln.dy0 : (cj - pj) * ln.dx0;  // along the unit axis: step = |dd|, direction = sign
+            const int d = dd < 0, t = abs(dd);
+            const PphtPos c = walk_pos(ln, d, t, W, H, TX);
+            const bool hit = t <= (d ? end_t[1] : end_t[0]) && c.j1 == cj && c.i1 == ci;
+            pend &= ~__ballot(hit);
+        }
+        PP_CLK(c6)
+        PP_ADD(4, c4, c6)
+    }
+    if (lane == 0) a.n_lines[scan] = nl;
+    __hip_atomic_store(&sh.job_seq, -1, __ATOMIC_RELEASE, PP_WG);  // the helper waves leave
+    PP_FLUSH
+}
 
 __global__ __launch_bounds__(OMR_PPHT_THREADS) void ppht_kernel(const PphtArgs a)
 {
     __shared__ PphtShared sh;
-    const int scan = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int W = a.width, H = a.height;
-    unsigned long long *mask = (unsigned long long *)a.mask + (int64_t)scan * (ppht_mask_bytes(H, W) / 8);
-    const int TX = ppht_tiles_x(W);
-    uint32_t *nz = a.nz + a.scan_off[scan];
-    int32_t *accum = a.accum + (int64_t)scan * a.numangle * a.numrho;
-    int32_t *lines = a.lines + (int64_t)scan * a.cap * 4;
-    const bool voter = tid < a.numangle;
-    float tc = 0.f, ts = 0.f;
-    if (voter) {
-        tc = a.ttab[2 * tid];
-        ts = a.ttab[2 * tid + 1];
+    const int scan = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    for (int k = tid; k < a.numangle; k += OMR_PPHT_THREADS) {
+        sh.walk[k] = a.walk[k];
+        sh.ang[k] = make_float4(a.ttab[2 * k], a.ttab[2 * k + 1], __uint_as_float(4u * (uint32_t)a.row_base[k]), 0.f);
     }
-    int32_t *row = accum + (int64_t)(voter ? tid : 0) * a.numrho + (a.numrho - 1) / 2;
-    const int dir = tid >> 7, slot = tid & 127;  // walk role
-    // wave 0 state
-    unsigned long long rng = ~0ull;  // cv::RNG((uint64)-1), stepped by lane 0
-    int count = a.count[scan];
-    uint32_t pt = 0;                 // this lane's drawn point of the current round
-    unsigned long long pend = 0;     // lanes whose point is still set and not served yet
-    int nl = 0;
-    volatile uint32_t *shr = sh.r;
-
-    for (;;) {
-        PP_CLK(c0)
-        if (wave == 0) {
-            while (pend == 0 && count > 0) {  // ---- a draw round
-                const int nd = min(64, count);
-                if (lane == 0) {
-                    for (int t = 0; t < nd; t++) {
-                        rng = (unsigned long long)(uint32_t)rng * 4164903690u + (uint32_t)(rng >> 32);
-                        shr[t] = (uint32_t)rng;
-                    }
-                }
-                __builtin_amdgcn_wave_barrier();  // same wave: LDS operations complete in order
-                const bool act = lane < nd;
-                const int c = count - lane;  // list length at this lane's draw
-                uint32_t idx = 0xffffffffu, p = 0, q = 0;
-                if (act) {
-                    idx = shr[lane] % (uint32_t)c;
-                    p = list_load(nz + idx);
-                    q = list_load(nz + (c - 1));
-                }
-                // draw s writes slot idx_s; a later draw t reads slots idx_t and c_t - 1
-                bool conf = false;
-                for (int s = 0; s + 1 < nd; s++) {
-                    const uint32_t is = (uint32_t)__builtin_amdgcn_readlane((int)idx, s);
-                    conf |= act && lane > s && (idx == is || (uint32_t)(c - 1) == is);
-                }
-                if (__ballot(conf)) {  // rare: replay the round in order
-                    if (lane == 0) {
-                        int cc = count;
-                        for (int t = 0; t < nd; t++) {
-                            const uint32_t ix = shr[t] % (uint32_t)cc;
-                            const uint32_t pp = list_load(nz + ix);
-                            list_store(nz + ix, list_load(nz + (cc - 1)));
-                            cc--;
-                            shr[t] = pp;
-                        }
-                    }
-                    __builtin_amdgcn_wave_barrier();
-                    p = act ? shr[lane] : 0;
-                } else if (act) {
-                    list_store(nz + idx, q);
-                }
-                count -= nd;
-                pt = p;
-                const bool on = act && mask_test(mask, (int)(p >> 16), (int)(p & 0xffffu), TX);
-                pend = __ballot(on);
-            }
-            int pi = -1, pj = -1;
-            if (pend) {
-                const int t = __ffsll((long long)pend) - 1;
-                pend &= pend - 1;
-                const uint32_t p = (uint32_t)__builtin_amdgcn_readlane((int)pt, t);
-                pi = (int)(p >> 16);
-                pj = (int)(p & 0xffffu);
-            }
-            if (lane == 0) {
-                sh.i = pi;
-                sh.j = pj;
-                sh.stop[0] = sh.stop[1] = 0;
-                sh.gap[0] = sh.gap[1] = 0;
-                sh.end_t[0] = sh.end_t[1] = 0;  // step 0 is the served point itself: non-zero
-            }
-        }
-        __syncthreads();
-        const int pi = sh.i, pj = sh.j;
-        if (pi < 0) break;
-        PP_CLK(c1)
-        PP_ADD(0, c0, c1)
-        PP_CNT(5)
-        // ---- vote: r = cvRound(j * cos/rho + i * sin/rho) in float32, no contraction
-        long long key = (long long)0x8000000000000000ull;
-        if (voter) {
-            const float fr = __fadd_rn(__fmul_rn((float)pj, tc), __fmul_rn((float)pi, ts));
-            // a plain load + store pair, not an RMW atomic: the row belongs to this lane alone, and L2
-            // keeps far more load misses in flight than atomic misses
-            int32_t *bin = row + __float2int_rn(fr);
-            const int val = __hip_atomic_load(bin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
-            __hip_atomic_store(bin, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            // larger value first, then the LOWER angle ("if (max_val < val)" keeps the first maximum)
-            key = ((long long)val << 32) | (long long)(uint32_t)(0x7fffffff - tid);
-        }
-        for (int off = 32; off > 0; off >>= 1) {
-            const long long o = __shfl_down(key, off);
-            key = o > key ? o : key;
-        }
-        if (lane == 0) sh.key[wave] = (unsigned long long)key;
-        __syncthreads();
-        long long best = (long long)sh.key[0];
-        for (int w = 1; w < 4; w++)
-            if ((long long)sh.key[w] > best) best = (long long)sh.key[w];
-        const int max_val = (int)(best >> 32);
-        const int max_n = 0x7fffffff - (int)(uint32_t)(best & 0xffffffffll);
-        PP_CLK(c2)
-        PP_ADD(1, c1, c2)
-        if (max_val >= a.threshold) {  // with threshold 0 false only when un-votes drove the bins negative
-            const PphtWalk wk = a.walk[max_n];
-            int x0 = pj, y0 = pi;
-            if (wk.xflag) y0 = (y0 << 16) + (1 << 15);
-            else x0 = (x0 << 16) + (1 << 15);
-            const int dx = dir ? -wk.dx0 : wk.dx0, dy = dir ? -wk.dy0 : wk.dy0;
-
-            // ---- first pass: the segment's two ends, both directions side by side
-            bool on0 = false;  // this thread's position of round 0 holds a point
-            for (int base = 0;; base += 128) {
-                PP_CNT(6)
-                const bool live = !sh.stop[dir];
-                bool out = false, on = false;
-                if (live) {
-                    const int t = base + slot;
-                    const int x = x0 + t * dx, y = y0 + t * dy;
-                    const int j1 = wk.xflag ? x : x >> 16, i1 = wk.xflag ? y >> 16 : y;
-                    out = j1 < 0 || j1 >= W || i1 < 0 || i1 >= H;
-                    on = !out && mask_test(mask, i1, j1, TX);
-                }
-                if (base == 0) on0 = on;
-                const unsigned long long bn = __ballot(on), bo = __ballot(out);
-                if (lane == 0) {
-                    sh.nzb[wave] = bn;
-                    sh.oob[wave] = bo;
-                }
-                __syncthreads();
-                if (slot == 0 && live) {  // threads 0 and 128: the sequential gap rule over this round
-                    int gap = sh.gap[dir], end_t = sh.end_t[dir], stop = 0;
-                    for (int w = 0; w < 2 && !stop; w++) {
-                        unsigned long long n = sh.nzb[2 * dir + w];
-                        const unsigned long long o = sh.oob[2 * dir + w];
-                        const int valid = o ? __ffsll((long long)o) - 1 : 64;  // steps before the border
-                        if (valid < 64) n &= (1ull << valid) - 1ull;
-                        int prev = -1;
-                        while (n) {
-                            const int q = __ffsll((long long)n) - 1;
-                            n &= n - 1;
-                            if (gap + (q - prev - 1) > a.line_gap) {
-                                stop = 1;
-                                break;
-                            }
-                            gap = 0;
-                            end_t = base + w * 64 + q;
-                            prev = q;
-                        }
-                        if (!stop) {
-                            gap += valid - prev - 1;
-                            if (gap > a.line_gap || valid < 64) stop = 1;
-                        }
-                    }
-                    sh.gap[dir] = gap;
-                    sh.end_t[dir] = end_t;
-                    sh.stop[dir] = stop;
-                }
-                __syncthreads();
-                if (sh.stop[0] && sh.stop[1]) break;
-            }
-            PP_CLK(c3)
-            PP_ADD(2, c2, c3)
-            // line ends and the length test
-            int ex[2], ey[2];
-            for (int k = 0; k < 2; k++) {
-                const int t = sh.end_t[k];
-                const int kx = k ? -wk.dx0 : wk.dx0, ky = k ? -wk.dy0 : wk.dy0;
-                const int x = x0 + t * kx, y = y0 + t * ky;
-                ex[k] = wk.xflag ? x : x >> 16;
-                ey[k] = wk.xflag ? y >> 16 : y;
-            }
-            const bool good = abs(ex[1] - ex[0]) >= a.line_length || abs(ey[1] - ey[0]) >= a.line_length;
-
-            // ---- second pass: erase the segment's points; un-vote them when the segment is accepted.
-            // Round 0 reuses the first pass's flags (the mask has not changed since).
-            const int last = sh.end_t[dir], last_max = max(sh.end_t[0], sh.end_t[1]);
-            for (int base = 0; base <= last_max; base += 128) {
-                PP_CNT(7)
-                const int t = base + slot;
-                bool on = false;
-                uint32_t ptw = 0;
-                if (t <= last && !(dir == 1 && t == 0)) {  // step 0 belongs to direction 0
-                    const int x = x0 + t * dx, y = y0 + t * dy;
-                    const int j1 = wk.xflag ? x : x >> 16, i1 = wk.xflag ? y >> 16 : y;
-                    on = base == 0 ? on0 : mask_test(mask, i1, j1, TX);
-                    if (on) {
-                        ptw = ((uint32_t)i1 << 16) | (uint32_t)j1;
-                        mask_clear(mask, i1, j1, TX);
-                    }
-                }
-                if (good) {  // block-uniform
-                    const unsigned long long bn = __ballot(on);
-                    if (lane == 0) sh.nzb[wave] = bn;
-                    __syncthreads();
-                    int before = __popcll(bn & ((1ull << lane) - 1ull)), np = 0;
-                    for (int w = 0; w < 4; w++) {
-                        const int c = __popcll(sh.nzb[w]);
-                        if (w < wave) before += c;
-                        np += c;
-                    }
-                    if (on) sh.pts[before] = (int)ptw;
-                    __syncthreads();
-                    if (voter) {
-                        // Un-vote as load / store pairs (the row is this lane's alone), eight points at
-                        // a time with all loads in flight together; points of a chunk that share a bin
-                        // are merged first (the last one carries the sum), chunks follow each other in
-                        // program order (same lane, same address: L2 keeps the order).
-                        {
-                            const int q1 = np;
-                            for (int qb = 0; qb < q1; qb += 8) {
-                                int bin[8], c[8], v[8];
-#pragma unroll
-                                for (int i = 0; i < 8; i++) {
-                                    const int q = qb + i;
-                                    bin[i] = -0x40000000 + i;  // distinct sentinels
-                                    c[i] = 0;
-                                    if (q < q1) {
-                                        const uint32_t p = (uint32_t)sh.pts[q];
-                                        bin[i] = __float2int_rn(__fadd_rn(__fmul_rn((float)(p & 0xffffu), tc),
-                                                                          __fmul_rn((float)(p >> 16), ts)));
-                                        c[i] = 1;
-                                    }
-                                }
-#pragma unroll
-                                for (int i = 1; i < 8; i++)
-#pragma unroll
-                                    for (int j = 0; j < i; j++)
-                                        if (bin[i] == bin[j]) {
-                                            c[i] += c[j];
-                                            c[j] = 0;
-                                        }
-                                if (a.latency_mode) {
-                                    // a single scan that is waited for: fire-and-forget RMW atomics -- nothing in this
-                                    // lane waits for the bins' old values (the load + store pairs below expose one
-                                    // memory round trip per chunk of eight points)
-#pragma unroll
-                                    for (int i = 0; i < 8; i++)
-                                        if (c[i]) __hip_atomic_fetch_sub(row + bin[i], c[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                                } else {
-#pragma unroll
-                                    for (int i = 0; i < 8; i++)
-                                        if (c[i]) v[i] = __hip_atomic_load(row + bin[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-                                    for (int i = 0; i < 8; i++)
-                                        if (c[i])
-                                            __hip_atomic_store(row + bin[i], v[i] - c[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                                }
-                            }
-                        }
-                    }
-                }
-            }
-            PP_CLK(c4)
-            PP_ADD(3, c3, c4)
-            if (tid == 0 && good) {
-                if (nl < a.cap) {
-                    lines[4 * nl] = ex[0];
-                    lines[4 * nl + 1] = ey[0];
-                    lines[4 * nl + 2] = ex[1];
-                    lines[4 * nl + 3] = ey[1];
-                }
-                nl++;
-            }
-        }
-        PP_CLK(c5)
-        __syncthreads();  // erasures are complete: wave 0 re-tests the points it still holds
-        if (wave == 0 && pend) {
-            const bool on = ((pend >> lane) & 1ull) && mask_test(mask, (int)(pt >> 16), (int)(pt & 0xffffu), TX);
-            pend = __ballot(on);
-        }
-        PP_CLK(c6)
-        PP_ADD(4, c5, c6)
+    if (tid == 0) {
+        sh.produced = 0;
+        sh.job_seq = 0;
+        sh.job_done = 0;
     }
-    if (tid == 0) a.n_lines[scan] = nl;
+    __syncthreads();  // the only workgroup barrier: from here on the waves run on their own
+    const int wave = tid >> 6;
+    if (wave == 1) ppht_draw(a, sh, scan, lane);
+    else if (wave >= 2) ppht_help(a, sh, scan, lane, wave - 1);
+    else if (a.numangle <= 192) ppht_serve<3>(a, sh, scan, lane);
+    else ppht_serve<4>(a, sh, scan, lane);
 }
 
 hipError_t launch_ppht(const PphtArgs &a, int n, hipStream_t s)
 {
     if (n <= 0) return hipSuccess;
-    if (a.numangle > OMR_PPHT_THREADS) return hipErrorInvalidValue;
+    if (a.numangle > OMR_PPHT_MAX_ANGLES) return hipErrorInvalidValue;
     hipLaunchKernelGGL(ppht_kernel, dim3(n), dim3(OMR_PPHT_THREADS), 0, s, a);
     return hipGetLastError();
 }

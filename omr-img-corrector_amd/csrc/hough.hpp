@@ -37,22 +37,25 @@ struct PphtArgs {
     uint8_t *mask;            // n x ppht_mask_bytes(): 64-bit words of 8x8 pixels, bit set = point still available
     int32_t width, height;
     uint32_t *nz;             // point lists (destroyed)
-    const int64_t *scan_off;  // [n] offset of a scan's list in nz
+    uint32_t *order;          // same size and offsets as nz: the points in the order they are drawn (written by the kernel)
+    const int64_t *scan_off;  // [n] offset of a scan's list in nz / order
     const int32_t *count;     // [n] points per scan
-    int32_t *accum;           // n x numangle x numrho, zeroed
-    int32_t numangle, numrho;
+    int32_t *accum;           // n x accum_stride, zeroed; row k of a scan starts at row_base[k] - (its lowest rho)
+    int64_t accum_stride;
+    const int32_t *row_base;  // numangle: offset of the bin rho = 0 of row k (rows hold only the reachable rho range)
+    int32_t numangle;
     const float *ttab;        // numangle x (cos / rho, sin / rho) as float
     const PphtWalk *walk;     // numangle
     int32_t threshold, line_length, line_gap;
     int32_t *lines;           // n x cap x 4
     int32_t cap;
     int32_t *n_lines;         // [n]
-    int32_t latency_mode;     // 1: few scans, waited for (un-votes as no-return atomics); 0: batch throughput
 };
-#define OMR_PPHT_THREADS 256  // lane = accumulator angle; numangle <= 256
+#define OMR_PPHT_THREADS 320      // wave 0 serves the points, wave 1 draws them, waves 2-4 help with the un-votes
+#define OMR_PPHT_MAX_ANGLES 256   // up to four accumulator angles per lane
 hipError_t launch_ppht(const PphtArgs &a, int n, hipStream_t s);
 #ifdef OMR_RUNS_DEBUG
-hipError_t debug_ppht_stamps(unsigned long long out[8], bool reset);
+hipError_t debug_ppht_stamps(unsigned long long out[12], bool reset);
 #endif
 
 // counts[i] = #{ j : |a[i] - a[j]| < 0.1 } in f32 (hough.rs:77-83) or in f64 on widened values

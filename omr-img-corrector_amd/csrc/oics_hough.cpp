@@ -86,8 +86,7 @@ int ppht_device(uint8_t *d_edges, int32_t *d_rowcnt, int rows, int cols, int n, 
     const float rho = (float)hp.rho, theta = (float)hp.theta, irho = 1.0f / rho;
     if (!(rho > 0) || !(theta > 0)) return fail(OMR_ERR_BADARG, "rho and theta must be positive");
     const int numangle = cv_round(3.1415926535897932384626433832795 / theta);
-    const int numrho = cv_round((float)((cols + rows) * 2 + 1) / rho);
-    if (numangle <= 0 || numangle > OMR_PPHT_THREADS)
+    if (numangle <= 0 || numangle > OMR_PPHT_MAX_ANGLES)
         return fail(OMR_ERR_NOTIMPL, "HoughLinesP: %d accumulator angles (theta too small; the reference uses pi/180)",
                     numangle);
     std::vector<float> ttab((size_t)numangle * 2);
@@ -108,7 +107,20 @@ int ppht_device(uint8_t *d_edges, int32_t *d_rowcnt, int rows, int cols, int n, 
         }
         walk[k] = w;
     }
-    DevBuf rowoff, total, scanoff, nz, d_ttab, d_walk, accum, lines, nlines, tiled;
+    // OpenCV's accumulator has (cols + rows) * 2 + 1 bins per angle; a pixel of a cols x rows image only reaches
+    // rho = cvRound(x cos + y sin) in [lo_k, hi_k], so row k keeps just that range (+-2 for the float rounding)
+    std::vector<int32_t> row_base((size_t)numangle);
+    int64_t accum_stride = 0;
+    for (int k = 0; k < numangle; k++) {
+        const double c = ttab[2 * k], sn = ttab[2 * k + 1];
+        const double lo = (cols - 1) * std::min(c, 0.0) + (rows - 1) * std::min(sn, 0.0);
+        const double hi = (cols - 1) * std::max(c, 0.0) + (rows - 1) * std::max(sn, 0.0);
+        const int64_t rmin = (int64_t)floor(lo) - 2, rmax = (int64_t)ceil(hi) + 2;
+        row_base[k] = (int32_t)(accum_stride - rmin);
+        accum_stride += rmax - rmin + 1;
+    }
+    accum_stride += 64;  // scratch bins of the lanes that hold no angle
+    DevBuf rowoff, total, scanoff, nz, order, d_ttab, d_walk, d_rowbase, accum, lines, nlines, tiled;
     OMR_HIP(rowoff.alloc(sizeof(int32_t) * (size_t)n * rows));
     OMR_HIP(total.alloc(sizeof(int32_t) * (size_t)n));
     OMR_HIP(launch_edges_rowscan(d_rowcnt, rows, n, rowoff.as<int32_t>(), total.as<int32_t>(), s));
@@ -126,6 +138,7 @@ int ppht_device(uint8_t *d_edges, int32_t *d_rowcnt, int rows, int cols, int n, 
     const int cap = std::max(1, std::min(maxc, 1 << 16));
     OMR_HIP(scanoff.alloc(sizeof(int64_t) * (size_t)n));
     OMR_HIP(nz.alloc(sizeof(uint32_t) * (size_t)std::max<int64_t>(sum, 1)));
+    OMR_HIP(order.alloc(sizeof(uint32_t) * (size_t)std::max<int64_t>(sum, 1)));
     OMR_HIP(hipMemcpyAsync(scanoff.p, off.data(), sizeof(int64_t) * (size_t)n, hipMemcpyHostToDevice, s));
     OMR_HIP(tiled.alloc((size_t)n * (size_t)ppht_mask_bytes(rows, cols)));
     OMR_HIP(hipMemsetAsync(tiled.p, 0, tiled.bytes, s));
@@ -135,7 +148,9 @@ int ppht_device(uint8_t *d_edges, int32_t *d_rowcnt, int rows, int cols, int n, 
     OMR_HIP(d_walk.alloc(sizeof(PphtWalk) * walk.size()));
     OMR_HIP(hipMemcpyAsync(d_ttab.p, ttab.data(), sizeof(float) * ttab.size(), hipMemcpyHostToDevice, s));
     OMR_HIP(hipMemcpyAsync(d_walk.p, walk.data(), sizeof(PphtWalk) * walk.size(), hipMemcpyHostToDevice, s));
-    OMR_HIP(accum.alloc(sizeof(int32_t) * (size_t)n * numangle * numrho));
+    OMR_HIP(d_rowbase.alloc(sizeof(int32_t) * row_base.size()));
+    OMR_HIP(hipMemcpyAsync(d_rowbase.p, row_base.data(), sizeof(int32_t) * row_base.size(), hipMemcpyHostToDevice, s));
+    OMR_HIP(accum.alloc(sizeof(int32_t) * (size_t)n * (size_t)accum_stride));
     OMR_HIP(hipMemsetAsync(accum.p, 0, accum.bytes, s));
     OMR_HIP(lines.alloc(sizeof(int32_t) * 4 * (size_t)n * cap));
     OMR_HIP(nlines.alloc(sizeof(int32_t) * (size_t)n));
@@ -144,11 +159,13 @@ int ppht_device(uint8_t *d_edges, int32_t *d_rowcnt, int rows, int cols, int n, 
     a.width = cols;
     a.height = rows;
     a.nz = nz.as<uint32_t>();
+    a.order = order.as<uint32_t>();
     a.scan_off = scanoff.as<int64_t>();
     a.count = total.as<int32_t>();
     a.accum = accum.as<int32_t>();
+    a.accum_stride = accum_stride;
+    a.row_base = d_rowbase.as<int32_t>();
     a.numangle = numangle;
-    a.numrho = numrho;
     a.ttab = d_ttab.as<float>();
     a.walk = d_walk.as<PphtWalk>();
     a.threshold = hp.threshold;
@@ -157,7 +174,6 @@ int ppht_device(uint8_t *d_edges, int32_t *d_rowcnt, int rows, int cols, int n, 
     a.lines = lines.as<int32_t>();
     a.cap = cap;
     a.n_lines = nlines.as<int32_t>();
-    a.latency_mode = n <= 4 ? 1 : 0;  // up to four scans cannot fill the chip anyway: favour their latency
     OMR_HIP(launch_ppht(a, n, s));
     std::vector<int32_t> nl((size_t)n);
     OMR_HIP(hipMemcpyAsync(nl.data(), nlines.p, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, s));
@@ -539,9 +555,9 @@ int omr_correct_default(const omr_image *src, uint16_t projection_max_angle, dou
 }  // extern "C"
 
 #ifdef OMR_RUNS_DEBUG
-extern "C" int omr_debug_ppht_stamps(unsigned long long *out8, int reset)
+extern "C" int omr_debug_ppht_stamps(unsigned long long *out12, int reset)
 {
-    OMR_HIP(omr::debug_ppht_stamps(out8, reset != 0));
+    OMR_HIP(omr::debug_ppht_stamps(out12, reset != 0));
     return OMR_OK;
 }
 #endif
