@@ -343,7 +343,8 @@ __device__ unsigned long long g_ppht_stamps[12];
     if (lane == 0 && scan == 0) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(V)::"memory");
 #define PP_ADD(I, T0, T1) pp_acc[I] += (T1) - (T0);  // accumulated in registers, stored once at the end
 #define PP_CNT(I) pp_acc[I] += 1;
-#define PP_DECL unsigned long long pp_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#define PP_DECL unsigned long long pp_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; \
+    auto pp_unvoted = [&](int n_) { pp_acc[8] += n_; };
 #define PP_FLUSH                          \
     if (lane == 0 && scan == 0)           \
         for (int i_ = 0; i_ < 12; i_++) g_ppht_stamps[i_] += pp_acc[i_];
@@ -360,7 +361,7 @@ hipError_t debug_ppht_stamps(unsigned long long out[12], bool reset)
 #define PP_CLK(V)
 #define PP_ADD(I, T0, T1)
 #define PP_CNT(I)
-#define PP_DECL
+#define PP_DECL auto pp_unvoted = [](int) {};
 #define PP_FLUSH
 #endif
 
@@ -498,8 +499,8 @@ __device__ __forceinline__ void gap_rule(unsigned long long n0, unsigned long lo
     const unsigned long long b0 = n0 & lt, b1 = n1 & lt;
     const int z0 = b0 ? lane - (63 - __clzll((long long)b0)) - 1 : lane + gap;        // zeros before step lane
     const int z1 = b1 ? lane - (63 - __clzll((long long)b1)) - 1 : 63 + lane - top0;  // zeros before step 64 + lane
-    const unsigned long long bad0 = __ballot(((n0 >> lane) & 1ull) && z0 > line_gap);
-    const unsigned long long bad1 = __ballot(((n1 >> lane) & 1ull) && z1 > line_gap);
+    const unsigned long long bad0 = __builtin_amdgcn_ballot_w64(((n0 >> lane) & 1ull) && z0 > line_gap);
+    const unsigned long long bad1 = __builtin_amdgcn_ballot_w64(((n1 >> lane) & 1ull) && z1 > line_gap);
     unsigned long long k0 = n0, k1 = n1;  // the set points the walk reaches
     bool st = false;
     if (bad0) {
@@ -521,6 +522,31 @@ __device__ __forceinline__ void gap_rule(unsigned long long n0, unsigned long lo
         st = g > line_gap || valid < 128;
     }
     stop = st;
+}
+
+// The same rule for lineGap < 64 (the reference passes 50), an order of magnitude fewer instructions: a step ends
+// the walk ("++gap > lineGap") exactly when none of the lineGap + 1 steps up to and including it holds a point --
+// one shift of the ballots per lane.  Steps outside the image never hold a point and a line that has left the image
+// does not come back, so the border needs no masks: the walk stops in this round whenever a step is outside.
+__device__ __forceinline__ void gap_rule_short(unsigned long long n0, unsigned long long n1, unsigned long long o0, unsigned long long o1,
+                                               int base, int line_gap, int lane, int &gap, int &end_t, bool &stop)
+{
+    const int up = 63 - lane, down = 63 - line_gap;
+    const unsigned long long w0 = (n0 << up) >> down;                             // steps lane - lineGap .. lane
+    const unsigned long long w1 = ((n1 << up) | ((n0 >> 1) >> lane)) >> down;     // steps 64 + lane - lineGap .. 64 + lane
+    const unsigned long long brk0 = __builtin_amdgcn_ballot_w64(w0 == 0 && lane + gap >= line_gap);  // (the state's last point: lane + 1 + gap steps back)
+    const unsigned long long brk1 = __builtin_amdgcn_ballot_w64(w1 == 0);
+    unsigned long long k0 = n0, k1 = n1;  // the points the walk reaches
+    if (brk0) {
+        k0 &= (brk0 & (0ull - brk0)) - 1ull;
+        k1 = 0;
+    } else if (brk1) {
+        k1 &= (brk1 & (0ull - brk1)) - 1ull;
+    }
+    if (k1) end_t = base + 127 - __clzll((long long)k1);
+    else if (k0) end_t = base + 63 - __clzll((long long)k0);
+    stop = (brk0 | brk1 | o0 | o1) != 0;
+    gap = n1 ? __clzll((long long)n1) : n0 ? 64 + __clzll((long long)n0) : gap + 128;  // only read when the walk goes on
 }
 
 #define OMR_PPHT_PTS 1024  // LDS list of a segment's points waiting for their un-votes
@@ -577,7 +603,7 @@ __device__ __forceinline__ void ppht_serve(const PphtArgs &a, PphtShared &sh, in
                 const int y = (int)(pt >> 16), x = (int)(pt & 0xffffu);
                 on = (mask_at(mask, (uint32_t)(__mul24(y >> 3, TX) + (x >> 3)) << 3) >> (((y & 7) << 3) | (x & 7))) & 1ull;
             }
-            pend = __ballot(on);
+            pend = __builtin_amdgcn_ballot_w64(on);
             k0 += nd;
             ahead = false;
         }
@@ -660,14 +686,20 @@ __device__ __forceinline__ void ppht_serve(const PphtArgs &a, PphtShared &sh, in
             }
 #pragma unroll
             for (int s = 0; s < 4; s++) {
-                bn[s] = __ballot(ps[s].inside && ((word[s] >> ps[s].bit) & 1ull));
-                bo[s] = __ballot(!ps[s].inside);
+                bn[s] = __builtin_amdgcn_ballot_w64(ps[s].inside && ((word[s] >> ps[s].bit) & 1ull));
+                bo[s] = __builtin_amdgcn_ballot_w64(!ps[s].inside);
             }
 #pragma unroll
             for (int d = 0; d < 2; d++)
-                if (!stop[d]) gap_rule(bn[2 * d], bn[2 * d + 1], bo[2 * d], bo[2 * d + 1], base, a.line_gap, lane, gap[d], end_t[d], stop[d]);
+                if (!stop[d]) {
+                    if ((uint32_t)a.line_gap < 64u) gap_rule_short(bn[2 * d], bn[2 * d + 1], bo[2 * d], bo[2 * d + 1], base, a.line_gap, lane, gap[d], end_t[d], stop[d]);
+                    else gap_rule(bn[2 * d], bn[2 * d + 1], bo[2 * d], bo[2 * d + 1], base, a.line_gap, lane, gap[d], end_t[d], stop[d]);
+                }
         };
         walk_round(0, ps0, on0);
+#ifdef OMR_RUNS_DEBUG
+        if ((end_t[0] + a.line_gap + 1 < 64) && (end_t[1] + a.line_gap + 1 < 64)) PP_CNT(11)
+#endif
         for (int base = 128; !(stop[0] && stop[1]); base += 128) {
             PphtPos ps[4];
             unsigned long long bn[4];
@@ -690,6 +722,7 @@ __device__ __forceinline__ void ppht_serve(const PphtArgs &a, PphtShared &sh, in
         int npts = 0;
         auto unvote = [&]() {
             PP_CLK(u0)
+            pp_unvoted(npts);
             int n0, n1;
             angle_share(a.numangle, 0, n0, n1);
             sh.job_npts = npts;
@@ -705,21 +738,18 @@ __device__ __forceinline__ void ppht_serve(const PphtArgs &a, PphtShared &sh, in
 #pragma unroll
             for (int s = 0; s < 4; s++) {
                 const int d = s >> 1, lo = base + 64 * (s & 1);
-                const int cnt = end_t[d] - lo + 1;  // steps of this slot that belong to the segment
-                if (cnt <= 0) m[s] = 0;
-                else if (cnt < 64) m[s] &= (1ull << cnt) - 1ull;
-                if (d == 1 && lo == 0) m[s] &= ~1ull;  // step 0 belongs to direction 0
-                if (m[s] == 0) continue;
+                const int cnt = min(64, end_t[d] - lo + 1);  // steps of this slot that belong to the segment
+                unsigned long long keep = cnt <= 0 ? 0ull : cnt >= 64 ? ~0ull : (1ull << cnt) - 1ull;
+                if (d == 1 && lo == 0) keep &= ~1ull;  // step 0 belongs to direction 0
+                m[s] &= keep;
                 if ((m[s] >> lane) & 1ull) {
                     // several lanes may clear bits of one word: atomic AND, no return value
                     __hip_atomic_fetch_and((unsigned long long *)((char *)mask + ps[s].off), ~(1ull << ps[s].bit), __ATOMIC_RELAXED, PP_WG);
-                    if (good) {
-                        const int k = npts + __builtin_amdgcn_mbcnt_hi((uint32_t)(m[s] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m[s], 0));
-                        sh.pts[k] = ((uint32_t)ps[s].i1 << 16) | (uint32_t)ps[s].j1;
-                        PP_CNT(8)
-                    }
+                    // (the list is only read when the segment is accepted)
+                    const int k = npts + __builtin_amdgcn_mbcnt_hi((uint32_t)(m[s] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m[s], 0));
+                    sh.pts[k] = ((uint32_t)ps[s].i1 << 16) | (uint32_t)ps[s].j1;
                 }
-                npts += good ? __popcll(m[s]) : 0;
+                npts += __popcll(m[s]);
             }
         };
         erase_round(0, ps0, on0);
@@ -733,8 +763,11 @@ __device__ __forceinline__ void ppht_serve(const PphtArgs &a, PphtShared &sh, in
                 word[s] = mask_at(mask, ps[s].inside ? ps[s].off : 0u);
             }
 #pragma unroll
-            for (int s = 0; s < 4; s++) m[s] = __ballot(ps[s].inside && ((word[s] >> ps[s].bit) & 1ull));
-            if (good && npts > OMR_PPHT_PTS - 256) unvote();
+            for (int s = 0; s < 4; s++) m[s] = __builtin_amdgcn_ballot_w64(ps[s].inside && ((word[s] >> ps[s].bit) & 1ull));
+            if (npts > OMR_PPHT_PTS - 256) {
+                if (good) unvote();
+                npts = 0;
+            }
             erase_round(base, ps, m);
         }
         if (good) {
@@ -759,7 +792,7 @@ __device__ __forceinline__ void ppht_serve(const PphtArgs &a, PphtShared &sh, in
             const int d = dd < 0, t = abs(dd);
             const PphtPos c = walk_pos(ln, d, t, W, H, TX);
             const bool hit = t <= (d ? end_t[1] : end_t[0]) && c.j1 == cj && c.i1 == ci;
-            pend &= ~__ballot(hit);
+            pend &= ~__builtin_amdgcn_ballot_w64(hit);
         }
         PP_CLK(c6)
         PP_ADD(4, c4, c6)

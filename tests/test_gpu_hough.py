@@ -43,7 +43,9 @@ def test_canny_threshold_order_and_flat_image(oracle):
 
 @pytest.mark.parametrize("rows,cols,seed,mll,mlg", [(64, 48, 3, 10, 2), (230, 248, 4, 20, 5), (230, 248, 4, 150, 50),
                                                    (512, 512, 1, 150, 50), (512, 512, 2, 100, 15),
-                                                   (700, 300, 5, 60, 200), (1754, 1240, 8, 150, 50)])
+                                                   (700, 300, 5, 60, 200), (1754, 1240, 8, 150, 50),
+                                                   (512, 512, 1, 100, 63), (512, 512, 1, 100, 64), (300, 300, 7, 30, 0),
+                                                   (600, 900, 9, 120, 127), (600, 900, 9, 120, 128)])
 def test_hough_lines_p_matches_oracle(oracle, rows, cols, seed, mll, mlg):
     img, _ = card(rows, cols, seed)
     edges = oracle.canny(img)

@@ -25,3 +25,4 @@ for i, nm in enumerate(names):
 print("  served points %d, pass-1 rounds %d (%.2f per point), pass-2 rounds %d" % (out[5], out[6], out[6] / max(1, out[5]), out[7]))
 print("  accepted segments %d, un-voted points %d, un-vote clocks %.1f Mcycles (part of pass 2)" % (out[9], out[8], out[10] / 1e6))
 print("  cycles per served point %.0f" % (tot / max(1, out[5])))
+print("  walks that end within 64 steps in both directions: %d" % out[11])
