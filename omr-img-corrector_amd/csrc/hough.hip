@@ -4,9 +4,9 @@
 // hysteresis result is a set (the candidates 8-connected to a strong pixel), so the order of
 // propagation does not matter.  HoughLinesP is a *sequential* randomised algorithm (hough.cpp
 // HoughLinesProbabilistic: every drawn point sees the accumulator and the mask left by all points
-// before it), so the kernel keeps the sequence and parallelises inside a step -- one workgroup per
-// scan, lane = accumulator angle for the 180 votes, lane = position for the line walks -- and
-// across scans (one workgroup each; a batch fills the chip).  Same RNG (cv::RNG seed 2^64-1), same
+// before it), so the kernel keeps the sequence, shortens the step (one serving wave per scan: lane =
+// accumulator angle for the 180 votes, lane = position for the line walks; a second wave draws ahead,
+// three more help with un-votes) and runs scans side by side (one workgroup each).  Same RNG (cv::RNG seed 2^64-1), same
 // float32 vote arithmetic (no contraction), same 16.16 walk: the segments are bit-identical to the
 // CPU restatement.
 //
