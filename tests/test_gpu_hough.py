@@ -1,6 +1,8 @@
 """Parity of the Hough-line deskew path through the C ABI against the CPU
 oracle: Canny edges byte for byte, HoughLinesP segments integer for integer and in the same order,
 angles / status / candidates bit for bit; correct_default's decision and its rotated image."""
+import os
+import sys
 import numpy as np
 import pytest
 
@@ -215,3 +217,14 @@ def test_hough_lines_p_other_resolutions(oracle, theta_div, rho):
         exp = oracle.hough_lines_p(edges, 30, 5, rho=rho, theta=np.pi / theta_div, threshold=thr)
         got = hough.hough_lines_p(edges, rho, np.pi / theta_div, thr, 30, 5)
         assert got.shape == exp.shape and (got == exp).all()
+
+
+def test_hough_lines_p_random_cases(oracle, monkeypatch):
+    """Random shapes, densities and parameters (tools/fuzz_hough.py: point counts around the 64-point draw rounds,
+    dense rows / columns, gaps on both sides of the 64-step rule, other rho / theta): segments equal the oracle's."""
+    import runpy
+    tool = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "fuzz_hough.py")
+    monkeypatch.setattr(sys, "argv", [tool, "80", "11"])
+    with pytest.raises(SystemExit) as e:
+        runpy.run_path(tool, run_name="__main__")
+    assert e.value.code == 0
