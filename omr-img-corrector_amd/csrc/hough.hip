@@ -461,7 +461,8 @@ __device__ __forceinline__ void ppht_help(const PphtArgs &a, PphtShared &sh, int
 struct PphtPos {
     uint32_t off;  // byte offset of the mask word
     int bit, i1, j1;
-    bool inside;
+    bool inx, iny;  // column / row inside the image (kept apart: a ballot of ONE compare is the compare's own lane mask,
+                    // a ballot of "a && b" is re-materialised through a VGPR)
 };
 struct PphtLine {  // uniform description of the walk of one served point
     int x0, y0, dx0, dy0, shx, shy;
@@ -471,7 +472,8 @@ __device__ __forceinline__ PphtPos walk_pos(const PphtLine &ln, int d, int t, in
     PphtPos p;
     p.j1 = (ln.x0 + __mul24(t, d ? -ln.dx0 : ln.dx0)) >> ln.shx;
     p.i1 = (ln.y0 + __mul24(t, d ? -ln.dy0 : ln.dy0)) >> ln.shy;
-    p.inside = (uint32_t)p.j1 < (uint32_t)W && (uint32_t)p.i1 < (uint32_t)H;
+    p.inx = (uint32_t)p.j1 < (uint32_t)W;
+    p.iny = (uint32_t)p.i1 < (uint32_t)H;
     p.off = (uint32_t)(__mul24(p.i1 >> 3, TX) + (p.j1 >> 3)) << 3;
     p.bit = ((p.i1 & 7) << 3) | (p.j1 & 7);
     return p;
@@ -534,7 +536,10 @@ __device__ __forceinline__ void gap_rule_short(unsigned long long n0, unsigned l
     const int up = 63 - lane, down = 63 - line_gap;
     const unsigned long long w0 = (n0 << up) >> down;                             // steps lane - lineGap .. lane
     const unsigned long long w1 = ((n1 << up) | ((n0 >> 1) >> lane)) >> down;     // steps 64 + lane - lineGap .. 64 + lane
-    const unsigned long long brk0 = __builtin_amdgcn_ballot_w64(w0 == 0 && lane + gap >= line_gap);  // (the state's last point: lane + 1 + gap steps back)
+    // the state's last point lies lane + 1 + gap steps back: it covers the steps lane < lineGap - gap
+    const int first = line_gap - gap;
+    const unsigned long long uncovered = first <= 0 ? ~0ull : first >= 64 ? 0ull : ~0ull << first;
+    const unsigned long long brk0 = __builtin_amdgcn_ballot_w64(w0 == 0) & uncovered;
     const unsigned long long brk1 = __builtin_amdgcn_ballot_w64(w1 == 0);
     unsigned long long k0 = n0, k1 = n1;  // the points the walk reaches
     if (brk0) {
@@ -682,12 +687,13 @@ __device__ __forceinline__ void ppht_serve(const PphtArgs &a, PphtShared &sh, in
 #pragma unroll
             for (int s = 0; s < 4; s++) {
                 ps[s] = walk_pos(ln, s >> 1, base + 64 * (s & 1) + lane, W, H, TX);
-                word[s] = mask_at(mask, ps[s].inside ? ps[s].off : 0u);  // (a stopped direction's reads are ignored)
+                word[s] = mask_at(mask, (ps[s].inx && ps[s].iny) ? ps[s].off : 0u);  // (a stopped direction's reads are ignored)
             }
 #pragma unroll
-            for (int s = 0; s < 4; s++) {
-                bn[s] = __builtin_amdgcn_ballot_w64(ps[s].inside && ((word[s] >> ps[s].bit) & 1ull));
-                bo[s] = __builtin_amdgcn_ballot_w64(!ps[s].inside);
+            for (int s = 0; s < 4; s++) {  // (all 64 lanes are active here)
+                const unsigned long long in = __builtin_amdgcn_ballot_w64(ps[s].inx) & __builtin_amdgcn_ballot_w64(ps[s].iny);
+                bn[s] = __builtin_amdgcn_ballot_w64((word[s] & (1ull << ps[s].bit)) != 0) & in;
+                bo[s] = ~in;
             }
 #pragma unroll
             for (int d = 0; d < 2; d++)
@@ -742,6 +748,7 @@ __device__ __forceinline__ void ppht_serve(const PphtArgs &a, PphtShared &sh, in
                 unsigned long long keep = cnt <= 0 ? 0ull : cnt >= 64 ? ~0ull : (1ull << cnt) - 1ull;
                 if (d == 1 && lo == 0) keep &= ~1ull;  // step 0 belongs to direction 0
                 m[s] &= keep;
+                if (m[s] == 0) continue;  // (uniform: most rounds touch one or two of the four slots)
                 if ((m[s] >> lane) & 1ull) {
                     // several lanes may clear bits of one word: atomic AND, no return value
                     __hip_atomic_fetch_and((unsigned long long *)((char *)mask + ps[s].off), ~(1ull << ps[s].bit), __ATOMIC_RELAXED, PP_WG);
@@ -760,10 +767,12 @@ __device__ __forceinline__ void ppht_serve(const PphtArgs &a, PphtShared &sh, in
 #pragma unroll
             for (int s = 0; s < 4; s++) {
                 ps[s] = walk_pos(ln, s >> 1, base + 64 * (s & 1) + lane, W, H, TX);
-                word[s] = mask_at(mask, ps[s].inside ? ps[s].off : 0u);
+                word[s] = mask_at(mask, (ps[s].inx && ps[s].iny) ? ps[s].off : 0u);
             }
 #pragma unroll
-            for (int s = 0; s < 4; s++) m[s] = __builtin_amdgcn_ballot_w64(ps[s].inside && ((word[s] >> ps[s].bit) & 1ull));
+            for (int s = 0; s < 4; s++)
+                m[s] = __builtin_amdgcn_ballot_w64((word[s] & (1ull << ps[s].bit)) != 0) & __builtin_amdgcn_ballot_w64(ps[s].inx) &
+                       __builtin_amdgcn_ballot_w64(ps[s].iny);
             if (npts > OMR_PPHT_PTS - 256) {
                 if (good) unvote();
                 npts = 0;

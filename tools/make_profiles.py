@@ -145,6 +145,12 @@ with open(os.path.join(dst, tag + "_hough.md"), "w") as f:
     j = last_json(read("hough.log"))
     if j:
         f.write("`python3 tools/bench_hough.py 256 8 2`:\n\n```\n%s\n```\n\n" % json.dumps(j, indent=1))
+    j1 = last_json(read("hough_single.log"))
+    if j1:
+        f.write("One resident A4 scan, Canny + HoughLinesP + vote, best of 5 (`python3 tools/hough_run.py 1 1 5`): **%.4f s**\n\n" % j1["seconds"])
+    ml = "\n".join(l for l in read("mem_latency.log").splitlines() if "amdgpu.ids" not in l)
+    if ml:
+        f.write("What one dependent memory round trip costs a lone wave (`tools/mem_latency.hip`, shader cycles):\n\n```\n%s\n```\n\n" % ml)
     f.write("Phase clocks of one scan's sequential stage (debug library, tools/hstamps.py):\n\n```\n%s%s```\n\n" % (
         read("hstamps_a4.log").replace("/opt/amdgpu/share/libdrm/amdgpu.ids: No such file or directory\n", ""),
         read("hstamps_half.log").replace("/opt/amdgpu/share/libdrm/amdgpu.ids: No such file or directory\n", "")))

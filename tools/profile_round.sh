@@ -31,6 +31,7 @@ timeout -k 10 300 python3 tools/bench_stages.py 30 > "$OUT/stages.log" 2>&1 || t
 timeout -k 10 300 python3 tools/bench_fft.py > "$OUT/fft.log" 2>&1 || true
 timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/fft_stats" -- python3 tools/bench_fft.py > "$OUT/fft_stats.log" 2>&1 || true
 timeout -k 10 600 python3 tools/bench_hough.py 256 8 2 > "$OUT/hough.log" 2>&1 || true
+timeout -k 10 300 python3 tools/hough_run.py 1 1 5 > "$OUT/hough_single.log" 2>&1 || true
 timeout -k 10 300 python3 tools/hstamps.py > "$OUT/hstamps_a4.log" 2>&1 || true
 timeout -k 10 300 python3 tools/hstamps.py 1754 1240 > "$OUT/hstamps_half.log" 2>&1 || true
 timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/hough_stats" -- python3 tools/hough_run.py 64 4 1 > "$OUT/hough_stats.log" 2>&1 || true
@@ -41,7 +42,7 @@ echo "[profile] stages / fft / hough done"
 timeout -k 10 300 python3 tools/bench_calls.py > "$OUT/calls.log" 2>&1 || true
 timeout -k 10 300 python3 tools/bench_host.py > "$OUT/host.log" 2>&1 || true
 # 5. micro-benchmarks behind DESIGN.md's issue-cost / LDS statements
-for t in valu_issue valu_ops lds_unaligned lds_bytes; do
+for t in valu_issue valu_ops lds_unaligned lds_bytes mem_latency; do
   hipcc -O2 --offload-arch=gfx950 tools/$t.hip -o /tmp/$t > "$OUT/$t.build.log" 2>&1 && timeout -k 10 200 /tmp/$t > "$OUT/$t.log" 2>&1 || true
 done
 echo "[profile] all done"
