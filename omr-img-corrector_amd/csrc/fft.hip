@@ -159,10 +159,12 @@ __global__ __launch_bounds__(FFT_THREADS) void fft_pass_kernel(FftPass p)
     // sector must meet in one XCD's L2.  Workgroups go round-robin to the 8 XCDs, so XCD x takes the
     // lines [x * lines / 8, (x + 1) * lines / 8) in order instead of every eighth line.
     int64_t line = blockIdx.x;
-    if (p.elem_stride > 1) {
-        const int per = p.lines / 8, body = per * 8;
+    if (p.xcd_blocked) {
+        const int per = gridDim.x / 8, body = per * 8;
         if ((int)blockIdx.x < body) line = (int64_t)(blockIdx.x % 8) * per + blockIdx.x / 8;
     }
+    const int64_t dls = p.dst_line_stride ? p.dst_line_stride : p.line_stride;
+    const int64_t des = p.dst_elem_stride ? p.dst_elem_stride : p.elem_stride;
     const bool blue = p.chirp != nullptr;
     const bool pairs = p.real_pairs != 0;
     const bool second = pairs && 2 * line + 1 < p.src_rows;
@@ -185,7 +187,7 @@ __global__ __launch_bounds__(FFT_THREADS) void fft_pass_kernel(FftPass p)
     if (inplace) fft_inplace_lds(A, m, p.log2m, p.Wfull, tid);
     else P = fft_forward_lds(A, B, m, p.log2m, p.W, tid);
     cfloat *Q = P == A ? B : A;
-    cfloat *dst = p.dst + line * p.line_stride;
+    cfloat *dst = p.dst + line * dls;
     // spectrum-picture mode (column pass): point k of this line is F(k, line); it lands at the quadrant-swapped
     // position of the |F| image
     const bool mag_mode = p.mag_dst != nullptr;
@@ -195,14 +197,14 @@ __global__ __launch_bounds__(FFT_THREADS) void fft_pass_kernel(FftPass p)
     float lo = __builtin_inff(), hi = -__builtin_inff();
     auto emit = [&](int k, cfloat v) {
         if (!mag_mode) {
-            dst[(int64_t)k * p.elem_stride] = v;
+            dst[(int64_t)k * des] = v;
             return;
         }
         // only points inside the four quadrants move; an odd last row / column keeps its place (fft.rs:69-74)
         const bool inq = sc < 2 * cxh && k < 2 * cyh;
         const int orow = inq ? (k < cyh ? k + cyh : k - cyh) : k, oc = inq ? sc_sw : sc;
         const float mg = sqrtf(v.x * v.x + v.y * v.y);
-        p.mag_dst[(int64_t)orow * p.mag_pitch + oc] = mg;
+        p.mag_dst[(int64_t)oc * p.mag_pitch + orow] = mg;
         if (p.half_mirror) {  // the conjugate-symmetric point of a real image's spectrum
             const int mc = sc == 0 ? 0 : p.img_cols - sc;
             if (mc != sc) {
@@ -210,7 +212,7 @@ __global__ __launch_bounds__(FFT_THREADS) void fft_pass_kernel(FftPass p)
                 const bool minq = mc < 2 * cxh && mk < 2 * cyh;
                 const int mrow = minq ? (mk < cyh ? mk + cyh : mk - cyh) : mk;
                 const int mcol = minq ? (mc < cxh ? mc + cxh : mc - cxh) : mc;
-                p.mag_dst[(int64_t)mrow * p.mag_pitch + mcol] = mg;
+                p.mag_dst[(int64_t)mcol * p.mag_pitch + mrow] = mg;
             }
         }
         lo = fminf(lo, mg);
@@ -240,11 +242,11 @@ __global__ __launch_bounds__(FFT_THREADS) void fft_pass_kernel(FftPass p)
     };
     // two real rows per workgroup: split Z = FFT(a + i b) into FFT(a) and FFT(b), columns 0 .. n / 2
     auto emit_pair = [&](const cfloat *Z) {
-        cfloat *d0 = p.dst + line * p.line_stride, *d1 = d0 + p.line_stride;
+        cfloat *d0 = p.dst + line * dls, *d1 = d0 + dls;
         for (int k = tid; k <= n / 2; k += FFT_THREADS) {
             const cfloat zk = Z[FPAD(k)], zn = Z[FPAD(k == 0 ? 0 : n - k)];
-            d0[k] = cfloat{(0.5f * (zk.x + zn.x)) * p.out_scale, (0.5f * (zk.y - zn.y)) * p.out_scale};
-            if (second) d1[k] = cfloat{(0.5f * (zk.y + zn.y)) * p.out_scale, (-0.5f * (zk.x - zn.x)) * p.out_scale};
+            d0[(int64_t)k * des] = cfloat{(0.5f * (zk.x + zn.x)) * p.out_scale, (0.5f * (zk.y - zn.y)) * p.out_scale};
+            if (second) d1[(int64_t)k * des] = cfloat{(0.5f * (zk.y + zn.y)) * p.out_scale, (-0.5f * (zk.x - zn.x)) * p.out_scale};
         }
     };
     if (!blue) {
@@ -387,11 +389,14 @@ __device__ __forceinline__ float spec_m3(float mg, float beta, float alpha)
 }
 __device__ __forceinline__ float spec_log(float m3) { return logf(m3 * 1.0f + (float)(1.0 / 255.0)); }
 
-__global__ __launch_bounds__(256) void spec_pictures_kernel(const float *__restrict__ mag, int rows, int cols, int mag_pitch,
+// magT: |F| transposed (cols lines of mag_pitch floats).  A workgroup turns a tile of 64 columns x 64 rows through LDS
+// (reads run along a transposed line = down a picture column, writes along picture rows) into both pictures.
+__global__ __launch_bounds__(256) void spec_pictures_kernel(const float *__restrict__ magT, int rows, int cols, int mag_pitch,
                                                             const uint32_t *__restrict__ mm, uint8_t *__restrict__ mag_u8,
                                                             uint8_t *__restrict__ log_u8, int64_t mag_scan_stride)
 {
-    mag += (int64_t)blockIdx.z * mag_scan_stride;
+    __shared__ float tile[64][65];
+    magT += (int64_t)blockIdx.z * mag_scan_stride;
     mm += 4 * blockIdx.z;
     if (mag_u8) mag_u8 += (int64_t)blockIdx.z * rows * cols;
     if (log_u8) log_u8 += (int64_t)blockIdx.z * rows * cols;
@@ -400,30 +405,41 @@ __global__ __launch_bounds__(256) void spec_pictures_kernel(const float *__restr
     // extrema of the log picture = the log picture of the extrema (monotone float steps)
     const double lmn = (double)spec_log(spec_m3((float)mn, beta, alpha)), lmx = (double)spec_log(spec_m3((float)mx, beta, alpha));
     const float beta2 = (float)(-lmn), alpha2 = (float)(1.0 / (lmx - lmn));
-    const int r = blockIdx.y;
-    const int c0 = (blockIdx.x * 256 + threadIdx.x) * 4;
-    if (c0 >= cols) return;
-    const float *M = mag + (int64_t)r * mag_pitch + c0;
-    uint32_t om = 0, ol = 0;
+    const int c0 = blockIdx.x * 64, r0 = blockIdx.y * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-        if (c0 + j < cols) {
-            const float m3 = spec_m3(M[j], beta, alpha);
-            const float u = rintf(m3 * 255.0f + 0.0f);  // convert_to(CV_8UC1, 255)
-            om |= (uint32_t)fminf(fmaxf(u, 0.f), 255.f) << (8 * j);
-            const float l = spec_log(m3);
-            const float v = rintf(((l * 1.0f + beta2) * alpha2 + 0.0f) * 255.0f + 0.0f);
-            ol |= (uint32_t)fminf(fmaxf(v, 0.f), 255.f) << (8 * j);
-        }
+    for (int i = 0; i < 16; i++) {
+        const int c = c0 + ty + 4 * i, r = r0 + tx;
+        tile[ty + 4 * i][tx] = (c < cols && r < rows) ? magT[(int64_t)c * mag_pitch + r] : 0.f;
     }
-    const int64_t o = (int64_t)r * cols + c0;
-    if (c0 + 4 <= cols && (o & 3) == 0) {
-        if (mag_u8) *(uint32_t *)(mag_u8 + o) = om;
-        if (log_u8) *(uint32_t *)(log_u8 + o) = ol;
-    } else {
-        for (int j = 0; j < 4 && c0 + j < cols; j++) {
-            if (mag_u8) mag_u8[o + j] = (uint8_t)(om >> (8 * j));
-            if (log_u8) log_u8[o + j] = (uint8_t)(ol >> (8 * j));
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const int item = threadIdx.x + 256 * q;
+        const int rl = item >> 4, cl = (item & 15) * 4;
+        const int r = r0 + rl, cc = c0 + cl;
+        if (r >= rows || cc >= cols) continue;
+        uint32_t om = 0, ol = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            if (cc + j < cols) {
+                const float m3 = spec_m3(tile[cl + j][rl], beta, alpha);
+                const float u = rintf(m3 * 255.0f + 0.0f);  // convert_to(CV_8UC1, 255)
+                om |= (uint32_t)fminf(fmaxf(u, 0.f), 255.f) << (8 * j);
+                const float l = spec_log(m3);
+                const float v = rintf(((l * 1.0f + beta2) * alpha2 + 0.0f) * 255.0f + 0.0f);
+                ol |= (uint32_t)fminf(fmaxf(v, 0.f), 255.f) << (8 * j);
+            }
+        }
+        const int64_t o = (int64_t)r * cols + cc;
+        if (cc + 4 <= cols && (o & 3) == 0) {
+            if (mag_u8) *(uint32_t *)(mag_u8 + o) = om;
+            if (log_u8) *(uint32_t *)(log_u8 + o) = ol;
+        } else {
+            for (int j = 0; j < 4 && cc + j < cols; j++) {
+                if (mag_u8) mag_u8[o + j] = (uint8_t)(om >> (8 * j));
+                if (log_u8) log_u8[o + j] = (uint8_t)(ol >> (8 * j));
+            }
         }
     }
 }
@@ -431,7 +447,7 @@ __global__ __launch_bounds__(256) void spec_pictures_kernel(const float *__restr
 hipError_t launch_spec_pictures(const float *d_mag, int rows, int cols, int mag_pitch, const uint32_t *d_minmax,
                                 uint8_t *d_mag_u8, uint8_t *d_log_u8, hipStream_t s, int scans, int64_t mag_scan_stride)
 {
-    hipLaunchKernelGGL(spec_pictures_kernel, dim3((cols + 1023) / 1024, rows, scans), dim3(256), 0, s, d_mag, rows, cols,
+    hipLaunchKernelGGL(spec_pictures_kernel, dim3((cols + 63) / 64, (rows + 63) / 64, scans), dim3(256), 0, s, d_mag, rows, cols,
                        mag_pitch, d_minmax, d_mag_u8, d_log_u8, mag_scan_stride);
     return hipGetLastError();
 }

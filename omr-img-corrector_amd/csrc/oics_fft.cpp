@@ -119,10 +119,11 @@ struct AxisTables {
 
 // workspace + tables for scans of one shape
 struct FftWork {
-    int rows = 0, cols = 0, pitch = 0;  // pitch: elements per row of the complex arrays (cols + 8: a column's
-                                        // points then spread over the memory channels instead of aliasing)
+    int rows = 0, cols = 0, pitch = 0;  // pitch: elements per line of the TRANSPOSED half spectrum (cols / 2 + 1 lines of
+                                        // rows + 8 elements: the row pass's stores of one column index then spread over
+                                        // the memory channels instead of aliasing)
     AxisTables ax_cols, ax_rows;  // transforms along a row (length cols) / along a column (length rows)
-    int mag_pitch = 0;  // floats per row of |F| (cols + 16: same reason, 4-byte elements)
+    int mag_pitch = 0;  // floats per line of the transposed |F| (cols lines of rows + 16)
     DevBuf c0, mag, mm, part;
     int group = 1;  // scans carried by one launch of each kernel (every per-scan array holds that many)
     int create(int r, int c, hipStream_t s, int scans_per_launch = 1)
@@ -133,10 +134,10 @@ struct FftWork {
         int rc;
         if ((rc = ax_cols.build(c, s))) return rc;
         if ((rc = ax_rows.build(r, s))) return rc;
-        pitch = c + 8;  // measured at 4096^2: +8 2184 scans/s, +32 (a 256-byte multiple) 1754, unpadded 1780
-        mag_pitch = c + 16;
-        OMR_HIP(c0.alloc(sizeof(cfloat) * (size_t)r * pitch * group));
-        OMR_HIP(mag.alloc(sizeof(float) * (size_t)r * mag_pitch * group));
+        pitch = r + 8;
+        mag_pitch = r + 16;
+        OMR_HIP(c0.alloc(sizeof(cfloat) * (size_t)(c / 2 + 1) * pitch * group));
+        OMR_HIP(mag.alloc(sizeof(float) * (size_t)c * mag_pitch * group));
         OMR_HIP(mm.alloc(sizeof(uint32_t) * 4 * group));
         OMR_HIP(part.alloc(sizeof(float) * 2 * (size_t)c * group));
         return OMR_OK;
@@ -150,8 +151,8 @@ struct FftWork {
         FftPass p{};
         p.scans = scans;
         p.src_u8_scan_stride = scan_stride;
-        p.c_scan_stride = (int64_t)rows * pitch;
-        // along rows: u8 * (1 / 255) -> complex spectrum lines
+        p.c_scan_stride = (int64_t)(cols / 2 + 1) * pitch;
+        // along rows: u8 * (1 / 255) -> complex spectrum lines, stored transposed (column index major)
         p.src_u8 = d_gray;
         p.src_step = step;
         p.in_scale = (float)(1.0 / 255.0);  // convert_to(CV_32F, 1.0 / 255.0): alpha cast to float
@@ -165,16 +166,19 @@ struct FftWork {
         p.chirp = ax_cols.blue ? ax_cols.chirp.as<cfloat>() : nullptr;
         p.Bf = ax_cols.blue ? ax_cols.Bf.as<cfloat>() : nullptr;
         p.out_scale = 1.0f;
-        p.line_stride = pitch;
+        p.line_stride = pitch;  // (unused: the input is the 8-bit scan)
         p.elem_stride = 1;
+        p.dst_line_stride = 1;  // row r, column index k -> c0[k * pitch + r]
+        p.dst_elem_stride = pitch;
+        p.xcd_blocked = 1;      // neighbouring rows' 16-byte pieces of a line meet in one XCD's L2
         p.real_pairs = 1;  // two real rows per workgroup, columns 0 .. cols / 2 written
         p.src_rows = rows;
         OMR_HIP(launch_fft_pass(p, s));
-        // along columns, in place in the row-major array (strided lines, see fft_pass_kernel), with DFT_SCALE
+        // along columns = along the lines of the transposed array, with DFT_SCALE
         FftPass q{};
         q.scans = scans;
-        q.c_scan_stride = (int64_t)rows * pitch;
-        q.mag_scan_stride = (int64_t)rows * mag_pitch;
+        q.c_scan_stride = (int64_t)(cols / 2 + 1) * pitch;
+        q.mag_scan_stride = (int64_t)cols * mag_pitch;
         q.part_scan_stride = 2 * (int64_t)cols;
         q.src_c = c0.as<cfloat>();
         q.dst = nullptr;  // spectrum-picture mode: |F|, quadrant-swapped, straight from the column pass
@@ -183,8 +187,8 @@ struct FftWork {
         q.img_rows = rows;
         q.img_cols = cols;
         q.part = part.as<float>();
-        q.line_stride = 1;
-        q.elem_stride = pitch;
+        q.line_stride = pitch;
+        q.elem_stride = 1;
         q.n = rows;
         q.m = ax_rows.m;
         q.log2m = ax_rows.log2m;
@@ -198,7 +202,7 @@ struct FftWork {
         OMR_HIP(launch_fft_pass(q, s));
         OMR_HIP(launch_minmax_final(part.as<float>(), cols / 2 + 1, mm.as<uint32_t>(), s, scans, 2 * (int64_t)cols));
         OMR_HIP(launch_spec_pictures(mag.as<float>(), rows, cols, mag_pitch, mm.as<uint32_t>(), d_mag_u8, d_log_u8, s, scans,
-                                     (int64_t)rows * mag_pitch));
+                                     (int64_t)cols * mag_pitch));
         return OMR_OK;
     }
 };
