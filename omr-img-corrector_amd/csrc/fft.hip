@@ -22,7 +22,7 @@ __device__ __forceinline__ cfloat cmul(const cfloat a, const cfloat b)
     return cfloat{a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x};
 }
 
-#define FFT_THREADS 512
+#define FFT_THREADS NT  // threads of the workgroup: template parameter of the kernel and its device functions
 // LDS lines are skewed by one element every 32: the Stockham stores of the first stages go to addresses
 // 8 j + q (stride 64 bytes between lanes: a 16-way bank conflict on ds_write_b64 without the skew).
 #define FPAD(i) ((i) + ((i) >> 5))
@@ -36,6 +36,7 @@ __device__ __forceinline__ cfloat cadd(const cfloat a, const cfloat b) { return 
 __device__ __forceinline__ cfloat csub(const cfloat a, const cfloat b) { return cfloat{a.x - b.x, a.y - b.y}; }
 __device__ __forceinline__ cfloat cmul_mi(const cfloat a) { return cfloat{a.y, -a.x}; }  // a * (-i)
 
+template <int NT>
 __device__ cfloat *fft_forward_lds(cfloat *in, cfloat *out, const int m, const int log2m,
                                    const cfloat *__restrict__ Wst, const int tid)
 {
@@ -123,6 +124,7 @@ __device__ cfloat *fft_forward_lds(cfloat *in, cfloat *out, const int m, const i
 
 // In-place forward FFT for lengths whose two ping-pong buffers would not fit LDS (m = 16384): radix-2
 // decimation in time on BIT-REVERSED input, natural-order output.  Wf: m / 2 twiddles exp(-2 pi i t / m).
+template <int NT>
 __device__ void fft_inplace_lds(cfloat *buf, const int m, const int log2m, const cfloat *__restrict__ Wf, const int tid)
 {
     for (int s = 0; s < log2m; s++) {
@@ -140,7 +142,8 @@ __device__ void fft_inplace_lds(cfloat *buf, const int m, const int log2m, const
     __syncthreads();
 }
 
-__global__ __launch_bounds__(FFT_THREADS) void fft_pass_kernel(FftPass p)
+template <int NT>
+__global__ __launch_bounds__(NT) void fft_pass_kernel(FftPass p)
 {
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
     {  // scan of the launch
@@ -184,8 +187,8 @@ __global__ __launch_bounds__(FFT_THREADS) void fft_pass_kernel(FftPass p)
         A[FPAD(at)] = v;
     }
     cfloat *P = A;
-    if (inplace) fft_inplace_lds(A, m, p.log2m, p.Wfull, tid);
-    else P = fft_forward_lds(A, B, m, p.log2m, p.W, tid);
+    if (inplace) fft_inplace_lds<NT>(A, m, p.log2m, p.Wfull, tid);
+    else P = fft_forward_lds<NT>(A, B, m, p.log2m, p.W, tid);
     cfloat *Q = P == A ? B : A;
     cfloat *dst = p.dst + line * dls;
     // spectrum-picture mode (column pass): point k of this line is F(k, line); it lands at the quadrant-swapped
@@ -274,9 +277,9 @@ __global__ __launch_bounds__(FFT_THREADS) void fft_pass_kernel(FftPass p)
                 P[FPAD(r)] = t;
             }
         }
-        fft_inplace_lds(P, m, p.log2m, p.Wfull, tid);
+        fft_inplace_lds<NT>(P, m, p.log2m, p.Wfull, tid);
     } else {
-        R = fft_forward_lds(P, Q, m, p.log2m, p.W, tid);
+        R = fft_forward_lds<NT>(P, Q, m, p.log2m, p.W, tid);
     }
     const float inv_m = 1.0f / (float)m;
     if (pairs) {  // the line's spectrum must be complete in LDS before the two rows can be separated
@@ -299,10 +302,17 @@ hipError_t launch_fft_pass(const FftPass &p, hipStream_t s)
     if (p.m > OMR_FFT_MAX_M || (1 << p.log2m) != p.m) return hipErrorInvalidValue;
     const size_t lds = (p.m > OMR_FFT_MAX_PINGPONG ? 1 : 2) * sizeof(cfloat) * (size_t)FFT_LDS_ELEMS(p.m);
     if (p.m > OMR_FFT_MAX_PINGPONG && !p.Wfull) return hipErrorInvalidValue;
-    hipError_t e = hipFuncSetAttribute((const void *)fft_pass_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(fft_pass_kernel, dim3(p.real_pairs ? (p.lines + 1) / 2 : p.lines, p.scans > 0 ? p.scans : 1),
-                       dim3(FFT_THREADS), lds, s, p);
+    // 8192-point transforms hold the CU alone (132 KB of LDS): 1024 threads (4 waves per SIMD) instead of 512
+    const dim3 grid(p.real_pairs ? (p.lines + 1) / 2 : p.lines, p.scans > 0 ? p.scans : 1);
+    if (p.m > 4096) {
+        hipError_t e = hipFuncSetAttribute((const void *)fft_pass_kernel<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(fft_pass_kernel<1024>, grid, dim3(1024), lds, s, p);
+    } else {
+        hipError_t e = hipFuncSetAttribute((const void *)fft_pass_kernel<512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(fft_pass_kernel<512>, grid, dim3(512), lds, s, p);
+    }
     return hipGetLastError();
 }
 
