@@ -11,6 +11,10 @@
 // applies the reference's vote.  No CPU fallback: without a HIP device every entry point returns -217.
 #include <math.h>
 #include <stdlib.h>
+
+#include <map>
+#include <mutex>
+#include <utility>
 #include <string.h>
 
 #include <algorithm>
@@ -53,18 +57,46 @@ void fft_host(std::vector<cd> &a)  // iterative radix-2, in place, forward
     }
 }
 
+// forward DFT of length R * 2^a (R odd, small) by decimation in time over the R residue classes
+void dft_host(std::vector<cd> &a)
+{
+    const size_t n = a.size();
+    size_t T = n;
+    while (T % 2 == 0) T /= 2;
+    const size_t R = T;  // odd part
+    if (R == 1) {
+        fft_host(a);
+        return;
+    }
+    T = n / R;
+    std::vector<std::vector<cd>> sub(R, std::vector<cd>(T));
+    for (size_t r = 0; r < R; r++) {
+        for (size_t t = 0; t < T; t++) sub[r][t] = a[t * R + r];
+        fft_host(sub[r]);
+    }
+    for (size_t k = 0; k < n; k++) {
+        cd acc(0, 0);
+        for (size_t r = 0; r < R; r++) {
+            const double ang = -2.0 * kPi * (double)((r * k) % n) / (double)n;
+            acc += sub[r][k % T] * cd(cos(ang), sin(ang));
+        }
+        a[k] = acc;
+    }
+}
+
 // device tables of one axis length
 struct AxisTables {
-    int n = 0, m = 0, log2m = 0;
+    int n = 0, m = 0, log2m = 0, odd = 1;  // m = odd << log2m
     bool blue = false;
     DevBuf W, Wfull, chirp, Bf;
     int build(int len, hipStream_t s)
     {
         n = len;
         blue = (n & (n - 1)) != 0;
+        const int need = blue ? 2 * n - 1 : n;
         m = 1;
         log2m = 0;
-        const int need = blue ? 2 * n - 1 : n;
+        odd = 1;
         while (m < need) {
             m <<= 1;
             log2m++;
@@ -72,11 +104,34 @@ struct AxisTables {
         if (m > OMR_FFT_MAX_M)
             return fail(OMR_ERR_NOTIMPL, "DFT length %d needs a transform of %d points; the kernel holds at most %d in LDS", n,
                         m, OMR_FFT_MAX_M);
+        if (blue && m <= OMR_FFT_MAX_PINGPONG) {
+            // Bluestein's length is free above 2n - 1: 3 * 2^a or 5 * 2^a when that is less work than the power of two
+            // (stage units per point: a / 3 radix-8 stages, + 0.7 for the radix-3 and + 1.0 for the radix-5 stage)
+            double best = (double)m * (log2m / 3.0);
+            for (int r = 3; r <= 5; r += 2)
+                for (int a = 6; (r << a) <= OMR_FFT_MAX_PINGPONG; a++)
+                    if ((r << a) >= need) {
+                        const double cost = (double)(r << a) * (a / 3.0 + (r == 3 ? 0.7 : 1.0));
+                        if (cost < best) {
+                            best = cost;
+                            m = r << a;
+                            log2m = a;
+                            odd = r;
+                        }
+                        break;
+                    }
+        }
         // twiddles of the radix-8 stages, one contiguous table per stage (Ns = Ns0, 8 Ns0, ... < m)
         std::vector<cfloat> w;
-        for (int Ns = 1 << (log2m % 3); Ns < m; Ns *= 8)
+        const int pow2 = 1 << log2m;
+        for (int Ns = 1 << (log2m % 3); Ns < pow2; Ns *= 8)
             for (int k = 0; k < Ns; k++) {
                 const double ang = -2.0 * kPi * (double)k / (8.0 * (double)Ns);
+                w.push_back(cfloat{(float)cos(ang), (float)sin(ang)});
+            }
+        if (odd > 1)  // the odd radix' stage (the last one, Ns = 2^log2m): exp(-2 pi i j / m)
+            for (int j = 0; j < pow2; j++) {
+                const double ang = -2.0 * kPi * (double)j / (double)m;
                 w.push_back(cfloat{(float)cos(ang), (float)sin(ang)});
             }
         if (w.empty()) w.push_back(cfloat{1.f, 0.f});
@@ -101,7 +156,7 @@ struct AxisTables {
             std::vector<cd> b((size_t)m, cd(0, 0));
             b[0] = std::conj(c[0]);
             for (int k = 1; k < n; k++) b[k] = b[m - k] = std::conj(c[k]);
-            fft_host(b);
+            dft_host(b);
             std::vector<cfloat> cf((size_t)n), bf((size_t)m);
             for (int k = 0; k < n; k++) cf[k] = cfloat{(float)c[k].real(), (float)c[k].imag()};
             for (int k = 0; k < m; k++) bf[k] = cfloat{(float)b[k].real(), (float)b[k].imag()};
@@ -117,12 +172,36 @@ struct AxisTables {
     }
 };
 
+// The tables of an axis length depend on nothing else: built once per (device, length) and kept for the life of the
+// process (a few hundred KB each), so that a call pays for them only the first time.
+const AxisTables *axis_tables(int len, hipStream_t s, int *rc)
+{
+    static std::mutex mu;
+    static std::map<std::pair<int, int>, AxisTables *> *cache = new std::map<std::pair<int, int>, AxisTables *>();
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = cache->find({dev, len});
+    if (it != cache->end()) {
+        *rc = OMR_OK;
+        return it->second;
+    }
+    AxisTables *t = new AxisTables();
+    *rc = t->build(len, s);  // synchronises the stream: the tables are complete for every later user
+    if (*rc) {
+        delete t;
+        return nullptr;
+    }
+    (*cache)[{dev, len}] = t;
+    return t;
+}
+
 // workspace + tables for scans of one shape
 struct FftWork {
     int rows = 0, cols = 0, pitch = 0;  // pitch: elements per line of the TRANSPOSED half spectrum (cols / 2 + 1 lines of
                                         // rows + 8 elements: the row pass's stores of one column index then spread over
                                         // the memory channels instead of aliasing)
-    AxisTables ax_cols, ax_rows;  // transforms along a row (length cols) / along a column (length rows)
+    const AxisTables *axc = nullptr, *axr = nullptr;  // transforms along a row (length cols) / along a column (length rows)
     int mag_pitch = 0;  // floats per line of the transposed |F| (cols lines of rows + 16)
     DevBuf c0, mag, mm, part;
     int group = 1;  // scans carried by one launch of each kernel (every per-scan array holds that many)
@@ -131,9 +210,9 @@ struct FftWork {
         rows = r;
         cols = c;
         group = scans_per_launch < 1 ? 1 : scans_per_launch;
-        int rc;
-        if ((rc = ax_cols.build(c, s))) return rc;
-        if ((rc = ax_rows.build(r, s))) return rc;
+        int rc = OMR_OK;
+        if (!(axc = axis_tables(c, s, &rc))) return rc;
+        if (!(axr = axis_tables(r, s, &rc))) return rc;
         pitch = r + 8;
         mag_pitch = r + 16;
         OMR_HIP(c0.alloc(sizeof(cfloat) * (size_t)(c / 2 + 1) * pitch * group));
@@ -158,13 +237,14 @@ struct FftWork {
         p.in_scale = (float)(1.0 / 255.0);  // convert_to(CV_32F, 1.0 / 255.0): alpha cast to float
         p.dst = c0.as<cfloat>();
         p.n = cols;
-        p.m = ax_cols.m;
-        p.log2m = ax_cols.log2m;
+        p.m = axc->m;
+        p.log2m = axc->log2m;
+        p.odd = axc->odd;
         p.lines = rows;
-        p.W = ax_cols.W.as<cfloat>();
-        p.Wfull = ax_cols.Wfull.as<cfloat>();
-        p.chirp = ax_cols.blue ? ax_cols.chirp.as<cfloat>() : nullptr;
-        p.Bf = ax_cols.blue ? ax_cols.Bf.as<cfloat>() : nullptr;
+        p.W = axc->W.as<cfloat>();
+        p.Wfull = axc->Wfull.as<cfloat>();
+        p.chirp = axc->blue ? axc->chirp.as<cfloat>() : nullptr;
+        p.Bf = axc->blue ? axc->Bf.as<cfloat>() : nullptr;
         p.out_scale = 1.0f;
         p.line_stride = pitch;  // (unused: the input is the 8-bit scan)
         p.elem_stride = 1;
@@ -190,14 +270,15 @@ struct FftWork {
         q.line_stride = pitch;
         q.elem_stride = 1;
         q.n = rows;
-        q.m = ax_rows.m;
-        q.log2m = ax_rows.log2m;
+        q.m = axr->m;
+        q.log2m = axr->log2m;
+        q.odd = axr->odd;
         q.lines = cols / 2 + 1;  // the other columns are mirror images (real input)
         q.half_mirror = 1;
-        q.W = ax_rows.W.as<cfloat>();
-        q.Wfull = ax_rows.Wfull.as<cfloat>();
-        q.chirp = ax_rows.blue ? ax_rows.chirp.as<cfloat>() : nullptr;
-        q.Bf = ax_rows.blue ? ax_rows.Bf.as<cfloat>() : nullptr;
+        q.W = axr->W.as<cfloat>();
+        q.Wfull = axr->Wfull.as<cfloat>();
+        q.chirp = axr->blue ? axr->chirp.as<cfloat>() : nullptr;
+        q.Bf = axr->blue ? axr->Bf.as<cfloat>() : nullptr;
         q.out_scale = (float)(1.0 / ((double)rows * (double)cols));
         OMR_HIP(launch_fft_pass(q, s));
         OMR_HIP(launch_minmax_final(part.as<float>(), cols / 2 + 1, mm.as<uint32_t>(), s, scans, 2 * (int64_t)cols));
