@@ -303,10 +303,18 @@ __global__ __launch_bounds__(NT) void fft_pass_kernel(FftPass p)
     // two real rows per workgroup: split Z = FFT(a + i b) into FFT(a) and FFT(b), columns 0 .. n / 2
     auto emit_pair = [&](const cfloat *Z) {
         cfloat *d0 = p.dst + line * dls, *d1 = d0 + dls;
+        // transposed output: the two rows' points are neighbours (16 bytes, aligned when the line pitch is even): one store
+        const bool wide = second && dls == 1 && (des & 1) == 0 && (((uintptr_t)p.dst) & 15) == 0;
         for (int k = tid; k <= n / 2; k += FFT_THREADS) {
             const cfloat zk = Z[FPAD(k)], zn = Z[FPAD(k == 0 ? 0 : n - k)];
-            d0[(int64_t)k * des] = cfloat{(0.5f * (zk.x + zn.x)) * p.out_scale, (0.5f * (zk.y - zn.y)) * p.out_scale};
-            if (second) d1[(int64_t)k * des] = cfloat{(0.5f * (zk.y + zn.y)) * p.out_scale, (-0.5f * (zk.x - zn.x)) * p.out_scale};
+            const cfloat a = cfloat{(0.5f * (zk.x + zn.x)) * p.out_scale, (0.5f * (zk.y - zn.y)) * p.out_scale};
+            const cfloat b = cfloat{(0.5f * (zk.y + zn.y)) * p.out_scale, (-0.5f * (zk.x - zn.x)) * p.out_scale};
+            if (wide) {
+                *(float4 *)(d0 + (int64_t)k * des) = make_float4(a.x, a.y, b.x, b.y);
+            } else {
+                d0[(int64_t)k * des] = a;
+                if (second) d1[(int64_t)k * des] = b;
+            }
         }
     };
     if (!blue) {

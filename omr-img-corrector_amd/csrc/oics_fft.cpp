@@ -213,7 +213,7 @@ struct FftWork {
         int rc = OMR_OK;
         if (!(axc = axis_tables(c, s, &rc))) return rc;
         if (!(axr = axis_tables(r, s, &rc))) return rc;
-        pitch = r + 8;
+        pitch = (r + 9) & ~1;  // even: a row pair's two points of a line are one aligned 16-byte store
         mag_pitch = r + 16;
         OMR_HIP(c0.alloc(sizeof(cfloat) * (size_t)(c / 2 + 1) * pitch * group));
         OMR_HIP(mag.alloc(sizeof(float) * (size_t)c * mag_pitch * group));
