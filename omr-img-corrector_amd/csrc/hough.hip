@@ -282,32 +282,36 @@ hipError_t launch_edges_compact(const uint8_t *d_edges, int rows, int cols, int 
 }
 
 // ------------------------------------------------------------------------------------------
-// HoughLinesProbabilistic, one workgroup of TWO waves per scan and no workgroup barrier.
+// HoughLinesProbabilistic, one workgroup of FIVE waves per scan and no workgroup barrier after the start.
 //
 // The algorithm is a dependent chain over the drawn points (every point sees the accumulator and the mask left
 // by all points before it), so a scan's time is (points served) x (latency of one step).  The step is cut down
-// to two memory round trips -- the vote's accumulator reads and the walk's mask reads:
+// to two memory round trips -- the vote's accumulator reads and the walk's mask reads -- on ONE serving wave:
 //
 //   wave 1, the draw stage, runs AHEAD of the rest: the draw order does not depend on the image (cv::RNG and
 //     swap-remove on the point list), so this wave turns the list into the sequence of drawn points, 64 draws
 //     per round -- lane 0 steps the RNG, every lane takes one draw (index, its slot, the slot swapped in), the
 //     64 sequential swap-removes are replayed on those registers (v_readlane of draw t, compare, select) and
-//     written back -- and publishes its progress in LDS (release / acquire at workgroup scope: both waves
-//     run on one CU and share its L1).
+//     written back -- and publishes its progress in LDS (release / acquire at workgroup scope: the waves of a
+//     workgroup run on one CU and share its L1).
 //   wave 0 takes 64 drawn points at a time, tests them against the mask in one round trip and serves those
 //     still set, lowest first:
 //       vote     lane = accumulator angle (three per lane): load, +1, store; arg-max by DPP (larger value,
-//                then the LOWER angle: "if (max_val < val)" keeps the first maximum);
+//                then the LOWER angle: "if (max_val < val)" keeps the first maximum).  The bins of the NEXT
+//                pending point are read ahead while this point walks;
 //       walk     lane = step: 128 steps of both directions per round (four mask words per lane in flight); the
-//                sequential gap rule runs on the ballots (scalar code);
-//       pass 2   erases the segment's points (atomic AND, nothing waits) from the flags pass 1 already holds and,
-//                for an accepted segment, un-votes them: lane = angle, fire-and-forget atomic decrements.  Row n
-//                of the accumulator is only touched by lane n % 64, so a bin's updates stay in program order;
+//                sequential gap rule without a loop, on the ballots;
+//       pass 2   erases the segment's points (atomic AND, nothing waits) from the flags pass 1 already holds;
+//                the points of an ACCEPTED segment are collected in LDS and un-voted lane = point, one angle
+//                after the other, the angles split between wave 0 and
+//   waves 2-4 (a no-return atomic costs a wave >= 72 cycles to issue whatever its lanes do);
 //       pending points are re-tested WITHOUT memory: a point that was set is erased by the walk exactly when it
 //                is one of the walked positions up to the segment's end -- integer arithmetic on registers.
 //
 // The accumulator rows are stored compactly (row n holds only the rho range an image of this size can reach:
-// 2.8 MB instead of 8.6 MB at A4, so that it stays in the XCD's L2 next to the 1.1 MB mask).
+// 2.8 MB instead of 8.6 MB at A4, so that it stays in the XCD's L2 next to the 1.1 MB mask).  What is left per
+// served point is mostly the CU's memory pipeline (one address per cycle, shared by all five waves: 180 bins read
+// and written, the mask words, the erasing and un-voting atomics) and the serving wave's own instruction stream.
 struct alignas(16) PphtShared {
     float4 ang[OMR_PPHT_MAX_ANGLES];     // (cos / rho, sin / rho, byte offset of the row's bin rho = 0 [bits], -)
     PphtWalk walk[OMR_PPHT_MAX_ANGLES];  // 16 bytes each
