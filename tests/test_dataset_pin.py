@@ -117,3 +117,24 @@ def test_correct_default_on_the_dataset_gpu(oracle):
         json.dump({"cases": n, "histogram": hist, "worst_believed_error_deg": worst, "believed_cases_at_0p5": edge,
                    "reference_claim": "99.9 % < 0.4 deg, ~100 % < 0.5 deg (lib.rs:108)",
                    "success_rate": hist.get("SUCCESS", 0) / n}, open(os.path.join(out, "dataset_pin_gpu.json"), "w"), indent=1)
+
+
+@pytest.mark.gpu
+def test_core_protocol_on_the_dataset_gpu():
+    """packages/core/src/main.rs:17-252, the reference's comparative benchmark, through the drop-in API (tools/
+    core_protocol.py): on the reference's 104 sheets, skewed by seeded angles in [-10, 10), the projection and the
+    Hough-line method must find the angle (the reference holds no numbers for this protocol; measured: mean 0.13 /
+    0.19 deg, max 0.58 / 0.46 deg), and the FFT method, which answers 0 when the spectrum's axis cross wins the
+    vote, must be right where it answers something else."""
+    import importlib.util
+    tool = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "core_protocol.py")
+    spec = importlib.util.spec_from_file_location("core_protocol", tool)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    j = mod.run(2024)
+    assert j["sheets"] == 104
+    for m, mean_max, frac in (("projection", 0.25, 0.95), ("hough", 0.30, 0.95)):
+        r = j[m]
+        assert r["answered"] == 104 and r["deviation_mean_deg"] < mean_max and r["within_0.5_deg"] >= frac * 104, (m, r)
+        assert r["deviation_max_deg"] < 1.0, (m, r)
+    assert j["fft"]["answered"] == 104 and j["fft"]["within_0.5_deg"] >= 40, j["fft"]

@@ -173,4 +173,13 @@ with open(os.path.join(dst, tag + "_calls.md"), "w") as f:
     f.write("`python3 tools/bench_calls.py`:\n\n```\n%s```\n\n`python3 tools/bench_host.py`:\n\n```\n%s```\n" % (
         "\n".join(l for l in read("calls.log").splitlines() if "amdgpu.ids" not in l) + "\n",
         "\n".join(l for l in read("host.log").splitlines() if "amdgpu.ids" not in l) + "\n"))
+cp = "\n".join(l for l in read("core_protocol.log").splitlines() if "amdgpu.ids" not in l)
+if cp.strip():
+    with open(os.path.join(dst, tag + "_core_protocol.md"), "w") as f:
+        f.write("# %s -- the reference's comparative benchmark (packages/core/src/main.rs:17-252) through the drop-in API\n\n" % tag + STAMP)
+        f.write("104 dataset sheets, each skewed by a seeded random angle in [-10, 10) (CONTAIN, INTER_LINEAR, white), then "
+                "`get_angle_with_projections(45, 0.2, 0.2, 1)`, `get_angle_with_hough(125, 15)`, `get_angle_with_fft(125, 150, 150, 75)` "
+                "and the rotation back; run time per sheet (host image in, host image out, no JPEG write) and |estimate - injected|. "
+                "The reference publishes no numbers for this protocol; its `main()` runs the first two methods.\n\n"
+                "`python3 tools/core_protocol.py`:\n\n```\n%s\n```\n" % cp)
 print("profiles written for", tag, "commit", commit)

@@ -40,6 +40,7 @@ timeout -k 10 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv 
 timeout -k 10 600 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAVE_CYCLES SQ_BUSY_CYCLES --kernel-trace --output-format csv -d "$OUT/hough_sq" -- python3 tools/hough_run.py 64 4 1 > "$OUT/hough_sq.log" 2>&1 || true
 echo "[profile] stages / fft / hough done"
 timeout -k 10 300 python3 tools/bench_calls.py > "$OUT/calls.log" 2>&1 || true
+timeout -k 10 600 python3 tools/core_protocol.py > "$OUT/core_protocol.log" 2>&1 || true
 timeout -k 10 300 python3 tools/bench_host.py > "$OUT/host.log" 2>&1 || true
 # 5. micro-benchmarks behind DESIGN.md's issue-cost / LDS statements
 for t in valu_issue valu_ops lds_unaligned lds_bytes mem_latency; do
