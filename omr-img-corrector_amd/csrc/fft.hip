@@ -253,30 +253,17 @@ __global__ __launch_bounds__(NT) void fft_pass_kernel(FftPass p)
     // spectrum-picture mode (column pass): point k of this line is F(k, line); it lands at the quadrant-swapped
     // position of the |F| image
     const bool mag_mode = p.mag_dst != nullptr;
-    const int cxh = p.img_cols / 2, cyh = p.img_rows / 2;
     const int sc = (int)line;
-    const int sc_sw = sc < cxh ? sc + cxh : sc - cxh;
     float lo = __builtin_inff(), hi = -__builtin_inff();
     auto emit = [&](int k, cfloat v) {
         if (!mag_mode) {
             dst[(int64_t)k * des] = v;
             return;
         }
-        // only points inside the four quadrants move; an odd last row / column keeps its place (fft.rs:69-74)
-        const bool inq = sc < 2 * cxh && k < 2 * cyh;
-        const int orow = inq ? (k < cyh ? k + cyh : k - cyh) : k, oc = inq ? sc_sw : sc;
+        // |F(k, sc)| of this half of the spectrum (columns 0 .. C/2), at its own place: the picture kernel applies
+        // fft_shift and takes the other half from the conjugate-symmetric points (F(-k, -c) = conj F(k, c))
         const float mg = sqrtf(v.x * v.x + v.y * v.y);
-        p.mag_dst[(int64_t)oc * p.mag_pitch + orow] = mg;
-        if (p.half_mirror) {  // the conjugate-symmetric point of a real image's spectrum
-            const int mc = sc == 0 ? 0 : p.img_cols - sc;
-            if (mc != sc) {
-                const int mk = k == 0 ? 0 : p.img_rows - k;
-                const bool minq = mc < 2 * cxh && mk < 2 * cyh;
-                const int mrow = minq ? (mk < cyh ? mk + cyh : mk - cyh) : mk;
-                const int mcol = minq ? (mc < cxh ? mc + cxh : mc - cxh) : mc;
-                p.mag_dst[(int64_t)mcol * p.mag_pitch + mrow] = mg;
-            }
-        }
+        p.mag_dst[(int64_t)sc * p.mag_pitch + k] = mg;
         lo = fminf(lo, mg);
         hi = fmaxf(hi, mg);
     };
@@ -470,7 +457,7 @@ __device__ __forceinline__ float spec_m3(float mg, float beta, float alpha)
 }
 __device__ __forceinline__ float spec_log(float m3) { return logf(m3 * 1.0f + (float)(1.0 / 255.0)); }
 
-// magT: |F| transposed (cols lines of mag_pitch floats).  A workgroup turns a tile of 64 columns x 64 rows through LDS
+// magT: |F| of the half spectrum, transposed (cols / 2 + 1 lines of mag_pitch floats, line = spectrum column).  A workgroup turns a tile of 64 columns x 64 rows through LDS
 // (reads run along a transposed line = down a picture column, writes along picture rows) into both pictures.
 __global__ __launch_bounds__(256) void spec_pictures_kernel(const float *__restrict__ magT, int rows, int cols, int mag_pitch,
                                                             const uint32_t *__restrict__ mm, uint8_t *__restrict__ mag_u8,
@@ -488,10 +475,24 @@ __global__ __launch_bounds__(256) void spec_pictures_kernel(const float *__restr
     const float beta2 = (float)(-lmn), alpha2 = (float)(1.0 / (lmx - lmn));
     const int c0 = blockIdx.x * 64, r0 = blockIdx.y * 64;
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    // picture pixel (r, c) <- fft_shift (fft.rs:67-86: the quadrants swap, an odd last row / column keeps its place) <-
+    // spectrum point (k, sc); points of the right half come from their mirror images (R - k, C - sc)
+    const int cxh = cols / 2, cyh = rows / 2;
 #pragma unroll
     for (int i = 0; i < 16; i++) {
         const int c = c0 + ty + 4 * i, r = r0 + tx;
-        tile[ty + 4 * i][tx] = (c < cols && r < rows) ? magT[(int64_t)c * mag_pitch + r] : 0.f;
+        float v = 0.f;
+        if (c < cols && r < rows) {
+            const bool inq = c < 2 * cxh && r < 2 * cyh;
+            int k = inq ? (r < cyh ? r + cyh : r - cyh) : r;
+            int sc = inq ? (c < cxh ? c + cxh : c - cxh) : c;
+            if (sc > cxh) {
+                sc = cols - sc;
+                k = k == 0 ? 0 : rows - k;
+            }
+            v = magT[(int64_t)sc * mag_pitch + k];
+        }
+        tile[ty + 4 * i][tx] = v;
     }
     __syncthreads();
 #pragma unroll

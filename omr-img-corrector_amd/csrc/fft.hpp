@@ -39,7 +39,8 @@ struct FftPass {
     // Column pass of the spectrum pictures: when mag_dst is set the pass writes |F| (float) instead of F,
     // already quadrant-swapped (fft_shift, fft.rs:67-86: an odd last row / column stays put), and the
     // per-workgroup extrema of |F| to part[2 * line .. + 1] -- no complex spectrum is ever written.
-    float *mag_dst;         // TRANSPOSED |F|: img_cols lines of mag_pitch floats (|F|(row, col) at [col * mag_pitch + row]), or NULL
+    float *mag_dst;         // TRANSPOSED |F| of the half spectrum: lines (= columns 0 .. C/2) of mag_pitch floats, |F(k, c)| at
+                            // [c * mag_pitch + k], unshifted (the picture kernel shifts and mirrors), or NULL
     int32_t mag_pitch, img_rows, img_cols;
     float *part;
     // The input is REAL (an 8-bit scan), which halves both passes:
@@ -71,7 +72,7 @@ inline size_t spec_part_floats(int rows, int cols)
 // fold n per-workgroup (min, max) pairs into d_minmax[0..1] (ordered-uint keys)
 hipError_t launch_minmax_final(const float *d_part, int n, uint32_t *d_minmax, hipStream_t s, int scans = 1,
                                int64_t part_scan_stride = 0);  // scan z: d_part + z * stride -> d_minmax + 4 z
-// Both 8-bit pictures (row-major, packed) from the TRANSPOSED |F| (cols lines of mag_pitch floats) in one pass: correction(|F|) * 255 -> "magnitude_image" (x 255 again,
+// Both 8-bit pictures (row-major, packed) from the transposed |F| of the half spectrum (cols / 2 + 1 lines of mag_pitch floats) in one pass: correction(|F|) * 255 -> "magnitude_image" (x 255 again,
 // fft.rs:134) and log(. + 1/255) -> correction -> "magnitude_log_image" (fft.rs:113-119, :136-138).  The
 // extrema of the log picture are the images of the extrema of |F| under the same float expressions (every
 // step is monotone), so no second reduction pass and no float log array are needed.

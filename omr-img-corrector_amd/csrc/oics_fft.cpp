@@ -202,7 +202,7 @@ struct FftWork {
                                         // rows + 8 elements: the row pass's stores of one column index then spread over
                                         // the memory channels instead of aliasing)
     const AxisTables *axc = nullptr, *axr = nullptr;  // transforms along a row (length cols) / along a column (length rows)
-    int mag_pitch = 0;  // floats per line of the transposed |F| (cols lines of rows + 16)
+    int mag_pitch = 0;  // floats per line of the transposed |F| (cols / 2 + 1 lines of rows + 16)
     DevBuf c0, mag, mm, part;
     int group = 1;  // scans carried by one launch of each kernel (every per-scan array holds that many)
     int create(int r, int c, hipStream_t s, int scans_per_launch = 1)
@@ -216,7 +216,7 @@ struct FftWork {
         pitch = (r + 9) & ~1;  // even: a row pair's two points of a line are one aligned 16-byte store
         mag_pitch = r + 16;
         OMR_HIP(c0.alloc(sizeof(cfloat) * (size_t)(c / 2 + 1) * pitch * group));
-        OMR_HIP(mag.alloc(sizeof(float) * (size_t)c * mag_pitch * group));
+        OMR_HIP(mag.alloc(sizeof(float) * (size_t)(c / 2 + 1) * mag_pitch * group));
         OMR_HIP(mm.alloc(sizeof(uint32_t) * 4 * group));
         OMR_HIP(part.alloc(sizeof(float) * 2 * (size_t)c * group));
         return OMR_OK;
@@ -258,7 +258,7 @@ struct FftWork {
         FftPass q{};
         q.scans = scans;
         q.c_scan_stride = (int64_t)(cols / 2 + 1) * pitch;
-        q.mag_scan_stride = (int64_t)cols * mag_pitch;
+        q.mag_scan_stride = (int64_t)(cols / 2 + 1) * mag_pitch;
         q.part_scan_stride = 2 * (int64_t)cols;
         q.src_c = c0.as<cfloat>();
         q.dst = nullptr;  // spectrum-picture mode: |F|, quadrant-swapped, straight from the column pass
@@ -283,7 +283,7 @@ struct FftWork {
         OMR_HIP(launch_fft_pass(q, s));
         OMR_HIP(launch_minmax_final(part.as<float>(), cols / 2 + 1, mm.as<uint32_t>(), s, scans, 2 * (int64_t)cols));
         OMR_HIP(launch_spec_pictures(mag.as<float>(), rows, cols, mag_pitch, mm.as<uint32_t>(), d_mag_u8, d_log_u8, s, scans,
-                                     (int64_t)cols * mag_pitch));
+                                     (int64_t)(cols / 2 + 1) * mag_pitch));
         return OMR_OK;
     }
 };
