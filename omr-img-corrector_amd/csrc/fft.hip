@@ -38,57 +38,9 @@ __device__ __forceinline__ cfloat cadd(const cfloat a, const cfloat b) { return 
 __device__ __forceinline__ cfloat csub(const cfloat a, const cfloat b) { return cfloat{a.x - b.x, a.y - b.y}; }
 __device__ __forceinline__ cfloat cmul_mi(const cfloat a) { return cfloat{a.y, -a.x}; }  // a * (-i)
 
-// One Stockham stage of odd radix R (3 or 5) as the LAST stage of a transform of m = R * T points, T a power of two
-// (Ns = T, so k = j): y[q] = sum_p u[p] w^p exp(-2 pi i p q / R), w = Wr[j] = exp(-2 pi i j / m).  The R-point DFT uses the
-// symmetry of the roots: with A_p = u_p + u_{R-p}, B_p = u_p - u_{R-p}:  y[q], y[R-q] = (u_0 + sum_p cos(2 pi p q / R) A_p)
-// -/+ i (sum_p sin(2 pi p q / R) B_p) -- real factors only.  Bluestein lengths between two powers of two (a 2480-point
-// row needs 4959 points: 5 * 1024 instead of 8192) cost 0.6 of the power-of-two transform this way.
-template <int NT, int R>
-__device__ __forceinline__ void fft_odd_stage(const cfloat *in, cfloat *out, const int T, const cfloat *__restrict__ Wr, const int tid)
-{
-    constexpr int H = (R - 1) / 2;
-    constexpr float C3[1] = {-0.5f}, S3[1] = {0.86602540378443864676f};
-    constexpr float C5[2] = {0.30901699437494742410f, -0.80901699437494742410f};
-    constexpr float S5[2] = {0.95105651629515357212f, 0.58778525229247312917f};
-    for (int j = tid; j < T; j += NT) {
-        const cfloat w1 = Wr[j];
-        cfloat u[R];
-        u[0] = in[FPAD(j)];
-        cfloat wp = w1;
-#pragma unroll
-        for (int p = 1; p < R; p++) {
-            u[p] = cmul(in[FPAD(j + p * T)], wp);
-            if (p + 1 < R) wp = cmul(wp, w1);
-        }
-        cfloat A[H], B[H], y0 = u[0];
-#pragma unroll
-        for (int p = 0; p < H; p++) {
-            A[p] = cadd(u[p + 1], u[R - 1 - p]);
-            B[p] = csub(u[p + 1], u[R - 1 - p]);
-            y0 = cadd(y0, A[p]);
-        }
-        out[FPAD(j)] = y0;
-#pragma unroll
-        for (int q = 1; q <= H; q++) {
-            cfloat c = u[0], sn = cfloat{0.f, 0.f};
-#pragma unroll
-            for (int p = 1; p <= H; p++) {
-                const int idx = (p * q) % R;  // cos(2 pi idx / R), sin(2 pi idx / R) from the half tables
-                const int h = idx <= H ? idx : R - idx;
-                const float cs = R == 3 ? C3[0] : C5[h - 1];
-                const float ss = (R == 3 ? S3[0] : S5[h - 1]) * (idx <= H ? 1.f : -1.f);
-                c = cfloat{c.x + cs * A[p - 1].x, c.y + cs * A[p - 1].y};
-                sn = cfloat{sn.x + ss * B[p - 1].x, sn.y + ss * B[p - 1].y};
-            }
-            out[FPAD(j + q * T)] = cfloat{c.x + sn.y, c.y - sn.x};        // c - i sn
-            out[FPAD(j + (R - q) * T)] = cfloat{c.x - sn.y, c.y + sn.x};  // c + i sn
-        }
-    }
-}
-
 template <int NT>
 __device__ cfloat *fft_forward_lds(cfloat *in, cfloat *out, const int m, const int log2m,
-                                   const cfloat *__restrict__ Wst, const int tid, const int odd = 1)
+                                   const cfloat *__restrict__ Wst, const int tid)
 {
     int s = 0;
     const int lead = log2m % 3;
@@ -168,15 +120,6 @@ __device__ cfloat *fft_forward_lds(cfloat *in, cfloat *out, const int m, const i
         in = out;
         out = t;
     }
-    if (odd > 1) {  // m = odd << log2m: the last stage; its twiddles exp(-2 pi i j / m) follow the radix-8 tables
-        const cfloat *Wr = Wst + (((1 << log2m) - Ns0) / 7);
-        __syncthreads();
-        if (odd == 3) fft_odd_stage<NT, 3>(in, out, 1 << log2m, Wr, tid);
-        else fft_odd_stage<NT, 5>(in, out, 1 << log2m, Wr, tid);
-        cfloat *t = in;
-        in = out;
-        out = t;
-    }
     __syncthreads();
     return in;
 }
@@ -247,7 +190,7 @@ __global__ __launch_bounds__(NT) void fft_pass_kernel(FftPass p)
     }
     cfloat *P = A;
     if (inplace) fft_inplace_lds<NT>(A, m, p.log2m, p.Wfull, tid);
-    else P = fft_forward_lds<NT>(A, B, m, p.log2m, p.W, tid, p.odd);
+    else P = fft_forward_lds<NT>(A, B, m, p.log2m, p.W, tid);
     cfloat *Q = P == A ? B : A;
     cfloat *dst = p.dst + line * dls;
     // spectrum-picture mode (column pass): point k of this line is F(k, line); it lands at the quadrant-swapped
@@ -333,7 +276,7 @@ __global__ __launch_bounds__(NT) void fft_pass_kernel(FftPass p)
         }
         fft_inplace_lds<NT>(P, m, p.log2m, p.Wfull, tid);
     } else {
-        R = fft_forward_lds<NT>(P, Q, m, p.log2m, p.W, tid, p.odd);
+        R = fft_forward_lds<NT>(P, Q, m, p.log2m, p.W, tid);
     }
     const float inv_m = 1.0f / (float)m;
     if (pairs) {  // the line's spectrum must be complete in LDS before the two rows can be separated
@@ -353,9 +296,7 @@ __global__ __launch_bounds__(NT) void fft_pass_kernel(FftPass p)
 hipError_t launch_fft_pass(const FftPass &p, hipStream_t s)
 {
     if (p.lines <= 0) return hipSuccess;
-    const int odd = p.odd > 1 ? p.odd : 1;
-    if (p.m > OMR_FFT_MAX_M || (odd << p.log2m) != p.m || (odd != 1 && odd != 3 && odd != 5)) return hipErrorInvalidValue;
-    if (odd > 1 && p.m > OMR_FFT_MAX_PINGPONG) return hipErrorInvalidValue;
+    if (p.m > OMR_FFT_MAX_M || (1 << p.log2m) != p.m) return hipErrorInvalidValue;
     const size_t lds = (p.m > OMR_FFT_MAX_PINGPONG ? 1 : 2) * sizeof(cfloat) * (size_t)FFT_LDS_ELEMS(p.m);
     if (p.m > OMR_FFT_MAX_PINGPONG && !p.Wfull) return hipErrorInvalidValue;
     // Transforms of more than 4096 points hold the CU alone (> 80 KB of LDS): 1024 threads (4 waves per SIMD, one

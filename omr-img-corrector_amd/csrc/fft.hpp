@@ -13,7 +13,7 @@ struct cfloat {
 
 // One pass of 1-D transforms over `lines` lines of length n, a whole line per workgroup in LDS:
 // a radix-4 / radix-2 Stockham FFT when n is a power of two (m = n), else Bluestein's chirp-z through two
-// FFTs of length m >= 2n - 1, m = 2^a, 3 * 2^a or 5 * 2^a (whichever costs least).  m <= 8192 ping-pongs between two LDS buffers (radix 8);
+// FFTs of length m = the power of two >= 2n - 1.  m <= 8192 ping-pongs between two LDS buffers (radix 8);
 // m = 16384 (lines of 4097 .. 8192 points, e.g. a 600-dpi A4 scan) runs in place in one buffer (radix 2).
 struct FftPass {
     const uint8_t *src_u8;  // real 8-bit input (im = 0), x = (float)v * in_scale; or NULL
@@ -23,7 +23,7 @@ struct FftPass {
     cfloat *dst;            // complex output
     int64_t line_stride;    // elements between consecutive lines of src_c and dst (n for packed rows, 1 for columns)
     int64_t elem_stride;    // elements between consecutive points of a line (1 for rows, the row pitch for columns)
-    int32_t n, m, log2m, lines;  // m = odd << log2m
+    int32_t n, m, log2m, lines;
     const cfloat *W;        // per-stage twiddle tables of the radix-8 stages, concatenated: stage Ns holds
                             // exp(-2 pi i k / (8 Ns)), k < Ns, at offset (Ns - Ns0) / 7, Ns0 = 2^(log2m % 3)
     const cfloat *chirp;    // n: exp(-i pi k^2 / n); NULL for the direct transform
@@ -33,7 +33,6 @@ struct FftPass {
     // (0, 0 = the input's strides).  The row pass of the pictures writes TRANSPOSED (line stride 1): the column
     // pass then reads whole lines of consecutive addresses instead of one 8-byte element per cache line.
     int64_t dst_line_stride, dst_elem_stride;
-    int32_t odd;            // 1, 3 or 5: m = odd * 2^log2m, the odd radix is the transform's last stage (m <= 8192)
     int32_t xcd_blocked;    // workgroups of one XCD take consecutive lines (their partial cache lines of a
                             // transposed / strided array then meet in that XCD's L2)
     // Column pass of the spectrum pictures: when mag_dst is set the pass writes |F| (float) instead of F,

@@ -57,36 +57,9 @@ void fft_host(std::vector<cd> &a)  // iterative radix-2, in place, forward
     }
 }
 
-// forward DFT of length R * 2^a (R odd, small) by decimation in time over the R residue classes
-void dft_host(std::vector<cd> &a)
-{
-    const size_t n = a.size();
-    size_t T = n;
-    while (T % 2 == 0) T /= 2;
-    const size_t R = T;  // odd part
-    if (R == 1) {
-        fft_host(a);
-        return;
-    }
-    T = n / R;
-    std::vector<std::vector<cd>> sub(R, std::vector<cd>(T));
-    for (size_t r = 0; r < R; r++) {
-        for (size_t t = 0; t < T; t++) sub[r][t] = a[t * R + r];
-        fft_host(sub[r]);
-    }
-    for (size_t k = 0; k < n; k++) {
-        cd acc(0, 0);
-        for (size_t r = 0; r < R; r++) {
-            const double ang = -2.0 * kPi * (double)((r * k) % n) / (double)n;
-            acc += sub[r][k % T] * cd(cos(ang), sin(ang));
-        }
-        a[k] = acc;
-    }
-}
-
 // device tables of one axis length
 struct AxisTables {
-    int n = 0, m = 0, log2m = 0, odd = 1;  // m = odd << log2m
+    int n = 0, m = 0, log2m = 0;
     bool blue = false;
     DevBuf W, Wfull, chirp, Bf;
     int build(int len, hipStream_t s)
@@ -96,7 +69,6 @@ struct AxisTables {
         const int need = blue ? 2 * n - 1 : n;
         m = 1;
         log2m = 0;
-        odd = 1;
         while (m < need) {
             m <<= 1;
             log2m++;
@@ -104,34 +76,11 @@ struct AxisTables {
         if (m > OMR_FFT_MAX_M)
             return fail(OMR_ERR_NOTIMPL, "DFT length %d needs a transform of %d points; the kernel holds at most %d in LDS", n,
                         m, OMR_FFT_MAX_M);
-        if (blue && m <= OMR_FFT_MAX_PINGPONG) {
-            // Bluestein's length is free above 2n - 1: 3 * 2^a or 5 * 2^a when that is less work than the power of two
-            // (stage units per point: a / 3 radix-8 stages, + 0.7 for the radix-3 and + 1.0 for the radix-5 stage)
-            double best = (double)m * (log2m / 3.0);
-            for (int r = 3; r <= 5; r += 2)
-                for (int a = 6; (r << a) <= OMR_FFT_MAX_PINGPONG; a++)
-                    if ((r << a) >= need) {
-                        const double cost = (double)(r << a) * (a / 3.0 + (r == 3 ? 0.7 : 1.0));
-                        if (cost < best) {
-                            best = cost;
-                            m = r << a;
-                            log2m = a;
-                            odd = r;
-                        }
-                        break;
-                    }
-        }
         // twiddles of the radix-8 stages, one contiguous table per stage (Ns = Ns0, 8 Ns0, ... < m)
         std::vector<cfloat> w;
-        const int pow2 = 1 << log2m;
-        for (int Ns = 1 << (log2m % 3); Ns < pow2; Ns *= 8)
+        for (int Ns = 1 << (log2m % 3); Ns < m; Ns *= 8)
             for (int k = 0; k < Ns; k++) {
                 const double ang = -2.0 * kPi * (double)k / (8.0 * (double)Ns);
-                w.push_back(cfloat{(float)cos(ang), (float)sin(ang)});
-            }
-        if (odd > 1)  // the odd radix' stage (the last one, Ns = 2^log2m): exp(-2 pi i j / m)
-            for (int j = 0; j < pow2; j++) {
-                const double ang = -2.0 * kPi * (double)j / (double)m;
                 w.push_back(cfloat{(float)cos(ang), (float)sin(ang)});
             }
         if (w.empty()) w.push_back(cfloat{1.f, 0.f});
@@ -156,7 +105,7 @@ struct AxisTables {
             std::vector<cd> b((size_t)m, cd(0, 0));
             b[0] = std::conj(c[0]);
             for (int k = 1; k < n; k++) b[k] = b[m - k] = std::conj(c[k]);
-            dft_host(b);
+            fft_host(b);
             std::vector<cfloat> cf((size_t)n), bf((size_t)m);
             for (int k = 0; k < n; k++) cf[k] = cfloat{(float)c[k].real(), (float)c[k].imag()};
             for (int k = 0; k < m; k++) bf[k] = cfloat{(float)b[k].real(), (float)b[k].imag()};
@@ -239,7 +188,6 @@ struct FftWork {
         p.n = cols;
         p.m = axc->m;
         p.log2m = axc->log2m;
-        p.odd = axc->odd;
         p.lines = rows;
         p.W = axc->W.as<cfloat>();
         p.Wfull = axc->Wfull.as<cfloat>();
@@ -272,7 +220,6 @@ struct FftWork {
         q.n = rows;
         q.m = axr->m;
         q.log2m = axr->log2m;
-        q.odd = axr->odd;
         q.lines = cols / 2 + 1;  // the other columns are mirror images (real input)
         q.half_mirror = 1;
         q.W = axr->W.as<cfloat>();
