@@ -144,7 +144,11 @@ __device__ void fft_inplace_lds(cfloat *buf, const int m, const int log2m, const
     __syncthreads();
 }
 
-template <int NT>
+// MODE: what is folded at compile time.  The code generated for this kernel is sensitive to what else is compiled into
+// it (an odd-radix stage that was merely present once slowed every transform by 15-25 %), so the variants were
+// measured side by side on one GPU: 1 = power-of-two row pass of the pictures (8-bit real rows in pairs -> transposed
+// half spectrum), 0 = power-of-two column pass (complex lines -> |F|), 8 = everything else, flags at run time.
+template <int NT, int MODE>
 __global__ __launch_bounds__(NT) void fft_pass_kernel(FftPass p)
 {
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
@@ -158,7 +162,9 @@ __global__ __launch_bounds__(NT) void fft_pass_kernel(FftPass p)
     }
     cfloat *A = (cfloat *)lds_raw, *B = A + FFT_LDS_ELEMS(p.m);  // B is not allocated (nor used) on the in-place path
     const int tid = threadIdx.x, n = p.n, m = p.m;
-    const bool inplace = m > OMR_FFT_MAX_PINGPONG;
+    // MODE 8: every flag read at run time (the Bluestein and in-place paths measured 5 % FASTER that way -- the
+    // compiler's choices, not ours); MODE 0 / 1: the power-of-two column / row pass with its flags folded
+    const bool inplace = MODE == 8 ? m > OMR_FFT_MAX_PINGPONG : false;
     const int rshift = 32 - p.log2m;
     // Column passes (elem_stride > 1) touch 8 bytes per 64-byte sector: the eight columns that share a
     // sector must meet in one XCD's L2.  Workgroups go round-robin to the 8 XCDs, so XCD x takes the
@@ -170,14 +176,14 @@ __global__ __launch_bounds__(NT) void fft_pass_kernel(FftPass p)
     }
     const int64_t dls = p.dst_line_stride ? p.dst_line_stride : p.line_stride;
     const int64_t des = p.dst_elem_stride ? p.dst_elem_stride : p.elem_stride;
-    const bool blue = p.chirp != nullptr;
-    const bool pairs = p.real_pairs != 0;
+    const bool blue = MODE == 8 ? p.chirp != nullptr : false;
+    const bool pairs = MODE == 8 ? p.real_pairs != 0 : (MODE & 1) != 0;
     const bool second = pairs && 2 * line + 1 < p.src_rows;
     if (pairs) line *= 2;
     for (int k = tid; k < m; k += FFT_THREADS) {
         cfloat v{0.f, 0.f};
         if (k < n) {
-            if (p.src_u8) {
+            if (pairs) {
                 v.x = (float)p.src_u8[line * p.src_step + k] * p.in_scale + 0.0f;
                 if (second) v.y = (float)p.src_u8[(line + 1) * p.src_step + k] * p.in_scale + 0.0f;
             } else {
@@ -195,7 +201,7 @@ __global__ __launch_bounds__(NT) void fft_pass_kernel(FftPass p)
     cfloat *dst = p.dst + line * dls;
     // spectrum-picture mode (column pass): point k of this line is F(k, line); it lands at the quadrant-swapped
     // position of the |F| image
-    const bool mag_mode = p.mag_dst != nullptr;
+    const bool mag_mode = !pairs;
     const int sc = (int)line;
     float lo = __builtin_inff(), hi = -__builtin_inff();
     auto emit = [&](int k, cfloat v) {
@@ -303,14 +309,23 @@ hipError_t launch_fft_pass(const FftPass &p, hipStream_t s)
     // radix-8 butterfly of a stage each) instead of 512 with two each.
     const dim3 grid(p.real_pairs ? (p.lines + 1) / 2 : p.lines, p.scans > 0 ? p.scans : 1);
     const int nt = p.m <= 4096 ? 512 : 1024;  // (640 threads for 5 * 1024 points measured no better than 1024)
-#define FFT_LAUNCH(NT_)                                                                                                       \
+#define FFT_LAUNCH(NT_, MODE_)                                                                                                \
     {                                                                                                                         \
-        hipError_t e = hipFuncSetAttribute((const void *)fft_pass_kernel<NT_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipError_t e = hipFuncSetAttribute((const void *)fft_pass_kernel<NT_, MODE_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         if (e != hipSuccess) return e;                                                                                        \
-        hipLaunchKernelGGL(fft_pass_kernel<NT_>, grid, dim3(NT_), lds, s, p);                                                 \
+        hipLaunchKernelGGL((fft_pass_kernel<NT_, MODE_>), grid, dim3(NT_), lds, s, p);                                        \
     }
-    if (nt == 512) FFT_LAUNCH(512)
-    else FFT_LAUNCH(1024)
+    const bool rowpass = p.real_pairs != 0 && p.src_u8 != nullptr && p.dst != nullptr;
+    const bool colpass = p.real_pairs == 0 && p.src_c != nullptr && p.mag_dst != nullptr;
+    if (!rowpass && !colpass) return hipErrorInvalidValue;
+    const bool plain = !p.chirp && p.m <= OMR_FFT_MAX_PINGPONG;  // power-of-two line, ping-pong buffers
+    if (nt == 512) {
+        if (plain && rowpass) FFT_LAUNCH(512, 1)
+        else if (plain) FFT_LAUNCH(512, 0)
+        else FFT_LAUNCH(512, 8)
+    } else {
+        FFT_LAUNCH(1024, 8)
+    }
 #undef FFT_LAUNCH
     return hipGetLastError();
 }
