@@ -559,7 +559,7 @@ __device__ __forceinline__ void gap_rule_short(unsigned long long n0, unsigned l
 }
 
 #define OMR_PPHT_PTS 1024  // LDS list of a segment's points waiting for their un-votes
-template <int NPL>         // accumulator angles per lane
+template <int NPL, bool SHORT_GAP>  // accumulator angles per lane; lineGap < 64 (the loop-free rule with one shift)
 __device__ __forceinline__ void ppht_serve(const PphtArgs &a, PphtShared &sh, int scan, int lane)
 {
     const int W = a.width, H = a.height;
@@ -702,7 +702,7 @@ __device__ __forceinline__ void ppht_serve(const PphtArgs &a, PphtShared &sh, in
 #pragma unroll
             for (int d = 0; d < 2; d++)
                 if (!stop[d]) {
-                    if ((uint32_t)a.line_gap < 64u) gap_rule_short(bn[2 * d], bn[2 * d + 1], bo[2 * d], bo[2 * d + 1], base, a.line_gap, lane, gap[d], end_t[d], stop[d]);
+                    if (SHORT_GAP) gap_rule_short(bn[2 * d], bn[2 * d + 1], bo[2 * d], bo[2 * d + 1], base, a.line_gap, lane, gap[d], end_t[d], stop[d]);
                     else gap_rule(bn[2 * d], bn[2 * d + 1], bo[2 * d], bo[2 * d + 1], base, a.line_gap, lane, gap[d], end_t[d], stop[d]);
                 }
         };
@@ -815,6 +815,9 @@ __device__ __forceinline__ void ppht_serve(const PphtArgs &a, PphtShared &sh, in
     PP_FLUSH
 }
 
+// (NPL, SHORT_GAP) are template parameters of the KERNEL: each launch then runs a body that holds one vote width and one
+// gap rule only (the reference's parameters: 180 angles, lineGap 15 .. 75).
+template <int NPL, bool SHORT_GAP>
 __global__ __launch_bounds__(OMR_PPHT_THREADS) void ppht_kernel(const PphtArgs a)
 {
     __shared__ PphtShared sh;
@@ -832,15 +835,21 @@ __global__ __launch_bounds__(OMR_PPHT_THREADS) void ppht_kernel(const PphtArgs a
     const int wave = tid >> 6;
     if (wave == 1) ppht_draw(a, sh, scan, lane);
     else if (wave >= 2) ppht_help(a, sh, scan, lane, wave - 1);
-    else if (a.numangle <= 192) ppht_serve<3>(a, sh, scan, lane);
-    else ppht_serve<4>(a, sh, scan, lane);
+    else ppht_serve<NPL, SHORT_GAP>(a, sh, scan, lane);
 }
 
 hipError_t launch_ppht(const PphtArgs &a, int n, hipStream_t s)
 {
     if (n <= 0) return hipSuccess;
     if (a.numangle > OMR_PPHT_MAX_ANGLES) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(ppht_kernel, dim3(n), dim3(OMR_PPHT_THREADS), 0, s, a);
+    const bool short_gap = (uint32_t)a.line_gap < 64u;
+    if (a.numangle <= 192) {
+        if (short_gap) hipLaunchKernelGGL((ppht_kernel<3, true>), dim3(n), dim3(OMR_PPHT_THREADS), 0, s, a);
+        else hipLaunchKernelGGL((ppht_kernel<3, false>), dim3(n), dim3(OMR_PPHT_THREADS), 0, s, a);
+    } else {
+        if (short_gap) hipLaunchKernelGGL((ppht_kernel<4, true>), dim3(n), dim3(OMR_PPHT_THREADS), 0, s, a);
+        else hipLaunchKernelGGL((ppht_kernel<4, false>), dim3(n), dim3(OMR_PPHT_THREADS), 0, s, a);
+    }
     return hipGetLastError();
 }
 
