@@ -28,7 +28,7 @@ for d in 0 1 2 4 6 7; do OMR_RUNS_DBG=$d timeout -k 10 120 python3 tools/kdbg.py
 echo "[profile] sweep kernel timings done"
 # 4. stage kernels, FFT, Hough (un-profiled numbers + kernel stats + split counter passes for the Hough stage)
 timeout -k 10 300 python3 tools/bench_stages.py 30 > "$OUT/stages.log" 2>&1 || true
-timeout -k 10 300 python3 tools/bench_fft.py > "$OUT/fft.log" 2>&1 || true
+timeout -k 10 300 python3 tools/bench_fft.py 64 4 > "$OUT/fft.log" 2>&1 || true
 timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/fft_stats" -- python3 tools/bench_fft.py > "$OUT/fft_stats.log" 2>&1 || true
 timeout -k 10 600 python3 tools/bench_hough.py 256 8 2 > "$OUT/hough.log" 2>&1 || true
 timeout -k 10 300 python3 tools/hough_run.py 1 1 5 > "$OUT/hough_single.log" 2>&1 || true
