@@ -16,8 +16,11 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
 @pytest.mark.skipif(not (os.path.exists(HIPCC) or shutil.which("hipcc")), reason="hipcc not available")
 def test_runs_kernel_has_no_spills(tmp_path):
+    # the flags runs.hip is built with: the Makefile's common ones plus its RUNS_FLAGS (scheduler strategy)
+    mk = open(os.path.join(CSRC, "Makefile")).read()
+    extra = re.search(r"^RUNS_FLAGS\s*:=\s*(.*)$", mk, re.M).group(1).split()
     cmd = [HIPCC if os.path.exists(HIPCC) else "hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off",
-           "-fno-fast-math", "-I", CSRC, "-c", os.path.join(CSRC, "runs.hip"), "-Rpass-analysis=kernel-resource-usage",
+           "-fno-fast-math", *extra, "-I", CSRC, "-c", os.path.join(CSRC, "runs.hip"), "-Rpass-analysis=kernel-resource-usage",
            "-o", str(tmp_path / "runs.o")]
     out = subprocess.run(cmd, capture_output=True, text=True, check=True).stderr
     # the production instantiation: runs_kernel<false>
