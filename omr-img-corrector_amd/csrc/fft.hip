@@ -78,7 +78,8 @@ __device__ cfloat *fft_forward_lds(cfloat *in, cfloat *out, const int m, const i
     for (; s < log2m; s += 3) {
         const int Ns = 1 << s;
         __syncthreads();
-        for (int j = tid; j < eighth; j += FFT_THREADS) {
+        // (launch_fft_pass gives a ping-pong transform at least m / 8 threads: one butterfly per thread and stage)
+        if (const int j = tid; j < eighth) {
             const int k = j & (Ns - 1);
             // one twiddle load per butterfly, from the stage's own contiguous table (lanes read neighbouring
             // entries), its powers by complex multiplication: the seven scattered loads W[q * tw] of the plain
