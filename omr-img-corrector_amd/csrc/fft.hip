@@ -38,18 +38,27 @@ __device__ __forceinline__ cfloat cadd(const cfloat a, const cfloat b) { return 
 __device__ __forceinline__ cfloat csub(const cfloat a, const cfloat b) { return cfloat{a.x - b.x, a.y - b.y}; }
 __device__ __forceinline__ cfloat cmul_mi(const cfloat a) { return cfloat{a.y, -a.x}; }  // a * (-i)
 
-template <int NT>
+// PRE: the input of the first stage is conj(in[i] * pre[i]) -- Bluestein's product with the chirp's spectrum and the
+// conjugation of the inverse transform ride on the loads of the second transform's first stage instead of a pass of
+// their own over the buffer.
+template <int NT, bool PRE = false>
 __device__ cfloat *fft_forward_lds(cfloat *in, cfloat *out, const int m, const int log2m,
-                                   const cfloat *__restrict__ Wst, const int tid)
+                                   const cfloat *__restrict__ Wst, const int tid, const cfloat *__restrict__ pre = nullptr)
 {
     int s = 0;
     const int lead = log2m % 3;
     const int Ns0 = 1 << lead;  // Ns of the first radix-8 stage
+    auto first_in = [&](int i) -> cfloat {
+        const cfloat v = in[FPAD(i)];
+        if (!PRE) return v;
+        const cfloat c = cmul(v, pre[i]);
+        return cfloat{c.x, -c.y};
+    };
     if (lead == 1) {  // radix 2, Ns = 1: no twiddles
         const int half = m >> 1;
         __syncthreads();
         for (int j = tid; j < half; j += FFT_THREADS) {
-            const cfloat u0 = in[FPAD(j)], u1 = in[FPAD(j + half)];
+            const cfloat u0 = first_in(j), u1 = first_in(j + half);
             out[FPAD(2 * j)] = cadd(u0, u1);
             out[FPAD(2 * j + 1)] = csub(u0, u1);
         }
@@ -61,7 +70,7 @@ __device__ cfloat *fft_forward_lds(cfloat *in, cfloat *out, const int m, const i
         const int quarter = m >> 2;
         __syncthreads();
         for (int j = tid; j < quarter; j += FFT_THREADS) {
-            const cfloat u0 = in[FPAD(j)], u1 = in[FPAD(j + quarter)], u2 = in[FPAD(j + 2 * quarter)], u3 = in[FPAD(j + 3 * quarter)];
+            const cfloat u0 = first_in(j), u1 = first_in(j + quarter), u2 = first_in(j + 2 * quarter), u3 = first_in(j + 3 * quarter);
             const cfloat a = cadd(u0, u2), b = csub(u0, u2), c = cadd(u1, u3), d = cmul_mi(csub(u1, u3));
             out[FPAD(4 * j)] = cadd(a, c);
             out[FPAD(4 * j + 1)] = cadd(b, d);
@@ -88,14 +97,20 @@ __device__ cfloat *fft_forward_lds(cfloat *in, cfloat *out, const int m, const i
             const cfloat w2 = cmul(w1, w1), w3 = cmul(w2, w1), w4 = cmul(w2, w2);
             const cfloat w5 = cmul(w4, w1), w6 = cmul(w3, w3), w7 = cmul(w4, w3);
             cfloat u[8];
-            u[0] = in[FPAD(j)];
-            u[1] = cmul(in[FPAD(j + eighth)], w1);
-            u[2] = cmul(in[FPAD(j + 2 * eighth)], w2);
-            u[3] = cmul(in[FPAD(j + 3 * eighth)], w3);
-            u[4] = cmul(in[FPAD(j + 4 * eighth)], w4);
-            u[5] = cmul(in[FPAD(j + 5 * eighth)], w5);
-            u[6] = cmul(in[FPAD(j + 6 * eighth)], w6);
-            u[7] = cmul(in[FPAD(j + 7 * eighth)], w7);
+            if (PRE && s == 0) {  // (no leading radix-2 / radix-4 stage: this is the transform's first stage)
+#pragma unroll
+                for (int q = 0; q < 8; q++) u[q] = first_in(j + q * eighth);
+            } else {
+#pragma unroll
+                for (int q = 0; q < 8; q++) u[q] = in[FPAD(j + q * eighth)];
+            }
+            u[1] = cmul(u[1], w1);
+            u[2] = cmul(u[2], w2);
+            u[3] = cmul(u[3], w3);
+            u[4] = cmul(u[4], w4);
+            u[5] = cmul(u[5], w5);
+            u[6] = cmul(u[6], w6);
+            u[7] = cmul(u[7], w7);
             // radix-8 butterfly: y[q] = sum_p u[p] exp(-2 pi i p q / 8)
             const cfloat a0 = cadd(u[0], u[4]), a1 = csub(u[0], u[4]);
             const cfloat a2 = cadd(u[2], u[6]), a3 = cmul_mi(csub(u[2], u[6]));
@@ -239,13 +254,14 @@ __global__ __launch_bounds__(NT) void fft_pass_kernel(FftPass p)
             p.part[2 * blockIdx.x + 1] = hi;
         }
     };
-    // two real rows per workgroup: split Z = FFT(a + i b) into FFT(a) and FFT(b), columns 0 .. n / 2
-    auto emit_pair = [&](const cfloat *Z) {
+    // two real rows per workgroup: split Z = FFT(a + i b) into FFT(a) and FFT(b), columns 0 .. n / 2.  zval(k): point k
+    // of the pair's spectrum (read from LDS; on the Bluestein path the final chirp product is applied on the way)
+    auto emit_pair = [&](auto zval) {
         cfloat *d0 = p.dst + line * dls, *d1 = d0 + dls;
         // transposed output: the two rows' points are neighbours (16 bytes, aligned when the line pitch is even): one store
         const bool wide = second && dls == 1 && (des & 1) == 0 && (((uintptr_t)p.dst) & 15) == 0;
         for (int k = tid; k <= n / 2; k += FFT_THREADS) {
-            const cfloat zk = Z[FPAD(k)], zn = Z[FPAD(k == 0 ? 0 : n - k)];
+            const cfloat zk = zval(k), zn = zval(k == 0 ? 0 : n - k);
             const cfloat a = cfloat{(0.5f * (zk.x + zn.x)) * p.out_scale, (0.5f * (zk.y - zn.y)) * p.out_scale};
             const cfloat b = cfloat{(0.5f * (zk.y + zn.y)) * p.out_scale, (-0.5f * (zk.x - zn.x)) * p.out_scale};
             if (wide) {
@@ -258,7 +274,7 @@ __global__ __launch_bounds__(NT) void fft_pass_kernel(FftPass p)
     };
     if (!blue) {
         if (pairs) {
-            emit_pair(P);
+            emit_pair([&](int k) { return P[FPAD(k)]; });
             return;
         }
         for (int k = tid; k < n; k += FFT_THREADS) emit(k, cfloat{P[FPAD(k)].x * p.out_scale, P[FPAD(k)].y * p.out_scale});
@@ -266,12 +282,12 @@ __global__ __launch_bounds__(NT) void fft_pass_kernel(FftPass p)
         return;
     }
     // convolution with the conjugate chirp: pointwise product, then an inverse FFT as conj(FFT(conj(.))) / m
-    for (int k = tid; k < m; k += FFT_THREADS) {
-        const cfloat c = cmul(P[FPAD(k)], p.Bf[k]);
-        P[FPAD(k)] = cfloat{c.x, -c.y};
-    }
     cfloat *R = P;
-    if (inplace) {  // bit-reverse in place (pairs swap), then the second transform in the same buffer
+    if (inplace) {  // product, bit-reverse in place (pairs swap), then the second transform in the same buffer
+        for (int k = tid; k < m; k += FFT_THREADS) {
+            const cfloat c = cmul(P[FPAD(k)], p.Bf[k]);
+            P[FPAD(k)] = cfloat{c.x, -c.y};
+        }
         __syncthreads();
         for (int k = tid; k < m; k += FFT_THREADS) {
             const int r = (int)(__brev((unsigned)k) >> rshift);
@@ -283,14 +299,11 @@ __global__ __launch_bounds__(NT) void fft_pass_kernel(FftPass p)
         }
         fft_inplace_lds<NT>(P, m, p.log2m, p.Wfull, tid);
     } else {
-        R = fft_forward_lds<NT>(P, Q, m, p.log2m, p.W, tid);
+        R = fft_forward_lds<NT, true>(P, Q, m, p.log2m, p.W, tid, p.Bf);  // (the product rides on the first stage's loads)
     }
     const float inv_m = 1.0f / (float)m;
-    if (pairs) {  // the line's spectrum must be complete in LDS before the two rows can be separated
-        cfloat *Z = inplace ? R : (R == A ? B : A);  // element-wise, so in place is fine
-        for (int k = tid; k < n; k += FFT_THREADS) Z[FPAD(k)] = cmul(cfloat{R[FPAD(k)].x * inv_m, -R[FPAD(k)].y * inv_m}, p.chirp[k]);
-        __syncthreads();
-        emit_pair(Z);
+    if (pairs) {  // (the second transform ended with a barrier: the line's spectrum is complete in LDS)
+        emit_pair([&](int k) { return cmul(cfloat{R[FPAD(k)].x * inv_m, -R[FPAD(k)].y * inv_m}, p.chirp[k]); });
         return;
     }
     for (int k = tid; k < n; k += FFT_THREADS) {
