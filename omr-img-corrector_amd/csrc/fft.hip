@@ -38,22 +38,18 @@ __device__ __forceinline__ cfloat cadd(const cfloat a, const cfloat b) { return 
 __device__ __forceinline__ cfloat csub(const cfloat a, const cfloat b) { return cfloat{a.x - b.x, a.y - b.y}; }
 __device__ __forceinline__ cfloat cmul_mi(const cfloat a) { return cfloat{a.y, -a.x}; }  // a * (-i)
 
-// PRE: the input of the first stage is conj(in[i] * pre[i]) -- Bluestein's product with the chirp's spectrum and the
-// conjugation of the inverse transform ride on the loads of the second transform's first stage instead of a pass of
-// their own over the buffer.
-template <int NT, bool PRE = false>
+// first_in(i): point i of the transform's input.  The first stage reads its input through it, so whatever precedes
+// a transform rides on that stage's loads instead of a pass of its own over an LDS buffer: the scan's pixels or the
+// half spectrum's points from global memory (times the chirp, zero beyond n), or Bluestein's product with the chirp's
+// spectrum and the conjugation of the inverse transform, conj(in[i] * Bf[i]).  The later stages read `in`.
+template <int NT, class F>
 __device__ cfloat *fft_forward_lds(cfloat *in, cfloat *out, const int m, const int log2m,
-                                   const cfloat *__restrict__ Wst, const int tid, const cfloat *__restrict__ pre = nullptr)
+                                   const cfloat *__restrict__ Wst, const int tid, F first_in)
 {
+    constexpr bool PRE = true;
     int s = 0;
     const int lead = log2m % 3;
     const int Ns0 = 1 << lead;  // Ns of the first radix-8 stage
-    auto first_in = [&](int i) -> cfloat {
-        const cfloat v = in[FPAD(i)];
-        if (!PRE) return v;
-        const cfloat c = cmul(v, pre[i]);
-        return cfloat{c.x, -c.y};
-    };
     if (lead == 1) {  // radix 2, Ns = 1: no twiddles
         const int half = m >> 1;
         __syncthreads();
@@ -196,7 +192,7 @@ __global__ __launch_bounds__(NT) void fft_pass_kernel(FftPass p)
     const bool pairs = MODE == 8 ? p.real_pairs != 0 : (MODE & 1) != 0;
     const bool second = pairs && 2 * line + 1 < p.src_rows;
     if (pairs) line *= 2;
-    for (int k = tid; k < m; k += FFT_THREADS) {
+    auto source = [&](int k) -> cfloat {  // point k of the line, as the first transform takes it
         cfloat v{0.f, 0.f};
         if (k < n) {
             if (pairs) {
@@ -207,12 +203,15 @@ __global__ __launch_bounds__(NT) void fft_pass_kernel(FftPass p)
             }
             if (blue) v = cmul(v, p.chirp[k]);
         }
-        const int at = inplace ? (int)(__brev((unsigned)k) >> rshift) : k;
-        A[FPAD(at)] = v;
-    }
+        return v;
+    };
     cfloat *P = A;
-    if (inplace) fft_inplace_lds<NT>(A, m, p.log2m, p.Wfull, tid);
-    else P = fft_forward_lds<NT>(A, B, m, p.log2m, p.W, tid);
+    if (inplace) {
+        for (int k = tid; k < m; k += FFT_THREADS) A[FPAD((int)(__brev((unsigned)k) >> rshift))] = source(k);
+        fft_inplace_lds<NT>(A, m, p.log2m, p.Wfull, tid);
+    } else {
+        P = fft_forward_lds<NT>(B, A, m, p.log2m, p.W, tid, source);  // (first stage: global -> A; B is its unused "in")
+    }
     cfloat *Q = P == A ? B : A;
     cfloat *dst = p.dst + line * dls;
     // spectrum-picture mode (column pass): point k of this line is F(k, line); it lands at the quadrant-swapped
@@ -299,7 +298,10 @@ __global__ __launch_bounds__(NT) void fft_pass_kernel(FftPass p)
         }
         fft_inplace_lds<NT>(P, m, p.log2m, p.Wfull, tid);
     } else {
-        R = fft_forward_lds<NT, true>(P, Q, m, p.log2m, p.W, tid, p.Bf);  // (the product rides on the first stage's loads)
+        R = fft_forward_lds<NT>(P, Q, m, p.log2m, p.W, tid, [&](int i) {  // (the product rides on the first stage's loads)
+            const cfloat c = cmul(P[FPAD(i)], p.Bf[i]);
+            return cfloat{c.x, -c.y};
+        });
     }
     const float inv_m = 1.0f / (float)m;
     if (pairs) {  // (the second transform ended with a barrier: the line's spectrum is complete in LDS)
