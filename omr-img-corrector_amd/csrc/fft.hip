@@ -38,6 +38,36 @@ __device__ __forceinline__ cfloat cadd(const cfloat a, const cfloat b) { return 
 __device__ __forceinline__ cfloat csub(const cfloat a, const cfloat b) { return cfloat{a.x - b.x, a.y - b.y}; }
 __device__ __forceinline__ cfloat cmul_mi(const cfloat a) { return cfloat{a.y, -a.x}; }  // a * (-i)
 
+// 16-point DFT in registers: 4 x 4 decimation (radix-4 over n1, twiddles W16^(n2 k1), radix-4 over n2); x[4 n1 + n2]
+// in, X[k1 + 4 k2] out, in place.
+__device__ __forceinline__ void fft_radix4(cfloat &a0, cfloat &a1, cfloat &a2, cfloat &a3)
+{
+    const cfloat t0 = cadd(a0, a2), t1 = csub(a0, a2), t2 = cadd(a1, a3), t3 = cmul_mi(csub(a1, a3));
+    a0 = cadd(t0, t2);
+    a1 = cadd(t1, t3);
+    a2 = csub(t0, t2);
+    a3 = csub(t1, t3);
+}
+__device__ __forceinline__ void fft_dft16(cfloat (&x)[16])
+{
+    const float c1 = 0.92387953251128675613f, s1 = 0.38268343236508977173f, r2 = 0.70710678118654752440f;
+#pragma unroll
+    for (int n2 = 0; n2 < 4; n2++) fft_radix4(x[n2], x[4 + n2], x[8 + n2], x[12 + n2]);  // -> y[k1][n2] at x[4 k1 + n2]
+    // y[k1][n2] *= W16^(n2 k1), W16 = exp(-2 pi i / 16)
+    auto rot = [](cfloat v, float c, float s) { return cfloat{v.x * c + v.y * s, v.y * c - v.x * s}; };  // v * (c - i s)
+    x[5] = rot(x[5], c1, s1);     // k1 = 1, n2 = 1: W^1
+    x[6] = rot(x[6], r2, r2);     // n2 = 2: W^2
+    x[7] = rot(x[7], s1, c1);     // n2 = 3: W^3
+    x[9] = rot(x[9], r2, r2);     // k1 = 2, n2 = 1: W^2
+    x[10] = cmul_mi(x[10]);       // W^4 = -i
+    x[11] = rot(x[11], -r2, r2);  // W^6
+    x[13] = rot(x[13], s1, c1);   // k1 = 3, n2 = 1: W^3
+    x[14] = rot(x[14], -r2, r2);  // W^6
+    x[15] = rot(x[15], -c1, -s1); // W^9
+#pragma unroll
+    for (int k1 = 0; k1 < 4; k1++) fft_radix4(x[4 * k1], x[4 * k1 + 1], x[4 * k1 + 2], x[4 * k1 + 3]);  // -> X[k1 + 4 k2] at x[4 k1 + k2]
+}
+
 // first_in(i): point i of the transform's input.  The first stage reads its input through it, so whatever precedes
 // a transform rides on that stage's loads instead of a pass of its own over an LDS buffer: the scan's pixels or the
 // half spectrum's points from global memory (times the chirp, zero beyond n), or Bluestein's product with the chirp's
@@ -48,8 +78,12 @@ __device__ cfloat *fft_forward_lds(cfloat *in, cfloat *out, const int m, const i
 {
     constexpr bool PRE = true;
     int s = 0;
-    const int lead = log2m % 3;
+    // log2m = 3 a + 1 (8192, 1024, 128 points): a - 1 radix-8 stages and ONE radix-16 stage at the end instead of a
+    // leading radix-2 stage and a radix-8 stages -- one pass over LDS and one barrier less for the same arithmetic
+    const bool tail16 = log2m % 3 == 1 && log2m >= 7;
+    const int lead = tail16 ? 0 : log2m % 3;
     const int Ns0 = 1 << lead;  // Ns of the first radix-8 stage
+    const int log2m8 = tail16 ? log2m - 4 : log2m;  // bits handled by the leading and the radix-8 stages
     if (lead == 1) {  // radix 2, Ns = 1: no twiddles
         const int half = m >> 1;
         __syncthreads();
@@ -80,7 +114,7 @@ __device__ cfloat *fft_forward_lds(cfloat *in, cfloat *out, const int m, const i
     }
     const int eighth = m >> 3;
     const float r2 = 0.70710678118654752440f;
-    for (; s < log2m; s += 3) {
+    for (; s < log2m8; s += 3) {
         const int Ns = 1 << s;
         __syncthreads();
         // (launch_fft_pass gives a ping-pong transform at least m / 8 threads: one butterfly per thread and stage)
@@ -127,6 +161,28 @@ __device__ cfloat *fft_forward_lds(cfloat *in, cfloat *out, const int m, const i
             out[FPAD(j0 + 5 * Ns)] = csub(b1, b5);
             out[FPAD(j0 + 6 * Ns)] = csub(b2, b6);
             out[FPAD(j0 + 7 * Ns)] = csub(b3, b7);
+        }
+        cfloat *t = in;
+        in = out;
+        out = t;
+    }
+    if (tail16) {  // the last stage, radix 16: Ns = m / 16, so k = j; its twiddles exp(-2 pi i j / m) follow the radix-8 tables
+        const int Ns = 1 << s, sixteenth = m >> 4;
+        __syncthreads();
+        if (const int j = tid; j < sixteenth) {
+            const cfloat w1 = Wst[(Ns - 1) / 7 + j];
+            const cfloat w2 = cmul(w1, w1), w3 = cmul(w2, w1), w4 = cmul(w2, w2), w5 = cmul(w4, w1), w6 = cmul(w3, w3);
+            const cfloat w7 = cmul(w4, w3), w8 = cmul(w4, w4), w9 = cmul(w8, w1), w10 = cmul(w5, w5), w11 = cmul(w8, w3);
+            const cfloat w12 = cmul(w6, w6), w13 = cmul(w8, w5), w14 = cmul(w7, w7), w15 = cmul(w8, w7);
+            const cfloat w[16] = {cfloat{1.f, 0.f}, w1, w2, w3, w4, w5, w6, w7, w8, w9, w10, w11, w12, w13, w14, w15};
+            cfloat u[16];
+#pragma unroll
+            for (int q = 0; q < 16; q++) u[q] = in[FPAD(j + q * sixteenth)];
+#pragma unroll
+            for (int q = 1; q < 16; q++) u[q] = cmul(u[q], w[q]);
+            fft_dft16(u);
+#pragma unroll
+            for (int q = 0; q < 16; q++) out[FPAD(j + q * sixteenth)] = u[4 * (q & 3) + (q >> 2)];  // X[k1 + 4 k2] sits at [4 k1 + k2]
         }
         cfloat *t = in;
         in = out;

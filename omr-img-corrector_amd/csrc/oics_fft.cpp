@@ -78,9 +78,17 @@ struct AxisTables {
                         m, OMR_FFT_MAX_M);
         // twiddles of the radix-8 stages, one contiguous table per stage (Ns = Ns0, 8 Ns0, ... < m)
         std::vector<cfloat> w;
-        for (int Ns = 1 << (log2m % 3); Ns < m; Ns *= 8)
+        // (lengths 2^(3a+1) >= 128 end in one radix-16 stage instead of starting with a radix-2 stage: fft_forward_lds)
+        const bool tail16 = log2m % 3 == 1 && log2m >= 7 && m <= OMR_FFT_MAX_PINGPONG;
+        const int m8 = tail16 ? m / 16 : m;
+        for (int Ns = tail16 ? 1 : 1 << (log2m % 3); Ns < m8; Ns *= 8)
             for (int k = 0; k < Ns; k++) {
                 const double ang = -2.0 * kPi * (double)k / (8.0 * (double)Ns);
+                w.push_back(cfloat{(float)cos(ang), (float)sin(ang)});
+            }
+        if (tail16)
+            for (int k = 0; k < m / 16; k++) {
+                const double ang = -2.0 * kPi * (double)k / (double)m;
                 w.push_back(cfloat{(float)cos(ang), (float)sin(ang)});
             }
         if (w.empty()) w.push_back(cfloat{1.f, 0.f});
