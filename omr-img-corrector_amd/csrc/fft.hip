@@ -116,14 +116,14 @@ __device__ cfloat *fft_forward_lds(cfloat *in, cfloat *out, const int m, const i
     const float r2 = 0.70710678118654752440f;
     for (; s < log2m8; s += 3) {
         const int Ns = 1 << s;
+        // one twiddle load per butterfly, from the stage's own contiguous table (lanes read neighbouring entries),
+        // its powers by complex multiplication: the seven scattered loads W[q * tw] of the plain form touched up to
+        // 64 cache lines per wave-instruction.  Requested BEFORE the barrier: its latency passes while the wave waits.
+        const cfloat w1 = Wst[(Ns - Ns0) / 7 + (min(tid, eighth - 1) & (Ns - 1))];  // exp(-2 pi i k / (8 Ns))
         __syncthreads();
         // (launch_fft_pass gives a ping-pong transform at least m / 8 threads: one butterfly per thread and stage)
         if (const int j = tid; j < eighth) {
             const int k = j & (Ns - 1);
-            // one twiddle load per butterfly, from the stage's own contiguous table (lanes read neighbouring
-            // entries), its powers by complex multiplication: the seven scattered loads W[q * tw] of the plain
-            // form touched up to 64 cache lines per wave-instruction
-            const cfloat w1 = Wst[(Ns - Ns0) / 7 + k];  // exp(-2 pi i k / (8 Ns))
             const cfloat w2 = cmul(w1, w1), w3 = cmul(w2, w1), w4 = cmul(w2, w2);
             const cfloat w5 = cmul(w4, w1), w6 = cmul(w3, w3), w7 = cmul(w4, w3);
             cfloat u[8];
