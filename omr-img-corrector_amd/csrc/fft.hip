@@ -72,9 +72,11 @@ __device__ __forceinline__ void fft_dft16(cfloat (&x)[16])
 // a transform rides on that stage's loads instead of a pass of its own over an LDS buffer: the scan's pixels or the
 // half spectrum's points from global memory (times the chirp, zero beyond n), or Bluestein's product with the chirp's
 // spectrum and the conjugation of the inverse transform, conj(in[i] * Bf[i]).  The later stages read `in`.
+// keep: only points 0 .. keep - 1 of the result are read by the caller (Bluestein's second transform: n of m); the
+// radix-16 tail does not store the others.
 template <int NT, class F>
 __device__ cfloat *fft_forward_lds(cfloat *in, cfloat *out, const int m, const int log2m,
-                                   const cfloat *__restrict__ Wst, const int tid, F first_in)
+                                   const cfloat *__restrict__ Wst, const int tid, F first_in, const int keep = 1 << 30)
 {
     constexpr bool PRE = true;
     int s = 0;
@@ -182,7 +184,8 @@ __device__ cfloat *fft_forward_lds(cfloat *in, cfloat *out, const int m, const i
             for (int q = 1; q < 16; q++) u[q] = cmul(u[q], w[q]);
             fft_dft16(u);
 #pragma unroll
-            for (int q = 0; q < 16; q++) out[FPAD(j + q * sixteenth)] = u[4 * (q & 3) + (q >> 2)];  // X[k1 + 4 k2] sits at [4 k1 + k2]
+            for (int q = 0; q < 16; q++)
+                if (q * sixteenth < keep) out[FPAD(j + q * sixteenth)] = u[4 * (q & 3) + (q >> 2)];  // X[k1 + 4 k2] sits at [4 k1 + k2]
         }
         cfloat *t = in;
         in = out;
@@ -357,7 +360,7 @@ __global__ __launch_bounds__(NT) void fft_pass_kernel(FftPass p)
         R = fft_forward_lds<NT>(P, Q, m, p.log2m, p.W, tid, [&](int i) {  // (the product rides on the first stage's loads)
             const cfloat c = cmul(P[FPAD(i)], p.Bf[i]);
             return cfloat{c.x, -c.y};
-        });
+        }, n);
     }
     const float inv_m = 1.0f / (float)m;
     if (pairs) {  // (the second transform ended with a barrier: the line's spectrum is complete in LDS)
