@@ -126,8 +126,6 @@ __device__ cfloat *fft_forward_lds(cfloat *in, cfloat *out, const int m, const i
         // (launch_fft_pass gives a ping-pong transform at least m / 8 threads: one butterfly per thread and stage)
         if (const int j = tid; j < eighth) {
             const int k = j & (Ns - 1);
-            const cfloat w2 = cmul(w1, w1), w3 = cmul(w2, w1), w4 = cmul(w2, w2);
-            const cfloat w5 = cmul(w4, w1), w6 = cmul(w3, w3), w7 = cmul(w4, w3);
             cfloat u[8];
             if (PRE && s == 0) {  // (no leading radix-2 / radix-4 stage: this is the transform's first stage)
 #pragma unroll
@@ -136,13 +134,17 @@ __device__ cfloat *fft_forward_lds(cfloat *in, cfloat *out, const int m, const i
 #pragma unroll
                 for (int q = 0; q < 8; q++) u[q] = in[FPAD(j + q * eighth)];
             }
-            u[1] = cmul(u[1], w1);
-            u[2] = cmul(u[2], w2);
-            u[3] = cmul(u[3], w3);
-            u[4] = cmul(u[4], w4);
-            u[5] = cmul(u[5], w5);
-            u[6] = cmul(u[6], w6);
-            u[7] = cmul(u[7], w7);
+            if (Ns > 1) {  // (Ns = 1: every twiddle is 1 -- 13 complex products less in a transform's first stage)
+                const cfloat w2 = cmul(w1, w1), w3 = cmul(w2, w1), w4 = cmul(w2, w2);
+                const cfloat w5 = cmul(w4, w1), w6 = cmul(w3, w3), w7 = cmul(w4, w3);
+                u[1] = cmul(u[1], w1);
+                u[2] = cmul(u[2], w2);
+                u[3] = cmul(u[3], w3);
+                u[4] = cmul(u[4], w4);
+                u[5] = cmul(u[5], w5);
+                u[6] = cmul(u[6], w6);
+                u[7] = cmul(u[7], w7);
+            }
             // radix-8 butterfly: y[q] = sum_p u[p] exp(-2 pi i p q / 8)
             const cfloat a0 = cadd(u[0], u[4]), a1 = csub(u[0], u[4]);
             const cfloat a2 = cadd(u[2], u[6]), a3 = cmul_mi(csub(u[2], u[6]));
