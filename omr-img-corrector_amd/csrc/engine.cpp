@@ -46,10 +46,10 @@ struct BlockCache {
     std::multimap<size_t, void *> free_blocks;  // size -> block
     size_t cached = 0;
 };
-BlockCache &cache_of(int dev)
+BlockCache &cache_of(int dev)  // callers check 0 <= dev < 16
 {
     static BlockCache caches[16];
-    return caches[dev & 15];
+    return caches[dev];
 }
 size_t cache_limit()
 {
@@ -66,38 +66,147 @@ size_t round_block(size_t n)
 }
 }  // namespace
 
+// ---- per-call stream + pinned staging buffer: leased from a bounded process-wide pool ------------
+// The host's worker "pool" (thread_pool.rs:41-88) spawns a fresh OS thread per task, so nothing may be owned by
+// a thread: a thread_local stream / staging buffer per caller would leak one HIP stream and one pinned block of
+// the rotated sheet's size per file.  A call leases a slot (its stream keeps the slot's pinned block warm) and
+// returns it; idle slots beyond the caps below are destroyed.
 namespace {
-struct PinnedStage {  // grow-only, one per host thread, never freed (a thread_local destructor could outlive the runtime)
-    void *p = nullptr;
-    size_t cap = 0;
+const size_t kStageMax = (size_t)64 << 20;      // larger results go in pieces
+const int kMaxDevices = 16;
+const int kIdleSlotsPerDevice = 32;             // streams kept for reuse
+const size_t kIdlePinnedBytes = (size_t)512 << 20;  // pinned memory kept for reuse, per device
+
+struct SlotPool {
+    std::mutex mu;
+    std::vector<CallSlot *> idle;
+    size_t idle_pinned = 0;
+    int live = 0;  // slots that exist (leased + idle): what the leak test watches
 };
-thread_local PinnedStage t_stage;
-const size_t kStageMax = (size_t)64 << 20;  // larger results go in pieces
-int stage_reserve(size_t n)
+SlotPool &slots_of(int dev)
+{
+    static SlotPool pools[kMaxDevices];
+    return pools[dev];
+}
+thread_local CallSlot *t_slot = nullptr;  // innermost lease of the calling thread
+
+void destroy_slot(CallSlot *c)
+{
+    if (c->pinned) (void)hipHostFree(c->pinned);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int stage_reserve(CallSlot *c, size_t n)
 {
     n = n > kStageMax ? kStageMax : n;
-    if (t_stage.cap >= n) return 0;
-    if (t_stage.p) (void)hipHostFree(t_stage.p);
-    t_stage.p = nullptr;
-    t_stage.cap = 0;
+    if (c->cap >= n) return 0;
+    if (c->pinned) (void)hipHostFree(c->pinned);
+    c->pinned = nullptr;
+    c->cap = 0;
     const size_t want = (n + ((size_t)1 << 20) - 1) & ~(((size_t)1 << 20) - 1);
-    hipError_t e = hipHostMalloc(&t_stage.p, want, hipHostMallocDefault);
-    if (e != hipSuccess) return fail_gpu("hipHostMalloc (download staging)", e);
-    t_stage.cap = want;
+    hipError_t e = hipHostMalloc(&c->pinned, want, hipHostMallocDefault);
+    if (e != hipSuccess) {
+        c->pinned = nullptr;
+        return fail_gpu("hipHostMalloc (download staging)", e);
+    }
+    c->cap = want;
     return 0;
 }
 }  // namespace
 
-int thread_stream(hipStream_t *out)
+int lease_call_slot(CallSlot **out)
 {
-    thread_local hipStream_t streams[16] = {};
     int dev = 0;
     OMR_HIP(hipGetDevice(&dev));
-    hipStream_t &s = streams[dev & 15];
-    if (!s) OMR_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
-    *out = s;
+    if (dev < 0 || dev >= kMaxDevices) return fail(OMR_ERR_BADARG, "device %d: at most %d devices are supported", dev, kMaxDevices);
+    SlotPool &pool = slots_of(dev);
+    CallSlot *c = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(pool.mu);
+        if (!pool.idle.empty()) {
+            c = pool.idle.back();
+            pool.idle.pop_back();
+            pool.idle_pinned -= c->cap;
+        }
+    }
+    if (!c) {
+        c = new CallSlot;
+        c->dev = dev;
+        hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+        if (e != hipSuccess) {
+            delete c;
+            return fail_gpu("hipStreamCreateWithFlags", e);
+        }
+        std::lock_guard<std::mutex> lk(pool.mu);
+        pool.live++;
+    }
+    c->outer = t_slot;
+    t_slot = c;
+    *out = c;
     return 0;
 }
+
+void return_call_slot(CallSlot *c)
+{
+    if (!c) return;
+    if (t_slot == c) t_slot = c->outer;
+    c->outer = nullptr;
+    SlotPool &pool = slots_of(c->dev);
+    bool keep;
+    {
+        std::lock_guard<std::mutex> lk(pool.mu);
+        keep = (int)pool.idle.size() < kIdleSlotsPerDevice;
+        if (keep && pool.idle_pinned + c->cap > kIdlePinnedBytes) {
+            // keep the stream, give the pinned block back
+            (void)hipHostFree(c->pinned);
+            c->pinned = nullptr;
+            c->cap = 0;
+        }
+        if (keep) {
+            pool.idle.push_back(c);
+            pool.idle_pinned += c->cap;
+        } else {
+            pool.live--;
+        }
+    }
+    if (!keep) {
+        (void)hipStreamSynchronize(c->stream);
+        destroy_slot(c);
+    }
+}
+
+void call_slot_stats(int dev, int *live, int *idle, size_t *idle_pinned)
+{
+    if (dev < 0 || dev >= kMaxDevices) dev = 0;
+    SlotPool &pool = slots_of(dev);
+    std::lock_guard<std::mutex> lk(pool.mu);
+    if (live) *live = pool.live;
+    if (idle) *idle = (int)pool.idle.size();
+    if (idle_pinned) *idle_pinned = pool.idle_pinned;
+}
+
+// RAII lease for copies made outside any entry point's own lease
+namespace {
+struct SlotLease {
+    CallSlot *c = nullptr;
+    bool mine = false;
+    int take(hipStream_t s)
+    {
+        if (t_slot && t_slot->stream == s) {
+            c = t_slot;
+            return 0;
+        }
+        int rc = lease_call_slot(&c);
+        mine = rc == 0;
+        return rc;
+    }
+    ~SlotLease()
+    {
+        if (mine) return_call_slot(c);
+    }
+};
+}  // namespace
 
 int staged_d2h(void *dst, const void *d_src, size_t bytes, hipStream_t s)
 {
@@ -106,13 +215,15 @@ int staged_d2h(void *dst, const void *d_src, size_t bytes, hipStream_t s)
         OMR_HIP(hipStreamSynchronize(s));
         return 0;
     }
-    int rc = stage_reserve(bytes);
+    SlotLease L;
+    int rc = L.take(s);
     if (rc) return rc;
-    for (size_t off = 0; off < bytes; off += t_stage.cap) {
-        const size_t n = bytes - off < t_stage.cap ? bytes - off : t_stage.cap;
-        OMR_HIP(hipMemcpyAsync(t_stage.p, (const char *)d_src + off, n, hipMemcpyDeviceToHost, s));
+    if ((rc = stage_reserve(L.c, bytes))) return rc;
+    for (size_t off = 0; off < bytes; off += L.c->cap) {
+        const size_t n = bytes - off < L.c->cap ? bytes - off : L.c->cap;
+        OMR_HIP(hipMemcpyAsync(L.c->pinned, (const char *)d_src + off, n, hipMemcpyDeviceToHost, s));
         OMR_HIP(hipStreamSynchronize(s));
-        memcpy((char *)dst + off, t_stage.p, n);
+        memcpy((char *)dst + off, L.c->pinned, n);
     }
     return 0;
 }
@@ -121,15 +232,18 @@ int staged_d2h_2d(void *dst, size_t dst_step, const void *d_src, size_t row_byte
 {
     if (dst_step == row_bytes) return staged_d2h(dst, d_src, row_bytes * rows, s);
     if (row_bytes == 0 || rows == 0) return 0;
-    int rc = stage_reserve(row_bytes * rows);
+    SlotLease L;
+    int rc = L.take(s);
     if (rc) return rc;
-    const size_t per = t_stage.cap / row_bytes > 0 ? t_stage.cap / row_bytes : 1;  // rows per piece
-    if (per * row_bytes > t_stage.cap && (rc = stage_reserve(row_bytes))) return rc;
+    if ((rc = stage_reserve(L.c, row_bytes * rows))) return rc;
+    if (L.c->cap < row_bytes && (rc = stage_reserve(L.c, row_bytes))) return rc;
+    if (L.c->cap < row_bytes) return fail(OMR_ERR_BADARG, "image row of %zu bytes exceeds the staging buffer", row_bytes);
+    const size_t per = L.c->cap / row_bytes;  // rows per piece
     for (size_t r0 = 0; r0 < rows; r0 += per) {
         const size_t nr = rows - r0 < per ? rows - r0 : per;
-        OMR_HIP(hipMemcpyAsync(t_stage.p, (const char *)d_src + r0 * row_bytes, nr * row_bytes, hipMemcpyDeviceToHost, s));
+        OMR_HIP(hipMemcpyAsync(L.c->pinned, (const char *)d_src + r0 * row_bytes, nr * row_bytes, hipMemcpyDeviceToHost, s));
         OMR_HIP(hipStreamSynchronize(s));
-        for (size_t r = 0; r < nr; r++) memcpy((char *)dst + (r0 + r) * dst_step, (const char *)t_stage.p + r * row_bytes, row_bytes);
+        for (size_t r = 0; r < nr; r++) memcpy((char *)dst + (r0 + r) * dst_step, (const char *)L.c->pinned + r * row_bytes, row_bytes);
     }
     return 0;
 }
@@ -162,7 +276,7 @@ hipError_t DevBuf::alloc(size_t n)
     if (n == 0) n = 16;
     if (t_pool_on && cache_limit() > 0) {
         int dev = 0;
-        if (hipGetDevice(&dev) == hipSuccess && dev < 16) {
+        if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 16) {
             const size_t want = round_block(n);
             BlockCache &c = cache_of(dev);
             {
@@ -360,49 +474,52 @@ int SweepTables::build_runs()
     host_mode.assign((size_t)A, 0);
     NWh = (cols + 31) / 32;
     Gh = (NWh + OMR_RUN_K - 1) / OMR_RUN_K;
-    const size_t tab_bytes = (size_t)A * (size_t)NWh * sizeof(RunTab);
+    // chunks of word groups per workgroup: as few row-count partials as possible while the grid still has
+    // several workgroups per CU slot (two chunks for an A4 sweep of 400 candidates)
+    Ph = (Gh + OMR_RUN_GC - 1) / OMR_RUN_GC;
+    if (Gh >= 8 && Ph < 2) Ph = 2;
+    GCh = (Gh + Ph - 1) / Ph;
+    Ph = (Gh + GCh - 1) / GCh;
+    NRp = (rows + 7) & ~7;
+    rowsT = (rows + 3) & ~3;
+    {
+        const int NB = (rows + 511) / 512, RBmax = OMR_RUN_MAX_ROWS / 512;
+        RCHh = (NB + RBmax - 1) / RBmax;
+        RBh = (NB + RCHh - 1) / RCHh;
+    }
+    const int NWp = Gh * OMR_RUN_K;
+    const size_t tab_bytes = (size_t)A * (size_t)NWp * sizeof(RunTab);
     if (tab_bytes > ((size_t)3 << 30)) return OMR_OK;  // gather kernels only
-    OMR_HIP(tabsH.alloc(sizeof(RunTab) * (size_t)A * NWh));
+    OMR_HIP(tabsH.alloc(sizeof(RunTab) * (size_t)A * NWp));
     OMR_HIP(metaH.alloc(sizeof(RunMeta) * (size_t)A * NWh));
+    OMR_HIP(metacH.alloc(sizeof(int2_t) * (size_t)A * NWp));
     OMR_HIP(blkH.alloc(sizeof(RunBlk) * (size_t)A * Gh));
     OMR_HIP(mode.alloc(sizeof(int32_t) * (size_t)A));
     OMR_HIP(list_runs.alloc(sizeof(int32_t) * (size_t)A));
     OMR_HIP(list_gather.alloc(sizeof(int32_t) * (size_t)A));
     OMR_HIP(hipMemset(tabsH.p, 0, tabsH.bytes));
     OMR_HIP(launch_runtab(adelta.as<int32_t>(), bdelta.as<int32_t>(), A, cols, NWh, tabsH.as<RunTab>(),
-                          metaH.as<RunMeta>(), blkH.as<RunBlk>(), nullptr));
-    // dry run
+                          metaH.as<RunMeta>(), metacH.as<int2_t>(), blkH.as<RunBlk>(), nullptr));
+    // dry run on an all-white scan: window geometry does not depend on the pixels, so a candidate whose
+    // windows fit once always fits
     DevBuf z0, hp, vp, gd, all;
-    OMR_HIP(z0.alloc(sizeof(uint32_t) * (size_t)rows * dims.wpr));
-    OMR_HIP(hp.alloc(sizeof(uint16_t) * (size_t)A * Gh * rows));
+    OMR_HIP(z0.alloc(sizeof(uint32_t) * (size_t)NWh * rowsT));
+    OMR_HIP(hp.alloc(sizeof(uint16_t) * (size_t)A * Ph * NRp));
     OMR_HIP(vp.alloc(sizeof(uint32_t) * (size_t)A * cols));
     OMR_HIP(gd.alloc(sizeof(int32_t) * (size_t)A));
     OMR_HIP(all.alloc(sizeof(int32_t) * (size_t)A));
     OMR_HIP(hipMemset(z0.p, 0, z0.bytes));
     OMR_HIP(hipMemset(gd.p, 0, gd.bytes));
+    OMR_HIP(hipMemset(vp.p, 0, vp.bytes));
     std::vector<int32_t> idx((size_t)A);
     for (int a = 0; a < A; a++) idx[a] = a;
     OMR_HIP(hipMemcpy(all.p, idx.data(), sizeof(int32_t) * (size_t)A, hipMemcpyHostToDevice));
-    RunPass ph{z0.as<uint32_t>(), rows, dims.wpr, xy0.as<int2_t>(), adelta.as<int32_t>(), bdelta.as<int32_t>(),
-               rows, cols, NWh, tabsH.as<RunTab>(), metaH.as<RunMeta>(), blkH.as<RunBlk>(), hp.as<uint16_t>(), Gh, 0, 1, A};
+    const RunPass ph = run_pass(z0.as<uint32_t>(), hp.as<uint16_t>(), 1);
     OMR_HIP(launch_runs(ph, all.as<int32_t>(), A, gd.as<int32_t>(), vp.as<uint32_t>(), nullptr));
     std::vector<int32_t> g((size_t)A);
     std::vector<RunMeta> mh((size_t)A * NWh);
     OMR_HIP(hipMemcpy(g.data(), gd.p, sizeof(int32_t) * (size_t)A, hipMemcpyDeviceToHost));
     OMR_HIP(hipMemcpy(mh.data(), metaH.p, sizeof(RunMeta) * mh.size(), hipMemcpyDeviceToHost));
-#ifdef OMR_RUNS_DEBUG
-    if (getenv("OMR_DEBUG")) {
-        int ng = 0, nh = 0;
-        for (int a = 0; a < A; a++) {
-            ng += g[a] != 0;
-            bool bh = false;
-            for (int w = 0; w < NWh; w++) bh |= mh[(size_t)a * NWh + w].ok == 0;
-            nh += bh;
-        }
-        fprintf(stderr, "[omr] runs: A=%d guard-fail=%d meta-bad=%d | [0,0]: nlev=%d smax=%d ok=%d\n", A, ng, nh,
-                mh[0].nlev, mh[0].smax, mh[0].ok);
-    }
-#endif
     std::vector<int32_t> lr, lg;
     for (int a = 0; a < A; a++) {
         bool ok = g[a] == 0;
@@ -419,14 +536,40 @@ int SweepTables::build_runs()
     return OMR_OK;
 }
 
+RunPass SweepTables::run_pass(const uint32_t *d_bitsT, uint16_t *d_part, int scans) const
+{
+    RunPass p{};
+    p.srcT = d_bitsT;
+    p.NWt = NWh;
+    p.rowsT = rowsT;
+    p.RT = xy0.as<int2_t>();
+    p.NR = dims.rows;
+    p.NC = dims.cols;
+    p.NWp = Gh * OMR_RUN_K;
+    p.tabs = tabsH.as<RunTab>();
+    p.metac = metacH.as<int2_t>();
+    p.blk = blkH.as<RunBlk>();
+    p.part = d_part;
+    p.G = Gh;
+    p.GC = GCh;
+    p.P = Ph;
+    p.NRp = NRp;
+    p.RB = RBh;
+    p.RCH = RCHh;
+    p.scans = scans;
+    p.A = dims.A;
+    return p;
+}
+
 int SweepScratch::create(const SweepTables &t, int scans_per_launch)
 {
     const SweepDims &d = t.dims;
     const size_t Z = (size_t)(scans_per_launch > 0 ? scans_per_launch : 1);
     zmax = (int)Z;
     if (t.runs_built && t.n_runs > 0) {
-        OMR_HIP(hpart.alloc(sizeof(uint16_t) * Z * (size_t)d.A * t.Gh * d.rows));
+        OMR_HIP(hpart.alloc(sizeof(uint16_t) * Z * (size_t)d.A * t.Ph * t.NRp));
         OMR_HIP(guard.alloc(sizeof(int32_t) * (size_t)d.A));
+        OMR_HIP(bitsT.alloc(sizeof(uint32_t) * Z * (size_t)t.NWh * t.rowsT));
     }
     OMR_HIP(bits.alloc(sizeof(uint32_t) * Z * (size_t)d.rows * d.wpr));
     OMR_HIP(vproj.alloc(sizeof(uint32_t) * Z * (size_t)d.A * d.cols));
@@ -472,17 +615,18 @@ int enqueue_sweep(const SweepTables &t, SweepScratch &s, int kernel_sel, const u
     double *hs = d_h_sd ? d_h_sd : s.hsd.as<double>();
     // The gather kernels accumulate with integer atomics -> vproj / hproj start at 0 when any
     // candidate is gathered; the run-merging kernel overwrites its candidates' rows.
-    if (n_g > 0) {
+    // (the run-merging kernel adds its column counts with atomics too when it sweeps the image in row chunks)
+    if (n_g > 0 || (use_runs && t.RCHh > 1))
         OMR_HIP(hipMemsetAsync(vp, 0, sizeof(uint32_t) * (size_t)scans * d.A * d.cols, stream));
-        OMR_HIP(hipMemsetAsync(hp, 0, sizeof(uint32_t) * (size_t)scans * d.A * d.rows, stream));
-    }
+    if (n_g > 0) OMR_HIP(hipMemsetAsync(hp, 0, sizeof(uint32_t) * (size_t)scans * d.A * d.rows, stream));
     OMR_HIP(launch_pack_bits(d_img, step, d.rows, d.cols, black_max, s.bits.as<uint32_t>(), d.wpr, stream, scans,
                              img_stride));
     if (ev0) OMR_HIP(hipEventRecord(ev0, stream));
     if (use_runs) {
-        RunPass ph{s.bits.as<uint32_t>(), d.rows, d.wpr, t.xy0.as<int2_t>(), t.adelta.as<int32_t>(),
-                   t.bdelta.as<int32_t>(), d.rows, d.cols, t.NWh, t.tabsH.as<RunTab>(), t.metaH.as<RunMeta>(),
-                   t.blkH.as<RunBlk>(), s.hpart.as<uint16_t>(), t.Gh, 0, scans, d.A};
+        // the run-merging kernel reads word columns: the bit images once more, transposed
+        OMR_HIP(launch_transpose_bits(s.bits.as<uint32_t>(), d.rows, d.wpr, s.bitsT.as<uint32_t>(), t.NWh, t.rowsT, stream,
+                                      scans));
+        const RunPass ph = t.run_pass(s.bitsT.as<uint32_t>(), s.hpart.as<uint16_t>(), scans);
         OMR_HIP(launch_runs(ph, t.list_runs.as<int32_t>(), t.n_runs, s.guard.as<int32_t>(), vp, stream));
     }
     for (int z = 0; z < scans && n_g > 0; z++) {  // the gather kernels take one scan per launch
@@ -503,8 +647,8 @@ int enqueue_sweep(const SweepTables &t, SweepScratch &s, int kernel_sel, const u
         stream = post_stream;
     }
     if (use_runs)  // row counts of the run-merged candidates: u16 partials per word group -> hproj
-        OMR_HIP(launch_fold_parts(s.hpart.as<uint16_t>(), t.Gh, d.rows, t.list_runs.as<int32_t>(), t.n_runs, hp, stream,
-                                  scans, d.A));
+        OMR_HIP(launch_fold_parts(s.hpart.as<uint16_t>(), t.Ph, d.rows, t.NRp, t.list_runs.as<int32_t>(), t.n_runs, hp,
+                                  stream, scans, d.A));
     OMR_HIP(launch_stddev(vp, hp, d, vs, hs, stream, scans, /*latency=*/post_stream == nullptr));
     if (d_best) OMR_HIP(launch_argmax_path1(vs, hs, d.A, d_best, stream, scans));
     return OMR_OK;
@@ -696,7 +840,8 @@ int omr_sweep_plan_info(const omr_sweep_plan *plan, int32_t *n_runs, int32_t *n_
     return OMR_OK;
 }
 
-// development aid (not in the public header): phase clocks of runs_kernel under OMR_RUNS_DBG=8
+#ifdef OMR_RUNS_DEBUG
+// development aid (make debug only, not in the public header): phase clocks of runs_kernel
 int omr_debug_runs_stamps(unsigned long long *out8, int reset)
 {
     if (!out8) return fail(OMR_ERR_BADARG, "null output");
@@ -704,6 +849,7 @@ int omr_debug_runs_stamps(unsigned long long *out8, int reset)
     OMR_HIP(debug_runs_stamps(out8, reset != 0));
     return OMR_OK;
 }
+#endif
 
 int omr_sweep_plan_tables(omr_sweep_plan *plan, int32_t a, int32_t *adelta, int32_t *bdelta, int32_t *X0, int32_t *Y0)
 {

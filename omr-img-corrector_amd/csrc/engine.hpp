@@ -68,12 +68,23 @@ struct NoPoolScope {
     bool prev_on_;
 };
 
-// The calling thread's stream for per-call work on the current device: created on first use and kept for the
-// thread's lifetime (hipStreamCreate / hipStreamDestroy per call cost more than a 248x230 sweep and serialise in
-// the runtime when the host's worker pool, thread_pool.rs:41-88, calls in from many threads).  Non-blocking.
-int thread_stream(hipStream_t *out);
+// A per-call stream with a pinned staging block, leased from a bounded per-device pool (engine.cpp).  The
+// host's worker pool (thread_pool.rs:41-88) runs every task on a fresh OS thread, so neither may belong to a
+// thread: creating a stream per call costs more than a 248x230 sweep and serialises in the runtime, keeping
+// one per thread leaks it.  Leases nest (a driver that calls another entry point on its own stream).
+struct CallSlot {
+    hipStream_t stream = nullptr;  // non-blocking
+    void *pinned = nullptr;        // grow-only download staging, at most 64 MB
+    size_t cap = 0;
+    int dev = 0;
+    CallSlot *outer = nullptr;     // the calling thread's enclosing lease
+};
+int lease_call_slot(CallSlot **out);  // on the current device; fails for devices >= 16
+void return_call_slot(CallSlot *c);   // the caller has drained c->stream (or only queued work that owns nothing)
+void call_slot_stats(int dev, int *live, int *idle, size_t *idle_pinned);
 
-// Device -> pageable host memory through a per-thread pinned staging buffer.  A direct hipMemcpy into a freshly
+// Device -> pageable host memory through the pinned staging block of the call's slot (the calling thread's
+// innermost lease when it owns `s`, a temporary lease otherwise).  A direct hipMemcpy into a freshly
 // malloc'ed result image makes the runtime pin the destination pages on the fly: 13 ms for the 5 MB rotated sheet
 // of correct_default (72 files/s) against 0.6 ms through the staging buffer.  Synchronises `s`.
 int staged_d2h(void *dst, const void *d_src, size_t bytes, hipStream_t s);
@@ -98,18 +109,24 @@ struct SweepTables {
     // run-merging ("S") kernel: per-(candidate, word) run tables and the split of the candidates
     // into run-merged ones and ones left to the gather kernels
     bool runs_built = false;
-    int NWh = 0, Gh = 0;
-    DevBuf tabsH, metaH, blkH, list_runs, list_gather, mode;
+    int NWh = 0, Gh = 0;    // words per row, word groups (of OMR_RUN_K words)
+    int GCh = 0, Ph = 0;    // word groups per workgroup chunk, chunks
+    int RBh = 0, RCHh = 0;  // bands of 512 rows per row chunk, row chunks (1 unless the image is taller than 4608 rows)
+    int NRp = 0, rowsT = 0; // row pitch of the u16 row-count partials; rows per word column of the transposed bit image
+    DevBuf tabsH, metaH, metacH, blkH, list_runs, list_gather, mode;
     int n_runs = 0, n_gather = 0;
     std::vector<int32_t> host_mode;
     int create(int rows, int cols, const double *fwd_M, int A, int device);
     int build_runs();
+    // arguments of the run-merging kernel for `scans` transposed bit images at d_bitsT
+    RunPass run_pass(const uint32_t *d_bitsT, uint16_t *d_part, int scans) const;
 };
 
 // Mutable per-stream scratch: bit image, integer projections, scores.
 struct SweepScratch {
     DevBuf bits, vproj, hproj, vsd, hsd, best;
-    DevBuf hpart, guard;  // run-merging scratch: u16 row-count partials per word group
+    DevBuf hpart, guard;  // run-merging scratch: u16 row-count partials per chunk of word groups
+    DevBuf bitsT;         // run-merging scratch: the bit images transposed (word columns contiguous)
     int zmax = 1;         // scans a launch may carry (every buffer above holds that many result sets)
     int create(const SweepTables &t, int scans_per_launch = 1);
 };

@@ -14,6 +14,7 @@ namespace hh {
 
 struct HStream {
     hipStream_t s = nullptr;
+    CallSlot *slot = nullptr;         // leased for the call: stream + pinned staging (engine.cpp)
     std::unique_ptr<PoolScope> pool;  // the call's device buffers come from / return to the block cache
     ~HStream();
     int create();

@@ -53,9 +53,9 @@ hipError_t launch_sweep_lds(const uint32_t *d_bits, SweepDims d, const int32_t *
 //     bit(r, c) = src[(RT[r].y + CB[c]) >> 10][(RT[r].x + CA[c]) >> 10],   RT = (X0, Y0), CA = adelta, CB = bdelta,
 // and counts them per destination row and per destination column.
 #define OMR_RUN_TUPLES 40
-#ifndef OMR_RUN_K
-#define OMR_RUN_K 8  // destination words per run-merging block (partials are per group of OMR_RUN_K words)
-#endif
+#define OMR_RUN_K 4          // destination words per word group of the run-merging kernel
+#define OMR_RUN_GC 16        // most word groups one workgroup walks (a "chunk"; row-count partials are per chunk)
+#define OMR_RUN_MAX_ROWS 4608  // rows the kernel's LDS row counters hold; taller images are swept in row chunks
 struct RunTab {                        // per (candidate, 32-column word); 3648 B, 16-B aligned
     // [id][level]: destination bits that read source row `level`; levels 0-3 and 4-7 are kept in two planes of
     // 16-byte entries: a wave's lanes use up to ~14 consecutive ids at once, and 32-byte entries put ids 8
@@ -82,33 +82,40 @@ struct RunBlk {  // per (candidate, word group): what a sweep block needs before
     int32_t cb_min, cb_max;  // CB likewise
     int32_t lagbits;      // 2 bits per word pair: the pair's largest column lag
 };
-struct RunPass {  // one orientation
-    const uint32_t *src;  // bit image of this orientation
-    int32_t src_rows, src_wpr;
-    const int2_t *RT;     // [A][NR]
-    const int32_t *CA;    // [A][NC]
-    const int32_t *CB;    // [A][NC]
-    int32_t NR, NC, NW;   // NW = ceil(NC / 32)
-    const RunTab *tabs;   // [A][NW]
-    const RunMeta *meta;  // [A][NW]
-    const RunBlk *blk;    // [A][G]
-    uint16_t *part;       // [A][G][NR] partial counts, G = ceil(NW / OMR_RUN_K)
-    int32_t G;
-    int32_t dbg;          // development switches (0 in production)
-    int32_t scans;        // scans per launch (blockIdx.z): src, part and vproj hold them back to back
-    int32_t A;            // candidates of the plan (stride of part / vproj between scans)
+struct RunPass {
+    const uint32_t *srcT;  // transposed bit images of the launch's scans: [scan][NWt][rowsT]
+    int32_t NWt, rowsT;    // word columns, rows per word column (a multiple of 4; zero below the image)
+    const int2_t *RT;      // [A][NR] (X0, Y0)
+    int32_t NR, NC;        // destination rows, columns
+    int32_t NWp;           // words per candidate in tabs / metac: G * OMR_RUN_K (the last group is padded)
+    const RunTab *tabs;    // [A][NWp]
+    const int2_t *metac;   // [A][NWp] (ca0, cb0)
+    const RunBlk *blk;     // [A][G]
+    uint16_t *part;        // [scan][A][P][NRp] row counts per chunk of word groups
+    int32_t G;             // word groups: ceil(ceil(NC / 32) / OMR_RUN_K)
+    int32_t GC, P;         // word groups per chunk, chunks (P = ceil(G / GC))
+    int32_t NRp;           // row pitch of part (even)
+    int32_t RB, RCH;       // bands of 512 rows per row chunk (RB * 512 <= OMR_RUN_MAX_ROWS), row chunks
+    int32_t scans;         // scans per launch (blockIdx.x)
+    int32_t A;             // candidates of the plan (stride of part / vproj between scans)
 };
+// run tables of every (candidate, word): d_tabs [A][G * OMR_RUN_K], d_meta [A][NW], d_metac [A][G * OMR_RUN_K], d_blk [A][G]
 hipError_t launch_runtab(const int32_t *d_CA, const int32_t *d_CB, int A, int NC, int NW, RunTab *d_tabs,
-                         RunMeta *d_meta, RunBlk *d_blk, hipStream_t s);
+                         RunMeta *d_meta, int2_t *d_metac, RunBlk *d_blk, hipStream_t s);
+// bit images [scan][rows][wpr] -> transposed [scan][NW][rowsT]
+hipError_t launch_transpose_bits(const uint32_t *d_bits, int rows, int wpr, uint32_t *d_T, int NW, int rowsT,
+                                 hipStream_t s, int scans = 1);
 // d_list: n_list candidate indices; d_guard[a] != 0 when a window did not fit for candidate a.
-// Row counts go to p.part (u16 partials per word group), column counts to d_vproj[a][NC] (complete,
-// plain stores).
+// Row counts go to p.part (u16 partials per chunk of word groups), column counts to d_vproj[scan][a][NC]
+// (complete, plain stores).
 hipError_t launch_runs(const RunPass &p, const int32_t *d_list, int n_list, int32_t *d_guard, uint32_t *d_vproj,
                        hipStream_t s);  // p.scans launches' worth of blocks in one grid
-// hproj[a][r] = sum of the G partial row counts, for the listed (run-merged) candidates
-// development aid: phase clocks summed by runs_kernel when OMR_RUNS_DBG=8 (see runs.hip)
+#ifdef OMR_RUNS_DEBUG
+// development aid (make debug only): phase clocks summed by runs_kernel
 hipError_t debug_runs_stamps(unsigned long long out[8], bool reset);
-hipError_t launch_fold_parts(const uint16_t *d_part, int G, int NR, const int32_t *d_list, int n_list,
+#endif
+// hproj[a][r] = sum of the P partial row counts, for the listed (run-merged) candidates
+hipError_t launch_fold_parts(const uint16_t *d_part, int P, int NR, int NRp, const int32_t *d_list, int n_list,
                              uint32_t *d_proj, hipStream_t s, int scans = 1, int A = 0);
 
 // calculate.rs:13-23 on the integer projections: one block per (candidate, axis).

@@ -85,12 +85,18 @@ struct DevImage {
 
 struct Stream {
     hipStream_t s = nullptr;
+    CallSlot *slot = nullptr;         // leased for the call: stream + pinned staging (engine.cpp)
     std::unique_ptr<PoolScope> pool;  // the call's device buffers come from / return to the block cache
-    ~Stream() { pool.reset(); }  // the stream belongs to the thread (engine.cpp thread_stream), not to the call
+    ~Stream()
+    {
+        pool.reset();  // drains the stream for the buffers it returns
+        return_call_slot(slot);
+    }
     int create()
     {
-        int rc = thread_stream(&s);
+        int rc = lease_call_slot(&slot);
         if (rc) return rc;
+        s = slot->stream;
         pool.reset(new PoolScope(s));
         return OMR_OK;
     }

@@ -31,12 +31,17 @@ namespace hh {
 
 int HStream::create()
 {
-    int rc = thread_stream(&s);  // the calling thread's stream, kept across calls
+    int rc = lease_call_slot(&slot);  // a pooled stream, returned when the call ends
     if (rc) return rc;
+    s = slot->stream;
     pool.reset(new PoolScope(s));
     return OMR_OK;
 }
-HStream::~HStream() { pool.reset(); }
+HStream::~HStream()
+{
+    pool.reset();
+    return_call_slot(slot);
+}
 
 int have_device()
 {

@@ -1,4 +1,4 @@
-// runs.hip -- the run-merging ("S") sweep kernels for gfx950.
+// runs.hip -- the run-merging ("S") sweep kernel for gfx950.
 //
 // Why: the gather kernels (kernels.hip) spend ~12 VALU operations per destination sample and are
 // VALU-issue bound (profiles/r01_pmc_sweep.md).  For the small angles of a deskew sweep a
@@ -12,9 +12,15 @@
 // (candidate, word, fraction): the plan ENUMERATES all 1024 fractions per (candidate, word) from the
 // integer tables of OpenCV's warpAffine (no threshold arithmetic, so bit-exact by construction) and
 // stores the <= 33 distinct mask tuples (RunTab).  Per word the kernel then needs two byte look-ups,
-// one 32-bit unaligned window per source row (LDS, ds_read2 + v_alignbit), and one and/or per row.
-// Row counts come from this pass on the bit image, column counts from the SAME pass on the
-// transposed bit image with the tables' roles swapped -- no cross-lane reduction anywhere.
+// one 32-bit unaligned window per source row (two LDS dwords + v_alignbit), and one and/or per row.
+//
+// Round-3 structure: nothing on the way into LDS passes through registers.
+// The scan's bit image is kept TRANSPOSED in HBM (word column x = rows contiguous dwords), the window
+// of a band is column-major in LDS, so one `buffer_load_dwordx4 ... lds` moves 256 rows of one word
+// column as whole cache lines, lane = row reads are bank-conflict free at any window height, and the
+// windows and run tables of the NEXT step are in flight while the current one is computed (two
+// window buffers, two table buffers, one barrier per band).  A workgroup walks a chunk of word
+// groups of one candidate, so the row counts stay in LDS until the chunk is done.
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
 
@@ -24,38 +30,41 @@
 
 namespace omr {
 
-// Development switches exist only in the debug build (`make debug`, -DOMR_RUNS_DEBUG, loaded by
-// tools/kstamps.py): a release library reads no environment variable and has no stage-skipping path.
-#ifdef OMR_RUNS_DEBUG
-#define RUN_DBG(p) ((p).dbg)
-#else
-#define RUN_DBG(p) 0
-#endif
-
-#define RUN_K OMR_RUN_K    // destination words per block column group (kernels.hpp)
+#define RUN_K OMR_RUN_K    // destination words per word group (kernels.hpp)
 #define RUN_BAND 512       // destination rows per band (8 waves x 64 lanes)
-#define RUN_QUADS ((RUN_K * 32 + 127 + 96) / 128 + 2)  // aligned 4-word pieces per window row
-#define RUN_PITCH (RUN_QUADS * 4 + 1)  // window row pitch in words (data words + 1 spill word), odd
-#define RUN_PITCHB (RUN_PITCH * 4)
-#define RUN_WIN_ROWS 588   // window rows; 588 x 84 B also holds the 8 x 3 x 512 counter words of a flush
+#define RUN_WCOLS 9        // window: word columns ...
+#define RUN_WROWS 576      // ... of this many rows each (column-major, 16-byte pieces of 4 rows)
+#define RUN_WIN_BYTES (RUN_WCOLS * RUN_WROWS * 4)
 #define RUN_TAB_BYTES 3648
 #define RUN_TUPHI_OFS 640
 #define RUN_TUPX_OFS 1280
 #define RUN_IDXY_OFS 1600
 #define RUN_IDXX_OFS 2624
-// LDS layout: window first (so a level's row offset fits ds_read2's 8-bit offset fields), then
-// the RUN_K (ca0, cb0) pairs, then the RUN_K run tables
-#define RUN_WIN_OFS 0
-#define RUN_META_OFS (RUN_WIN_ROWS * RUN_PITCHB)
-#define RUN_TABS_OFS (RUN_META_OFS + RUN_K * 8)
-#define RUN_COL_OFS (RUN_TABS_OFS + RUN_K * RUN_TAB_BYTES)  // column totals of the block, u32[RUN_K * 32]
-#define RUN_LDS_BYTES (RUN_COL_OFS + RUN_K * 32 * 4)
-// no static LDS in runs_kernel: the dynamic segment then starts at LDS address 0 and every table
-// offset folds into the ds_read immediate
-static_assert(2 * RUN_LDS_BYTES <= 160 * 1024, "two blocks per CU");
+#define RUN_TABSET_BYTES (RUN_K * RUN_TAB_BYTES)
+// LDS map.  The two table sets start at multiples of 1024 (a set's base is OR-ed under the 10-bit
+// fraction / the shifted tuple id, the word's offset is the ds_read immediate).
+#define RUN_TAB0_OFS 0
+#define RUN_META_OFS RUN_TABSET_BYTES                       // [2 sets][RUN_K] (ca0, cb0)
+#define RUN_TAB1_OFS 15360
+#define RUN_WIN0_OFS (RUN_TAB1_OFS + RUN_TABSET_BYTES)      // 29952
+#define RUN_WIN1_OFS (RUN_WIN0_OFS + RUN_WIN_BYTES)         // 50688
+#define RUN_GEO_OFS (RUN_WIN1_OFS + RUN_WIN_BYTES)          // 71424: band corners + word-group constants
+#define RUN_GEO_BANDS 12
+#define RUN_GEO_BYTES (RUN_GEO_BANDS * 16 + OMR_RUN_GC * 32)
+#define RUN_HROW_OFS (RUN_GEO_OFS + 1024)                   // row counts of the chunk, two u16 per dword
+#define RUN_LDS_BYTES (RUN_HROW_OFS + OMR_RUN_MAX_ROWS * 2)
+static_assert(RUN_K == 4, "one (word, 16-column half) per wave in the column reduction");
+static_assert(RUN_META_OFS + 2 * RUN_K * 8 <= RUN_TAB1_OFS, "meta fits the gap between the table sets");
+static_assert(RUN_TAB1_OFS % 1024 == 0 && RUN_TAB0_OFS % 1024 == 0, "table sets are 1024-aligned");
+static_assert(RUN_GEO_BYTES <= 1024, "geometry scratch");
+static_assert(OMR_RUN_MAX_ROWS <= RUN_GEO_BANDS * RUN_BAND, "bands of the tallest image");
+static_assert(2 * RUN_LDS_BYTES <= 160 * 1024, "two workgroups per CU");
+static_assert(RUN_WROWS % 64 == 0, "a 16-byte piece never straddles two columns");
+static_assert(RUN_K * 4 * 256 * 4 <= RUN_WIN_BYTES, "the column counters of a flush park in a window buffer");
 
 static_assert(sizeof(RunTab) == RUN_TAB_BYTES, "RunTab layout");
 static_assert(sizeof(RunMeta) == 32, "RunMeta layout");
+static_assert(sizeof(RunBlk) == 32, "RunBlk layout");
 
 // ------------------------------------------------------------------------------------------
 // RunTab builder: block = one (candidate, word), thread = one 10-bit fraction f.
@@ -73,20 +82,23 @@ __device__ __forceinline__ int block_dedupe_1024(bool change, int *s_wave)
     return base + before;
 }
 
+// Words NW .. NWp-1 pad the last word group: copies of the last real word (every lane address stays
+// meaningful) whose level masks are EMPTY, so they add nothing to any count.
 __global__ __launch_bounds__(1024) void runtab_kernel(const int32_t *__restrict__ CA, const int32_t *__restrict__ CB,
-                                                      int NC, int NW, RunTab *__restrict__ tabs,
-                                                      RunMeta *__restrict__ meta)
+                                                      int NC, int NW, int NWp, RunTab *__restrict__ tabs,
+                                                      RunMeta *__restrict__ meta, int2_t *__restrict__ metac)
 {
     __shared__ int s_ca[32], s_cb[32];
     __shared__ uint32_t s_tup[1024][9];  // padded: conflict-free row compare
     __shared__ int s_wave[16];
     __shared__ int s_bad, s_smax;
-    const int w = blockIdx.x, a = blockIdx.y, c0 = w * 32, f = threadIdx.x;
+    const int wp = blockIdx.x, a = blockIdx.y, w = min(wp, NW - 1), c0 = w * 32, f = threadIdx.x;
+    const bool real = wp < NW;
     const int32_t *ca_row = CA + (int64_t)a * NC, *cb_row = CB + (int64_t)a * NC;
     if (f < 32) {
-        // columns past the end of the row (last word only) are don't-cares: the pass kernel masks
-        // them with RunMeta::valid.  Give them lag 0 and the row of the last real column so they add
-        // neither a level nor a validity failure.
+        // columns past the end of the row (last word only) are don't-cares: their destination bits are
+        // masked out of the level masks below.  Give them lag 0 and the row of the last real column so
+        // they add neither a level nor a validity failure.
         const int c = min(c0 + f, NC - 1);
         s_ca[f] = (c0 + f < NC) ? ca_row[c] - ca_row[c0] : 1024 * f;
         s_cb[f] = cb_row[c] - cb_row[c0];
@@ -136,14 +148,15 @@ __global__ __launch_bounds__(1024) void runtab_kernel(const int32_t *__restrict_
         for (int lv = 0; lv < 8; lv++) change |= s_tup[f - 1][lv] != my[lv];
     }
     int idy = block_dedupe_1024(change, s_wave) + (change ? 1 : 0) - 1;  // inclusive count - 1
-    RunTab *T = tabs + ((int64_t)a * NW + w);
+    RunTab *T = tabs + ((int64_t)a * NWp + wp);
+    // destination bits that exist (last word of a row; none in a padding word): folded into the level
+    // masks, so the sweep kernel needs no per-word validity mask (the lag merge happens before the
+    // level select)
+    const uint32_t valid = !real ? 0u : ((c0 + 32 <= NC) ? 0xffffffffu : ((1u << (NC - c0)) - 1u));
     if (idy >= OMR_RUN_TUPLES) {
         bad = true;
         idy = 0;
     } else if (change) {
-        // destination bits that exist (last word of a row): folded into the level masks, so the sweep
-        // kernel needs no per-word validity mask (the lag merge happens before the level select)
-        const uint32_t valid = (c0 + 32 <= NC) ? 0xffffffffu : ((1u << (NC - c0)) - 1u);
 #pragma unroll
         for (int lv = 0; lv < 4; lv++) {
             T->tupYlo[idy][lv] = my[lv] & valid;
@@ -186,10 +199,11 @@ __global__ __launch_bounds__(1024) void runtab_kernel(const int32_t *__restrict_
         m.cb0 = cb_row[c0] + base_off * 1024;
         m.nlev = nlev;
         m.smax = s_smax;
-        m.valid = (c0 + 32 <= NC) ? 0xffffffffu : ((1u << (NC - c0)) - 1u);
+        m.valid = valid;
         m.ok = s_bad ? 0 : 1;
         m.pad0 = m.pad1 = 0;
-        meta[(int64_t)a * NW + w] = m;
+        if (real) meta[(int64_t)a * NW + w] = m;
+        metac[(int64_t)a * NWp + wp] = int2_t{m.ca0, m.cb0};
     }
 }
 
@@ -226,30 +240,67 @@ __global__ __launch_bounds__(256) void runblk_kernel(const int32_t *__restrict__
 }
 
 hipError_t launch_runtab(const int32_t *d_CA, const int32_t *d_CB, int A, int NC, int NW, RunTab *d_tabs,
-                         RunMeta *d_meta, RunBlk *d_blk, hipStream_t s)
+                         RunMeta *d_meta, int2_t *d_metac, RunBlk *d_blk, hipStream_t s)
 {
-    hipLaunchKernelGGL(runtab_kernel, dim3(NW, A), dim3(1024), 0, s, d_CA, d_CB, NC, NW, d_tabs, d_meta);
+    const int G = (NW + RUN_K - 1) / RUN_K;
+    hipLaunchKernelGGL(runtab_kernel, dim3(G * RUN_K, A), dim3(1024), 0, s, d_CA, d_CB, NC, NW, G * RUN_K, d_tabs, d_meta,
+                       d_metac);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    const int G = (NW + RUN_K - 1) / RUN_K;
     hipLaunchKernelGGL(runblk_kernel, dim3((A * G + 255) / 256), dim3(256), 0, s, d_CA, d_CB, A, NC, NW, G, d_meta,
                        d_blk);
     return hipGetLastError();
 }
 
 // ------------------------------------------------------------------------------------------
-// The sweep kernel.  Block = (candidate, group of RUN_K words = 256 destination columns); it walks
-// ALL destination rows in bands of 512 (8 waves x 64 lanes, lane = destination row).
-//   row counts   : popcount of the lane's words, one u16 partial per (row, word group)
-//   column counts: every lane keeps a 3-plane bit-sliced counter per word (its rows of up to 7
-//                  bands); the counters are reduced across the 64 lanes with one
-//                  v_add_co_u32 (shift + carry-out = ballot of the top bit) and one s_bcnt1 per bit,
-//                  added up in LDS over the 8 waves and stored once per block (no atomics).
+// Bit image -> transposed bit image: T[x][y] = word x of row y, rowsT (a multiple of 4) dwords per word
+// column, zero below the image.  32 x 32 word tiles through LDS: 128-byte reads and 128-byte writes.
+__global__ __launch_bounds__(256) void transpose_bits_kernel(const uint32_t *__restrict__ bits, int rows, int wpr,
+                                                             uint32_t *__restrict__ T, int NW, int rowsT)
+{
+    __shared__ uint32_t tile[32][33];
+    bits += (int64_t)blockIdx.z * rows * wpr;  // blockIdx.z = scan of the launch
+    T += (int64_t)blockIdx.z * NW * rowsT;
+    const int x0 = blockIdx.x * 32, y0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int y = y0 + ty + 8 * j, x = x0 + tx;
+        tile[ty + 8 * j][tx] = (y < rows && x < wpr) ? bits[(int64_t)y * wpr + x] : 0u;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int x = x0 + ty + 8 * j, y = y0 + tx;
+        if (x < NW && y < rowsT) T[(int64_t)x * rowsT + y] = tile[tx][ty + 8 * j];
+    }
+}
+
+hipError_t launch_transpose_bits(const uint32_t *d_bits, int rows, int wpr, uint32_t *d_T, int NW, int rowsT,
+                                 hipStream_t s, int scans)
+{
+    hipLaunchKernelGGL(transpose_bits_kernel, dim3((NW + 31) / 32, (rowsT + 31) / 32, scans), dim3(256), 0, s, d_bits,
+                       rows, wpr, d_T, NW, rowsT);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// The sweep kernel.  Workgroup = (scan, chunk of word groups, candidate); it walks the chunk's word
+// groups (RUN_K words = 128 destination columns each) one after the other and, inside a group, ALL
+// destination rows in bands of 512 (8 waves x 64 lanes, lane = destination row, every lane builds the
+// group's RUN_K words of its row).
+//   row counts   : popcount of the lane's words, added to the chunk's per-row count in LDS (two u16 per
+//                  dword); written once per workgroup as a u16 partial per (row, chunk)
+//   column counts: every lane keeps a 3-plane bit-sliced counter per word (its rows of up to 7 bands);
+//                  at the end of a group lane pairs add their counters (DPP), park them in the window
+//                  buffer that was just consumed, and wave w sums the 256 parked numbers of (word w/2,
+//                  column half w%2) lane-wise, then over its 64 lanes with one v_add_co_u32 (shift +
+//                  carry-out = ballot of the top bit) and one s_bcnt1 per bit.  Plain stores, no atomics.
 // LDS accesses of the inner loop take INTEGER byte addresses (the dynamic segment starts at LDS address
-// 0, checked once per block): table offsets then fold into the ds_read immediates and no per-access
-// "base + offset" VALU add is left.
+// 0, checked once per block): table offsets then fold into the ds_read immediates.
 typedef __attribute__((address_space(3))) const uint8_t lds_cu8;
 typedef __attribute__((address_space(3))) const uint32_t lds_cu32;
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
 typedef uint32_t v2u32 __attribute__((ext_vector_type(2)));
 typedef uint32_t v4u32 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) const v2u32 lds_cu2;
@@ -270,6 +321,39 @@ __device__ __forceinline__ int4 ldsr_i4(uint32_t a)
 {
     const v4u32 v = *(lds_cu4 *)(uintptr_t)a;
     return make_int4((int)v.x, (int)v.y, (int)v.z, (int)v.w);
+}
+__device__ __forceinline__ void ldsw_u32(uint32_t a, uint32_t v) { *(lds_u32 *)(uintptr_t)a = v; }
+
+// ---- LDS-DMA.  `buffer_load_dword(x4) ... lds` writes M0 + 4 (16) * lane: 64 consecutive dwords (pieces)
+// per wave-instruction, each from the lane's own buffer offset; a lane whose offset is outside
+// [0, num_records) lands as zeros (tools/lds_dma_window.hip checks both on the hardware).  Issued as
+// inline assembly: the compiler then neither tracks them in its vmcnt bookkeeping (it would wait for
+// them before the first LDS read that follows) nor needs to -- the band loop waits with an explicit
+// `s_waitcnt vmcnt(0)` at the one place where their data is needed.
+// raw buffer descriptor (stride 0, no swizzle, DATA_FORMAT 32)
+__device__ __forceinline__ v4u32 make_rsrc(const void *base, uint32_t nbytes)
+{
+    const uint64_t b = (uint64_t)base;
+    v4u32 r;
+    r.x = __builtin_amdgcn_readfirstlane((uint32_t)b);
+    r.y = __builtin_amdgcn_readfirstlane((uint32_t)(b >> 32) & 0xffffu);
+    r.z = __builtin_amdgcn_readfirstlane(nbytes);
+    r.w = 0x00020000u;
+    return r;
+}
+__device__ __forceinline__ void dma_b32(const v4u32 rsrc, uint32_t voff, uint32_t lds_base)
+{
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, 0 offen lds"
+                 :
+                 : "s"(__builtin_amdgcn_readfirstlane(lds_base)), "v"(voff), "s"(rsrc)
+                 : "memory", "m0");
+}
+__device__ __forceinline__ void dma_b128(const v4u32 rsrc, uint32_t voff, uint32_t lds_base)
+{
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
+                 :
+                 : "s"(__builtin_amdgcn_readfirstlane(lds_base)), "v"(voff), "s"(rsrc)
+                 : "memory", "m0");
 }
 
 template <int LANE>
@@ -316,7 +400,6 @@ __device__ __forceinline__ uint32_t shl1_sum6(uint32_t &p0, uint32_t &p1, uint32
 // only the plain two-VGPR-source VOP2 ops (v_add/sub, v_and/or/xor, v_lshrrev, v_ashrrev, v_mov) issue in
 // 2 cycles per wave64; every VOP3 op (v_alignbit, v_bfi, v_and_or, v_lshl_add, v_mad_u32_u24, v_bcnt, v_bfe),
 // v_lshlrev_b32, v_mul_u32_u24 and any VOP2 with an SGPR source take 4; v_cndmask on an SGPR mask far more.
-// One word = 22 cycles of addressing + (8 NLEV - 2) of merge + 10 of column counters + 4 of row count.
 
 // one word: NLEV unaligned 32-bit windows -> destination word
 template <int NLEV, int SMAX>
@@ -348,173 +431,195 @@ __device__ __forceinline__ void count_columns(uint32_t &c0, uint32_t &c1, uint32
 
 // One pair of words of one band for one wave.  Both words are in flight together: both fraction
 // look-ups and all 2 x NLEV window reads are issued before anything is consumed (LDS latency hiding at
-// 4 waves per SIMD).  Words past the end of the row were staged with
-// empty level masks, the last word's masks carry the row-end mask (runtab_kernel), rows past the end
-// of the image are EXEC-masked by the caller: nothing to mask here.
+// 4 waves per SIMD).  Padding words were built with empty level masks, the last word's masks carry the
+// row-end mask (runtab_kernel), rows past the end of the image are EXEC-masked by the caller: nothing
+// to mask here.  `tabv` is the byte address of the step's table set (a multiple of 1024), `metav` of
+// its (ca0, cb0) pairs; the window's base and first row are folded into (rx, ry) by the caller.
 template <int NLEV, int SMAX, int K>
-__device__ __forceinline__ uint32_t pair_words(const int rx, const int ry, uint32_t (&c0)[RUN_K], uint32_t (&c1)[RUN_K],
-                                               uint32_t (&c2)[RUN_K])
+__device__ __forceinline__ uint32_t pair_words(const int rx, const int ry, const uint32_t tabv, const uint32_t metav,
+                                               uint32_t (&c0)[RUN_K], uint32_t (&c1)[RUN_K], uint32_t (&c2)[RUN_K])
 {
     constexpr int k = K;
-    constexpr uint32_t ta = RUN_TABS_OFS + k * RUN_TAB_BYTES, tb = ta + RUN_TAB_BYTES;
-    const int4 m = ldsr_i4(RUN_META_OFS + k * 8);  // (ca0, cb0) of both words: same address in every lane
+    constexpr uint32_t ta = k * RUN_TAB_BYTES, tb = ta + RUN_TAB_BYTES;
+    const int4 m = ldsr_i4(metav + k * 8);  // (ca0, cb0) of both words: same address in every lane
     const int A0a = rx + m.x, B0a = ry + m.y, A0b = rx + m.z, B0b = ry + m.w;
     uint32_t Da, Db;
-    const uint32_t idya = ldsr_u8(ta + RUN_IDXY_OFS + (uint32_t)(B0a & 1023));
-    const uint32_t idyb = ldsr_u8(tb + RUN_IDXY_OFS + (uint32_t)(B0b & 1023));
+    const uint32_t idya = ldsr_u8((((uint32_t)B0a & 1023u) | tabv) + (ta + RUN_IDXY_OFS));
+    const uint32_t idyb = ldsr_u8((((uint32_t)B0b & 1023u) | tabv) + (tb + RUN_IDXY_OFS));
     uint32_t idxa = 0, idxb = 0;
     if (SMAX > 0) {
-        idxa = ldsr_u8(ta + RUN_IDXX_OFS + (uint32_t)(A0a & 1023));
-        idxb = ldsr_u8(tb + RUN_IDXX_OFS + (uint32_t)(A0b & 1023));
+        idxa = ldsr_u8((((uint32_t)A0a & 1023u) | tabv) + (ta + RUN_IDXX_OFS));
+        idxb = ldsr_u8((((uint32_t)A0b & 1023u) | tabv) + (tb + RUN_IDXX_OFS));
     }
-    // window byte address: row * pitch + first word * 4 (v_mad_i32_i24; window-local coordinates are >= 0)
-    const uint32_t addra = RUN_WIN_OFS + (uint32_t)(__mul24(B0a >> 10, RUN_PITCHB) + ((A0a >> 13) & ~3));
-    const uint32_t addrb = RUN_WIN_OFS + (uint32_t)(__mul24(B0b >> 10, RUN_PITCHB) + ((A0b >> 13) & ~3));
+    // window byte address: (word column * RUN_WROWS + row) * 4, column-major; window-local coordinates
+    // are >= 0 and the buffer's base rides in ry
+    const uint32_t addra = (uint32_t)__mul24(A0a >> 15, RUN_WROWS * 4) + (((uint32_t)B0a >> 8) & ~3u);
+    const uint32_t addrb = (uint32_t)__mul24(A0b >> 15, RUN_WROWS * 4) + (((uint32_t)B0b >> 8) & ~3u);
     uint2 wa[NLEV], wb[NLEV];
 #pragma unroll
-    for (int lv = 0; lv < NLEV; lv++) {  // two adjacent dwords, 4-byte aligned: ds_read2_b32
-        wa[lv].x = ldsr_u32(addra + lv * RUN_PITCHB);
-        wa[lv].y = ldsr_u32(addra + lv * RUN_PITCHB + 4);
+    for (int lv = 0; lv < NLEV; lv++) {  // the same rows of two adjacent word columns
+        wa[lv].x = ldsr_u32(addra + lv * 4);
+        wa[lv].y = ldsr_u32(addra + lv * 4 + RUN_WROWS * 4);
     }
 #pragma unroll
     for (int lv = 0; lv < NLEV; lv++) {
-        wb[lv].x = ldsr_u32(addrb + lv * RUN_PITCHB);
-        wb[lv].y = ldsr_u32(addrb + lv * RUN_PITCHB + 4);
+        wb[lv].x = ldsr_u32(addrb + lv * 4);
+        wb[lv].y = ldsr_u32(addrb + lv * 4 + RUN_WROWS * 4);
     }
     const uint4 z4 = make_uint4(0, 0, 0, 0);
-    const uint32_t tya = ta + (idya << 4), tyb = tb + (idyb << 4);
-    const uint4 sa03 = ldsr_u4(tya), sa47 = NLEV > 4 ? ldsr_u4(tya + RUN_TUPHI_OFS) : z4;
-    const uint4 sb03 = ldsr_u4(tyb), sb47 = NLEV > 4 ? ldsr_u4(tyb + RUN_TUPHI_OFS) : z4;
+    const uint32_t tya = (idya << 4) | tabv, tyb = (idyb << 4) | tabv;
+    const uint4 sa03 = ldsr_u4(tya + ta), sa47 = NLEV > 4 ? ldsr_u4(tya + (ta + RUN_TUPHI_OFS)) : z4;
+    const uint4 sb03 = ldsr_u4(tyb + tb), sb47 = NLEV > 4 ? ldsr_u4(tyb + (tb + RUN_TUPHI_OFS)) : z4;
     uint2 sxa = make_uint2(0, 0), sxb = make_uint2(0, 0);
     if (SMAX > 0) {
-        sxa = ldsr_u2(ta + RUN_TUPX_OFS + (idxa << 3));
-        sxb = ldsr_u2(tb + RUN_TUPX_OFS + (idxb << 3));
+        sxa = ldsr_u2(((idxa << 3) | tabv) + (ta + RUN_TUPX_OFS));
+        sxb = ldsr_u2(((idxb << 3) | tabv) + (tb + RUN_TUPX_OFS));
     }
-#ifdef RUN_FENCE_MERGE
-    __builtin_amdgcn_sched_barrier(0);
-#endif
     Da = merge_word<NLEV, SMAX>(wa, (uint32_t)A0a >> 10, sa03, sa47, sxa);
-#ifdef RUN_FENCE_MERGE
-    count_columns(c0[k], c1[k], c2[k], Da);
-    __builtin_amdgcn_sched_barrier(0);
-    Db = merge_word<NLEV, SMAX>(wb, (uint32_t)A0b >> 10, sb03, sb47, sxb);
-#else
     Db = merge_word<NLEV, SMAX>(wb, (uint32_t)A0b >> 10, sb03, sb47, sxb);
     count_columns(c0[k], c1[k], c2[k], Da);
-#endif
     count_columns(c0[k + 1], c1[k + 1], c2[k + 1], Db);
     return __popc(Da) + __popc(Db);
 }
 
 // A pair's column lag bound (0, 1 or 2; wave-uniform) picks its specialisation: most words of a
-// candidate need no lag handling even when some word of the block does.
+// candidate need no lag handling even when some word of the group does.
 template <int NLEV, int K>
-__device__ __forceinline__ uint32_t pair_dispatch(const int rx, const int ry, uint32_t (&c0)[RUN_K],
-                                                  uint32_t (&c1)[RUN_K], uint32_t (&c2)[RUN_K], const int lagbits)
+__device__ __forceinline__ uint32_t pair_dispatch(const int rx, const int ry, const uint32_t tabv, const uint32_t metav,
+                                                  uint32_t (&c0)[RUN_K], uint32_t (&c1)[RUN_K], uint32_t (&c2)[RUN_K],
+                                                  const int lagbits)
 {
-    // keep the pairs apart: without this fence the scheduler hoists all four pairs' loads and the
-    // kernel needs 180 VGPRs (2 waves per SIMD instead of 4)
+    // keep the pairs apart: without this fence the scheduler hoists both pairs' loads
     __builtin_amdgcn_sched_barrier(0);
     const int lag = (lagbits >> K) & 3;
-    if (lag == 0) return pair_words<NLEV, 0, K>(rx, ry, c0, c1, c2);
-    if (lag == 1) return pair_words<NLEV, 1, K>(rx, ry, c0, c1, c2);
-    return pair_words<NLEV, 2, K>(rx, ry, c0, c1, c2);
+    if (lag == 0) return pair_words<NLEV, 0, K>(rx, ry, tabv, metav, c0, c1, c2);
+    if (lag == 1) return pair_words<NLEV, 1, K>(rx, ry, tabv, metav, c0, c1, c2);
+    return pair_words<NLEV, 2, K>(rx, ry, tabv, metav, c0, c1, c2);
 }
 
-// The RUN_K words of one band for one wave.  NLEV is uniform for the whole block (maximum over its
-// words; unused levels have empty masks), so the block dispatches once per band to a straight-line
+// The RUN_K words of one band for one wave.  NLEV is uniform for the whole group (maximum over its
+// words; unused levels have empty masks), so the wave dispatches once per band to a straight-line
 // specialisation.
 template <int NLEV>
-__device__ __forceinline__ uint32_t band_words(const int rx, const int ry, uint32_t (&c0)[RUN_K], uint32_t (&c1)[RUN_K],
-                                               uint32_t (&c2)[RUN_K], const int lagbits)
+__device__ __forceinline__ uint32_t band_words(const int rx, const int ry, const uint32_t tabv, const uint32_t metav,
+                                               uint32_t (&c0)[RUN_K], uint32_t (&c1)[RUN_K], uint32_t (&c2)[RUN_K],
+                                               const int lagbits)
 {
-    static_assert(RUN_K == 8, "four pairs");
-    uint32_t cnt = pair_dispatch<NLEV, 0>(rx, ry, c0, c1, c2, lagbits);
-    cnt += pair_dispatch<NLEV, 2>(rx, ry, c0, c1, c2, lagbits);
-    cnt += pair_dispatch<NLEV, 4>(rx, ry, c0, c1, c2, lagbits);
-    cnt += pair_dispatch<NLEV, 6>(rx, ry, c0, c1, c2, lagbits);
+    uint32_t cnt = pair_dispatch<NLEV, 0>(rx, ry, tabv, metav, c0, c1, c2, lagbits);
+    cnt += pair_dispatch<NLEV, 2>(rx, ry, tabv, metav, c0, c1, c2, lagbits);
     return cnt;
 }
 
-__device__ __forceinline__ uint32_t band_words_s(const int rx, const int ry, uint32_t (&c0)[RUN_K], uint32_t (&c1)[RUN_K],
-                                                 uint32_t (&c2)[RUN_K], const int nlev, const int lagbits)
+__device__ __forceinline__ uint32_t band_words_s(const int rx, const int ry, const uint32_t tabv, const uint32_t metav,
+                                                 uint32_t (&c0)[RUN_K], uint32_t (&c1)[RUN_K], uint32_t (&c2)[RUN_K],
+                                                 const int nlev, const int lagbits)
 {
     switch (nlev) {
-    case 1: return band_words<1>(rx, ry, c0, c1, c2, lagbits);
-    case 2: return band_words<2>(rx, ry, c0, c1, c2, lagbits);
-    case 3: return band_words<3>(rx, ry, c0, c1, c2, lagbits);
-    case 4: return band_words<4>(rx, ry, c0, c1, c2, lagbits);
-    case 5: return band_words<5>(rx, ry, c0, c1, c2, lagbits);
-    case 6: return band_words<6>(rx, ry, c0, c1, c2, lagbits);
-    case 7: return band_words<7>(rx, ry, c0, c1, c2, lagbits);
-    default: return band_words<8>(rx, ry, c0, c1, c2, lagbits);
+    case 1: return band_words<1>(rx, ry, tabv, metav, c0, c1, c2, lagbits);
+    case 2: return band_words<2>(rx, ry, tabv, metav, c0, c1, c2, lagbits);
+    case 3: return band_words<3>(rx, ry, tabv, metav, c0, c1, c2, lagbits);
+    case 4: return band_words<4>(rx, ry, tabv, metav, c0, c1, c2, lagbits);
+    case 5: return band_words<5>(rx, ry, tabv, metav, c0, c1, c2, lagbits);
+    case 6: return band_words<6>(rx, ry, tabv, metav, c0, c1, c2, lagbits);
+    case 7: return band_words<7>(rx, ry, tabv, metav, c0, c1, c2, lagbits);
+    default: return band_words<8>(rx, ry, tabv, metav, c0, c1, c2, lagbits);
     }
 }
 
-// Column counts of one word group: every lane holds a 3-plane bit-sliced counter per word (its rows
-// of the last <= 7 bands).  All 512 lanes park their counters in LDS (the window region is free
-// between bands); wave w then owns word w: it adds the 8 waves' counters lane-wise into a 6-plane
-// number (bit-sliced ripple adds), sums that over its 64 lanes with shl1_sum6 -- one column per
-// step, most significant bit first -- and adds the 32 column totals to colacc.
-// (reduce_columns is deliberately NOT inlined: its 32 scalar totals and asm temporaries would
-// otherwise raise the register pressure of the band loop, which runs at exactly 128 VGPRs.)
-__device__ __noinline__ void reduce_columns(const char *lds, uint32_t *colacc, const int tid)
+// bit-sliced a += b for two NP-plane numbers; a grows to NP + 1 planes
+template <int NP>
+__device__ __forceinline__ void bs_add(uint32_t (&a)[6], const uint32_t (&b)[6])
 {
-    const uint32_t *park = (const uint32_t *)(lds + RUN_WIN_OFS);  // [word][plane][512 lanes]
-    const int lane = tid & 63, wave = tid >> 6;
-    const uint32_t *mine = park + (wave * 3) * RUN_BAND + lane;  // word `wave`
-    uint32_t s0 = mine[0], s1 = mine[RUN_BAND], s2 = mine[2 * RUN_BAND], s3 = 0, s4 = 0, s5 = 0;
+    uint32_t c = 0;
 #pragma unroll
-    for (int wv = 1; wv < 8; wv++) {
-        const uint32_t x0 = mine[wv * 64], x1 = mine[RUN_BAND + wv * 64], x2 = mine[2 * RUN_BAND + wv * 64];
-        uint32_t c = s0 & x0;  // bit-sliced s += x
-        s0 ^= x0;
-        uint32_t t = s1 ^ x1 ^ c;
-        c = (s1 & x1) | (c & (s1 ^ x1));
-        s1 = t;
-        t = s2 ^ x2 ^ c;
-        c = (s2 & x2) | (c & (s2 ^ x2));
-        s2 = t;
-        t = s3 ^ c;
-        c &= s3;
-        s3 = t;
-        t = s4 ^ c;
-        c &= s4;
-        s4 = t;
-        s5 ^= c;
+    for (int i = 0; i < NP; i++) {
+        const uint32_t t = a[i] ^ b[i];
+        const uint32_t g = a[i] & b[i];
+        a[i] = t ^ c;
+        c = g | (c & t);
     }
-    uint32_t tot[32];
+    a[NP] = c;
+}
+
+// Column counts of one word group.  Every lane holds a 3-plane bit-sliced counter per word (its rows of
+// the last <= 7 bands).  Lane pairs add their counters (4 planes, DPP), the even lane parks the sum in
+// `park` (a window buffer nobody reads any more): [word][plane][wave][32 pairs].  After the barrier
+// wave w owns (word w / 2, columns 16 (1 - w % 2) .. + 15): lanes 0-31 add the parked numbers of waves
+// 0-3, lanes 32-63 those of waves 4-7 (6 planes), the 64 lanes are summed with shl1_sum6 -- one column
+// per step, most significant bit first -- and the 16 column totals are added to lanes 0-15 of `acc`.
+// (Deliberately NOT inlined: its scalar totals and asm temporaries would otherwise raise the register
+// pressure of the band loop.)
+__device__ __noinline__ uint32_t reduce_columns(const uint32_t park, const int tid, uint32_t acc)
+{
+    const int lane = tid & 63, wave = tid >> 6;
+    const int k = wave >> 1, hh = wave & 1;
+    const uint32_t base = park + (uint32_t)(((k * 4) * 256 + (lane >> 5) * 128 + (lane & 31)) * 4);
+    uint32_t x[4][6];
 #pragma unroll
-    for (int b = 31; b >= 0; b--) tot[b] = shl1_sum6(s0, s1, s2, s3, s4, s5);
+    for (int j = 0; j < 4; j++) {
+#pragma unroll
+        for (int pl = 0; pl < 4; pl++) x[j][pl] = ldsr_u32(base + (uint32_t)((pl * 256 + j * 32) * 4));
+        x[j][4] = x[j][5] = 0;
+    }
+    bs_add<4>(x[0], x[1]);
+    bs_add<4>(x[2], x[3]);
+    bs_add<5>(x[0], x[2]);
+    uint32_t s0 = x[0][0], s1 = x[0][1], s2 = x[0][2], s3 = x[0][3], s4 = x[0][4], s5 = x[0][5];
+    if (hh) {  // wave-uniform: this wave takes columns 15..0
+        s0 <<= 16, s1 <<= 16, s2 <<= 16, s3 <<= 16, s4 <<= 16, s5 <<= 16;
+    }
+    uint32_t tot[16];
+#pragma unroll
+    for (int b = 15; b >= 0; b--) tot[b] = shl1_sum6(s0, s1, s2, s3, s4, s5);
     uint32_t v = 0;
 #define WL(B) v = write_lane_imm<B>(v, tot[B]);
     WL(0) WL(1) WL(2) WL(3) WL(4) WL(5) WL(6) WL(7) WL(8) WL(9) WL(10) WL(11) WL(12) WL(13) WL(14) WL(15)
-    WL(16) WL(17) WL(18) WL(19) WL(20) WL(21) WL(22) WL(23) WL(24) WL(25) WL(26) WL(27) WL(28) WL(29) WL(30) WL(31)
 #undef WL
-    if (lane < 32) colacc[wave * 32 + lane] += v;  // only this wave touches word `wave`
+    return acc + v;  // lanes 16-63 add 0
 }
 
-__device__ __forceinline__ void flush_columns(char *lds, uint32_t (&c0)[RUN_K], uint32_t (&c1)[RUN_K],
-                                              uint32_t (&c2)[RUN_K], uint32_t *colacc, const int tid)
+__device__ __forceinline__ uint32_t dpp_pair_swap(uint32_t v)
 {
-    static_assert(RUN_K == 8 && RUN_BAND == 512, "one wave per word");
-    static_assert(RUN_K * 3 * RUN_BAND * 4 <= RUN_WIN_ROWS * RUN_PITCHB, "counter scratch must fit the window");
-    uint32_t *park = (uint32_t *)(lds + RUN_WIN_OFS);  // [word][plane][512 lanes]
-    __syncthreads();  // every wave is done with the window of the last band
+    return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1 /* quad_perm [1,0,3,2] */, 0xF, 0xF, true);
+}
+
+__device__ __forceinline__ uint32_t flush_columns(const uint32_t park, uint32_t (&c0)[RUN_K], uint32_t (&c1)[RUN_K],
+                                                  uint32_t (&c2)[RUN_K], const int tid, uint32_t acc)
+{
+    const int lane = tid & 63, wave = tid >> 6;
+    const uint32_t mine = park + (uint32_t)((wave * 32 + (lane >> 1)) * 4);
 #pragma unroll
     for (int k = 0; k < RUN_K; k++) {
-        park[(k * 3 + 0) * RUN_BAND + tid] = c0[k];
-        park[(k * 3 + 1) * RUN_BAND + tid] = c1[k];
-        park[(k * 3 + 2) * RUN_BAND + tid] = c2[k];
+        // this lane's 3-plane counter + its neighbour's -> 4 planes (the same in both lanes of the pair)
+        const uint32_t b0 = dpp_pair_swap(c0[k]), b1 = dpp_pair_swap(c1[k]), b2 = dpp_pair_swap(c2[k]);
+        const uint32_t t0 = c0[k] ^ b0, g0 = c0[k] & b0;
+        const uint32_t t1 = c1[k] ^ b1, g1 = (c1[k] & b1) | (g0 & t1);
+        const uint32_t t2 = c2[k] ^ b2, g2 = (c2[k] & b2) | (g1 & t2);
+        if ((lane & 1) == 0) {
+            ldsw_u32(mine + (uint32_t)(((k * 4 + 0) * 256) * 4), t0);
+            ldsw_u32(mine + (uint32_t)(((k * 4 + 1) * 256) * 4), t1 ^ g0);
+            ldsw_u32(mine + (uint32_t)(((k * 4 + 2) * 256) * 4), t2 ^ g1);
+            ldsw_u32(mine + (uint32_t)(((k * 4 + 3) * 256) * 4), g2);
+        }
         c0[k] = c1[k] = c2[k] = 0;
     }
     __syncthreads();
-    reduce_columns(lds, colacc, tid);
+    return reduce_columns(park, tid, acc);
 }
 
-// Diagnostic build only (OMR_RUNS_DBG=8): per-block phase clocks of wave 0, summed into a global
-// array [tables, commit+barriers, prefetch-issue, compute, flush, total]; read back with
-// omr_debug_runs_stamps().  No stamp executes in a production run (dbg == 0).
+#define RUN_FLUSH_BANDS 7  // 3-plane counters hold up to 7 rows per lane
+
+struct RunGeom {  // source window of one step (wave-uniform)
+    int wxw;      // first word column
+    int wy0;      // first row, a multiple of 4
+    int nrows;    // rows that hold samples (<= RUN_WROWS)
+    bool fits;
+};
+
+// Diagnostic build only (make debug, -DOMR_RUNS_DEBUG): per-block phase clocks of wave 0, summed into a global
+// array [prologue, wait + barrier, issue of the next step, compute, flush, total, blocks]; read back with
+// omr_debug_runs_stamps().  No stamp exists in the release library.
+#ifdef OMR_RUNS_DEBUG
 __device__ unsigned long long g_run_stamps[8];
 __device__ __forceinline__ unsigned long long run_clock()
 {
@@ -522,41 +627,38 @@ __device__ __forceinline__ unsigned long long run_clock()
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
     return t;
 }
+#define RUN_STAMP_DECL unsigned long long st_t0 = run_clock(), st_prev = st_t0, st_acc[5] = {0, 0, 0, 0, 0};
+#define RUN_STAMP(I)                                 \
+    {                                                \
+        const unsigned long long now_ = run_clock(); \
+        st_acc[I] += now_ - st_prev;                 \
+        st_prev = now_;                              \
+    }
+#define RUN_STAMP_END                                                          \
+    if (tid == 0) {                                                            \
+        for (int i = 0; i < 5; i++) atomicAdd(&g_run_stamps[i], st_acc[i]);    \
+        atomicAdd(&g_run_stamps[5], run_clock() - st_t0);                      \
+        atomicAdd(&g_run_stamps[6], 1ull);                                     \
+    }
+#else
+#define RUN_STAMP_DECL
+#define RUN_STAMP(I)
+#define RUN_STAMP_END
+#endif
 
-struct RunGeom {  // source window of one band (wave-uniform)
-    int wxw, wy0, nrows;
-    int nq;  // aligned 4-word pieces per window row that hold samples (3..RUN_QUADS)
-    bool fits;
-};
-
-#define RUN_FLUSH_BANDS 7  // 3-plane counters hold up to 7 rows per lane
-
-template <bool STAMP>
 __global__ __launch_bounds__(RUN_BAND, 4) void runs_kernel(const RunPass p, const int32_t *__restrict__ list,
-                                                        int32_t *__restrict__ guard, uint32_t *__restrict__ vproj)
+                                                           int32_t *__restrict__ guard, uint32_t *__restrict__ vproj)
 {
     extern __shared__ __attribute__((aligned(16))) char lds[];
-    uint32_t *colacc = (uint32_t *)(lds + RUN_COL_OFS);
-    constexpr bool stamp = STAMP;
-    unsigned long long st_t0 = 0, st_prev = 0, st_acc[5] = {0, 0, 0, 0, 0};
-    if (stamp) st_t0 = st_prev = run_clock();
-#define RUN_STAMP(I)                                   \
-    if (stamp) {                                       \
-        const unsigned long long now_ = run_clock();   \
-        st_acc[I] += now_ - st_prev;                   \
-        st_prev = now_;                                \
-    }
-    // grid = (scans, word groups, candidates), scans fastest.  Workgroups go round-robin to the 8 XCDs, so
-    // with 8 (4, 2) scans per launch XCD x only ever sweeps scan x (x mod 4, x mod 2): that scan's 1.09 MB
-    // bit image stays in the XCD's 4 MB L2 and every window fetch hits it.  (Tried: giving an XCD all
-    // scans of a (candidate, word group) pair so that the pair's run table is fetched once -- 3.3 k
-    // instead of 3.7 k images/s, the eight bit images then evict each other.)
+    RUN_STAMP_DECL
+    // grid = (scans, chunks, candidates), scans fastest.  Workgroups go round-robin to the 8 XCDs, so with 8
+    // (4, 2) scans per launch XCD x only ever sweeps scan x (x mod 4, x mod 2): that scan's 1.1 MB bit
+    // image stays in the XCD's 4 MB L2 and every window fetch hits it.
     const int a = __builtin_amdgcn_readfirstlane(list[blockIdx.z]);
-    const int g = blockIdx.y;
+    const int pc = blockIdx.y / p.RCH, rc = blockIdx.y - pc * p.RCH;  // chunk of word groups, chunk of rows
     const int zscan = blockIdx.x;  // scan of the launch
-    const int w0 = g * RUN_K;
-    const int kw = min(RUN_K, p.NW - w0);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // the inner loop addresses LDS by integer: the dynamic segment must start at LDS address 0 (no
     // static LDS in this kernel).  If a toolchain ever places it elsewhere the candidate is handed to
     // the gather kernel instead of computing from wrong addresses.
@@ -564,233 +666,188 @@ __global__ __launch_bounds__(RUN_BAND, 4) void runs_kernel(const RunPass p, cons
         if (tid == 0) guard[a] = 1;
         return;
     }
-
-#ifdef OMR_RUNS_DEBUG
-    {   // experiment: de-phase the two workgroups of a CU (they otherwise run fetch / compute / flush in lockstep)
-        const int st = p.dbg >> 8;  // units of 1024 cycles
-        const uint32_t tg = __builtin_amdgcn_s_getreg(((4 - 1) << 11) | (16 << 6) | 4);  // HW_ID.TG_ID
-        if (st > 0 && (tg & 1)) for (int i = 0; i < st; i++) __builtin_amdgcn_s_sleep(16);
-    }
-#endif
-    // block constants: one scalar load (the address is uniform)
-    const RunBlk bk = p.blk[(int64_t)a * p.G + g];
-    const int nlev_blk = bk.nlev, lagbits = bk.lagbits;
-    const int ca_min = bk.ca_min, ca_max = bk.ca_max, cb_min = bk.cb_min, cb_max = bk.cb_max;
+    const int g_begin = pc * p.GC, g_end = min(p.G, g_begin + p.GC);
+    const int ngroups = g_end - g_begin;
+    // images taller than the LDS row counters are cut into row chunks of p.RB bands; the column counts of
+    // the chunks then meet in vproj by atomics
+    const int band0 = rc * p.RB, row0 = band0 * RUN_BAND;
+    const int NB = min(p.RB, (p.NR + RUN_BAND - 1) / RUN_BAND - band0);  // bands per word group in this chunk
+    const int nsteps = ngroups * NB;
+    const int NRh = (min(p.NRp - row0, p.RB * RUN_BAND) + 1) >> 1;  // dwords of the row-count array
     const int2_t *__restrict__ RT = p.RT + (int64_t)a * p.NR;
-    const int c_first = w0 * 32;
-    uint16_t *__restrict__ out = p.part + (((int64_t)zscan * p.A + a) * p.G + g) * p.NR;
-
-    // source bounding box of a band x word group: the map is monotone in r and in c, so the four
-    // corner samples bound it.  The corner rows' (X0, Y0) are fetched one band ahead of their use.
-    auto corners = [&](int yb, int2_t &t0, int2_t &t1) {
-        const int yy = min(yb, p.NR - 1);
-        t0 = RT[yy];
-        t1 = RT[min(p.NR, yy + RUN_BAND) - 1];
+    // per-row (X0, Y0): one 8-byte buffer load per lane and band, offset = an SGPR + tid * 8
+    const __amdgpu_buffer_rsrc_t rs_rt = __builtin_amdgcn_make_buffer_rsrc((void *)RT, 0, p.NR * 8, 0x00020000);
+    const int tid8 = tid * 8;
+    auto load_rt = [&](const int row_first) -> int2_t {
+        const v2u32 v = __builtin_bit_cast(v2u32, __builtin_amdgcn_raw_buffer_load_b64(rs_rt, tid8 + row_first * 8, 0, 0));
+        return int2_t{(int32_t)v.x, (int32_t)v.y};
     };
-    auto geometry = [&](const int2_t t0, const int2_t t1) -> RunGeom {
+
+    // ---- descriptors (wave-uniform): the scan's transposed bit image, the candidate's run tables
+    const v4u32 rs_img = make_rsrc(p.srcT + (int64_t)zscan * p.NWt * p.rowsT, (uint32_t)p.NWt * (uint32_t)p.rowsT * 4u);
+    const char *tab_base = (const char *)(p.tabs + ((int64_t)a * p.NWp + (int64_t)g_begin * RUN_K));
+    const char *met_base = (const char *)(p.metac + ((int64_t)a * p.NWp + (int64_t)g_begin * RUN_K));
+
+    // ---- prologue: band corners and word-group constants go to LDS once
+    if (tid < NB) {
+        const int yb = row0 + tid * RUN_BAND;
+        const int2_t t0 = RT[yb], t1 = RT[min(p.NR, yb + RUN_BAND) - 1];
+        *(int4 *)(lds + RUN_GEO_OFS + tid * 16) = make_int4(t0.x, t0.y, t1.x, t1.y);
+    }
+    if (tid >= 64 && tid < 64 + ngroups * 8) {
+        const int i = tid - 64;
+        const int32_t *src = (const int32_t *)(p.blk + ((int64_t)a * p.G + g_begin));
+        *(int32_t *)(lds + RUN_GEO_OFS + RUN_GEO_BANDS * 16 + i * 4) = src[i];
+    }
+    for (int i = tid; i < NRh; i += RUN_BAND) *(uint32_t *)(lds + RUN_HROW_OFS + i * 4) = 0u;
+
+    // source bounding box of a band x word group: the map is monotone in r and in c, so the four corner
+    // samples bound it
+    auto geometry = [&](const int gl, const int band) -> RunGeom {
+        const int4 cn = *(const int4 *)(lds + RUN_GEO_OFS + band * 16);
+        const int32_t *bk = (const int32_t *)(lds + RUN_GEO_OFS + RUN_GEO_BANDS * 16 + gl * 32);
+        const int t0x = __builtin_amdgcn_readfirstlane(cn.x), t0y = __builtin_amdgcn_readfirstlane(cn.y);
+        const int t1x = __builtin_amdgcn_readfirstlane(cn.z), t1y = __builtin_amdgcn_readfirstlane(cn.w);
+        const int ca_min = __builtin_amdgcn_readfirstlane(bk[3]), ca_max = __builtin_amdgcn_readfirstlane(bk[4]);
+        const int cb_min = __builtin_amdgcn_readfirstlane(bk[5]), cb_max = __builtin_amdgcn_readfirstlane(bk[6]);
         RunGeom q;
-        const int t0x = __builtin_amdgcn_readfirstlane(t0.x), t0y = __builtin_amdgcn_readfirstlane(t0.y);
-        const int t1x = __builtin_amdgcn_readfirstlane(t1.x), t1y = __builtin_amdgcn_readfirstlane(t1.y);
         const int minbit = (min(t0x, t1x) + ca_min) >> 10;  // min over the four corners
         const int maxbit = (max(t0x, t1x) + ca_max) >> 10;
         const int minrow = (min(t0y, t1y) + cb_min) >> 10;
         const int maxrow = (max(t0y, t1y) + cb_max) >> 10;
-        q.wxw = (minbit >> 5) & ~3;  // first window word (multiple of 4: 16-byte loads)
-        q.wy0 = minrow - 7;          // a word reads up to 7 rows beside its true samples
-        q.nrows = maxrow - minrow + 15;
-        // every selected sample lies in words wxw .. maxbit >> 5; the word after a sample's word is
-        // read too but none of its bits is ever selected, so it may hold anything
-        q.nq = max(3, (((maxbit >> 5) - q.wxw) >> 2) + 1);
-        q.fits = q.nq <= RUN_QUADS && q.nrows <= RUN_WIN_ROWS;
+        q.wxw = minbit >> 5;
+        q.wy0 = (minrow - 7) & ~3;  // a word reads up to 7 rows beside its true samples; pieces are 4 rows
+        q.nrows = maxrow + 8 - q.wy0;
+        // every selected sample lies in word columns wxw .. maxbit >> 5; the column after a sample's is
+        // read too but none of its bits is ever selected: it only has to exist
+        q.fits = (maxbit >> 5) - q.wxw + 2 <= RUN_WCOLS && q.nrows <= RUN_WROWS;
         return q;
     };
-    // The window (nrows x nq aligned 16-byte pieces, zero outside the image) is fetched into
-    // registers one band ahead, so the fetch of band b+1 overlaps the compute of band b and every
-    // wave carries the same share.  A round of the block covers rpr = 512 / nq whole rows: thread t
-    // owns piece t % nq of row t / nq + n * rpr in round n, so both its global and its LDS address
-    // advance by a wave-uniform stride.  The loads go through a buffer descriptor of the bit image:
-    // rows above / below the image give byte offsets outside [0, num_records) (as unsigned), which
-    // the hardware range check turns into zeros, and a thread whose words lie left / right of the
-    // image (the same in every round) uses an offset that is out of range in every round -- no
-    // compare, no branch and no zero fill per piece.
-    constexpr int PIECES = (RUN_WIN_ROWS * RUN_QUADS + RUN_BAND - 1) / RUN_BAND;
-    static_assert(RUN_QUADS == 5 && RUN_BAND == 512, "piece -> row uses 16-bit reciprocals of 3 and 5");
-    static_assert(PIECES * (RUN_BAND / RUN_QUADS) >= RUN_WIN_ROWS, "rounds cover the window");
-    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        (void *)(p.src + (int64_t)zscan * p.src_rows * p.src_wpr), /*stride*/ 0,
-        (int)((uint32_t)p.src_rows * (uint32_t)p.src_wpr * 4u), 0x00020000);
-    // (row, first word) of the thread's round-0 piece.  Recomputed where it is used from an opaque
-    // copy of tid: cached or loop-hoisted offsets cost more registers than the kernel has, and a
-    // spill reload inside the fetch sequence would wait for the loads already in flight.
-    auto piece0 = [&](const RunGeom &q, int &row0, int &w4, int &rpr) {
-        int t = tid;
-        asm volatile("" : "+v"(t));
-        const uint32_t magic = q.nq == 3 ? 21846u : (q.nq == 4 ? 16384u : 13108u);  // 65536 / nq, rounded up
-        rpr = q.nq == 3 ? 170 : (q.nq == 4 ? 128 : 102);
-        row0 = (int)(((uint32_t)t * magic) >> 16);
-        w4 = 4 * (t - row0 * q.nq);
+    // window of one step -> LDS, column-major, 16-byte pieces of 4 rows.  Wave w moves word column w (256 rows
+    // per wave-instruction, the column's base in an SGPR) and an eighth of the last column, so a piece costs
+    // four VALU operations: its row, the range test of that row (rows outside the image must land as zeros,
+    // and so must every row of a column outside it), the offset.
+    const int lane4 = lane * 4;
+    auto fetch_pieces = [&](const RunGeom &q, const int col, const int row_first, const int nlanes, const uint32_t ldsb) {
+        const int x = q.wxw + col;                         // word column of the image (wave-uniform)
+        const int y0 = q.wy0 + row_first;                  // image row of lane 0's piece
+        const uint32_t xb = (uint32_t)x < (uint32_t)p.NWt ? (uint32_t)(x * p.rowsT) * 4u : 0x80000000u;
+        const uint32_t y = (uint32_t)(y0 + lane4);
+        const uint32_t voff = (y < (uint32_t)p.rowsT && xb != 0x80000000u) ? xb + y * 4u : 0x80000000u;
+        if (lane < nlanes) dma_b128(rs_img, voff, ldsb);
     };
-    // The loads of a window are issued as soon as a wave has finished the previous band (before the
-    // barrier: they do not touch LDS) and committed after it.  They are NOT held in registers across a
-    // compute phase: the merge loop runs at the edge of the 128-VGPR budget of 4 waves per SIMD, and every
-    // variant that kept 16-24 piece registers live through it ended with the allocator spilling them
-    // (round 2: six variants, 16-78 spilled VGPRs); the second workgroup of the CU covers the fetch instead.
-    // Rounds 0..3 (all of a 3-piece window: 69 % of the bands at C2) fly across the loop-top barrier; the
-    // rounds of wider windows are loaded inside the commit, so that no more than 16 piece registers are
-    // ever live at the loop's back edge (with 24 the allocator spilled two pieces around the whole loop).
-    constexpr int EARLY = 4;
-    static_assert(EARLY * 170 >= RUN_WIN_ROWS, "the early rounds cover a 3-piece window");
-    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-    u32x4 pre[EARLY];
-    auto fetch = [&](const RunGeom &q) {
-        if (!q.fits) return;
-        int row0, w4, rpr;
-        piece0(q, row0, w4, rpr);
-        const int w = q.wxw + w4;
-        const bool in_w = row0 < rpr && w >= 0 && w + 3 < p.src_wpr;
-        // out-of-image threads: 2^31 stays out of range after adding any round's stride (< 2^31)
-        const uint32_t voff = in_w ? (uint32_t)(((q.wy0 + row0) * p.src_wpr + w) * 4) : 0x80000000u;
-        const uint32_t stride = (uint32_t)(rpr * p.src_wpr * 4);
-#pragma unroll
-        for (int n = 0; n < EARLY; n++) {
-            if (n * rpr >= q.nrows) break;  // wave-uniform: this round has no rows
-            pre[n] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(voff + n * stride), 0, 0);
-        }
+    auto fetch_window = [&](const RunGeom &q, const uint32_t winbase) {
+        static_assert(RUN_WCOLS == 9 && RUN_WROWS == 576 && RUN_BAND == 512, "eight waves, nine columns");
+        const uint32_t colb = winbase + (uint32_t)(wave * RUN_WROWS * 4);
+        fetch_pieces(q, wave, 0, 64, colb);
+        if (q.nrows > 256) fetch_pieces(q, wave, 256, 64, colb + 256 * 4);
+        if (q.nrows > 512) fetch_pieces(q, wave, 512, 16, colb + 512 * 4);
+        if (wave * 72 < q.nrows) fetch_pieces(q, 8, wave * 72, 18, winbase + (uint32_t)((8 * RUN_WROWS + wave * 72) * 4));
     };
-    auto commit = [&](const RunGeom &q) {
-        int row0, w4, rpr;
-        piece0(q, row0, w4, rpr);
-        char *d0 = lds + RUN_WIN_OFS + row0 * RUN_PITCHB + w4 * 4;
-        const int rows_left = row0 < rpr ? q.nrows - row0 : 0;
-        const int dstride = rpr * RUN_PITCHB;
-        u32x4 late[PIECES - EARLY];
-        if (EARLY * rpr < q.nrows) {  // wave-uniform: a 4- or 5-piece window has late rounds
-            const int w = q.wxw + w4;
-            const bool in_w = row0 < rpr && w >= 0 && w + 3 < p.src_wpr;
-            const uint32_t voff = in_w ? (uint32_t)(((q.wy0 + row0) * p.src_wpr + w) * 4) : 0x80000000u;
-            const uint32_t stride = (uint32_t)(rpr * p.src_wpr * 4);
+    // run tables + (ca0, cb0) pairs of one word group -> LDS
+    auto fetch_tables = [&](const int gl, const int set) {
+        const v4u32 rs_tab = make_rsrc(tab_base + (int64_t)gl * RUN_TABSET_BYTES, RUN_TABSET_BYTES);
+        const v4u32 rs_met = make_rsrc(met_base + (int64_t)gl * (RUN_K * 8), RUN_K * 8);
+        const uint32_t tabbase = set ? RUN_TAB1_OFS : RUN_TAB0_OFS;
 #pragma unroll
-            for (int n = EARLY; n < PIECES; n++) {
-                if (n * rpr >= q.nrows) break;
-                late[n - EARLY] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(voff + n * stride), 0, 0);
-            }
+        for (int n = 0; n < (RUN_TABSET_BYTES / 16 + RUN_BAND - 1) / RUN_BAND; n++) {
+            const int i = n * RUN_BAND + tid;
+            if (i < RUN_TABSET_BYTES / 16) dma_b128(rs_tab, (uint32_t)(i * 16), tabbase + (uint32_t)(n * RUN_BAND * 16 + wave * 1024));
         }
-#pragma unroll
-        for (int n = 0; n < PIECES; n++) {
-            if (n * rpr >= q.nrows) break;
-            if (n * rpr < rows_left) {
-                const u32x4 v = n < EARLY ? pre[n < EARLY ? n : 0] : late[n >= EARLY ? n - EARLY : 0];
-                uint32_t *d = (uint32_t *)(d0 + n * dstride);
-                d[0] = v.x;
-                d[1] = v.y;
-                d[2] = v.z;
-                d[3] = v.w;
-            }
-        }
+        if (tid < RUN_K * 2) dma_b32(rs_met, (uint32_t)(tid * 4), (uint32_t)(RUN_META_OFS + set * (RUN_K * 8)));
     };
 
-    // ---- prologue: the first band's fetch goes out before the run tables are staged
-    int2_t cn0, cn1;
-    corners(0, cn0, cn1);
-    int2_t rt = RT[min(wave * 64 + lane, p.NR - 1)];
-    // run tables of this block's words (16-byte copies; words past the end of the row repeat the
-    // last real word so that every lane address stays meaningful)
-    constexpr int W16 = RUN_TAB_BYTES / 16;
-    constexpr int TP = (RUN_K * W16 + RUN_BAND - 1) / RUN_BAND;
-    uint4 tv[TP];
-    {
-        const uint4 *src = (const uint4 *)(p.tabs + ((int64_t)a * p.NW + w0));
-#pragma unroll
-        for (int n = 0; n < TP; n++) {
-            const int i = tid + n * RUN_BAND;
-            const int k = i / W16, c = i - k * W16;
-            // words past the end of the row: a copy of the last real word (addresses stay meaningful) whose
-            // level masks are EMPTY, so they add nothing to any count
-            tv[n] = (i < RUN_K * W16 && !(k >= kw && c < RUN_TUPX_OFS / 16)) ? src[min(k, kw - 1) * W16 + c]
-                                                                            : make_uint4(0, 0, 0, 0);
-        }
-    }
-    int2 mv = make_int2(0, 0);  // (ca0, cb0) of word tid: read back from LDS as a broadcast
-    if (tid < RUN_K) {
-        const RunMeta *__restrict__ mt = p.meta + ((int64_t)a * p.NW + w0);
-        const int kk = min(tid, kw - 1);
-        mv = make_int2(mt[kk].ca0, mt[kk].cb0);
-    }
-    RunGeom cur = geometry(cn0, cn1);
-    if (!(RUN_DBG(p) & 2)) fetch(cur);
-    corners(RUN_BAND, cn0, cn1);  // next band's corners: in flight until the end of the first iteration
-    {
-        uint4 *dst = (uint4 *)(lds + RUN_TABS_OFS);
-#pragma unroll
-        for (int n = 0; n < TP; n++) {
-            const int i = tid + n * RUN_BAND;
-            if (i < RUN_K * W16) dst[i] = tv[n];
-        }
-    }
-    if (tid < RUN_K) *(int2 *)(lds + RUN_META_OFS + tid * 8) = mv;
-    if (tid < RUN_K * 32) colacc[tid] = 0;
+    __syncthreads();  // corners / word-group constants are in LDS
+    RunGeom cur = geometry(0, 0);
+    RunGeom nxt = cur;
+    if (nsteps > 1) nxt = NB > 1 ? geometry(0, 1) : geometry(1, 0);
+    fetch_tables(0, 0);
+    if (cur.fits) fetch_window(cur, RUN_WIN0_OFS);
+    int2_t rt = load_rt(row0);
+    const uint32_t hrow_lane = RUN_HROW_OFS + (uint32_t)(tid >> 1) * 4u, hrow_shift = (uint32_t)(tid & 1) * 16u;
 
     uint32_t c0[RUN_K], c1[RUN_K], c2[RUN_K];
 #pragma unroll
     for (int k = 0; k < RUN_K; k++) c0[k] = c1[k] = c2[k] = 0;
+    uint32_t acc = 0;  // lanes 0-15: column totals of this wave's (word, half) of the current group
 
-    int bands_pending = 0;
+    int gl = 0, band = 0, bands_pending = 0;
     RUN_STAMP(0)
-    for (int yb = 0; yb < p.NR; yb += RUN_BAND) {
-        const int r = yb + wave * 64 + lane;
-        __syncthreads();  // previous band's readers are done (first pass: tables, meta, colacc staged)
-        if (cur.fits) {
-            if (!(RUN_DBG(p) & 2)) commit(cur);
-        } else if (tid == 0) {
-            guard[a] = 1;
-        }
+    for (int s = 0; s < nsteps; s++) {
+        const int wset = s & 1, tset = gl & 1;
+        // every DMA this wave issued for this step has landed; after the barrier so have the other waves',
+        // and nobody reads the buffers of step s - 1 any more
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         RUN_STAMP(1)
         const RunGeom now = cur;
         const int2_t rt_now = rt;
-        const bool more = yb + RUN_BAND < p.NR;
+        // ---- next step: its window (and, at the start of a group, the next group's tables) go out now
+        int gl_n = gl, band_n = band + 1;
+        if (band_n == NB) band_n = 0, gl_n = gl + 1;
+        const bool more = s + 1 < nsteps;
         if (more) {
-            cur = geometry(cn0, cn1);
-            corners(yb + 2 * RUN_BAND, cn0, cn1);
-            rt = RT[min(r + RUN_BAND, p.NR - 1)];
+            cur = nxt;
+            rt = load_rt(row0 + band_n * RUN_BAND);
+            if (cur.fits) fetch_window(cur, wset ? RUN_WIN0_OFS : RUN_WIN1_OFS);
         }
+        if (band == 0 && gl + 1 < ngroups) fetch_tables(gl + 1, tset ^ 1);
+        if (!now.fits && tid == 0) guard[a] = 1;
         RUN_STAMP(2)
-        // rows past the end of the image are masked off by EXEC for the whole compute phase (their
-        // counters must not move); the band loop's barriers are outside this branch
-        if (now.fits && r < p.NR && !(RUN_DBG(p) & 1)) {
+
+        // ---- this step.  Rows past the end of the image are masked off by EXEC for the whole compute
+        // phase (their counters must not move); the barriers are outside this branch
+        const int r = band * RUN_BAND + tid;  // row within the chunk
+        if (now.fits && row0 + r < p.NR) {
+            const int32_t *bk = (const int32_t *)(lds + RUN_GEO_OFS + RUN_GEO_BANDS * 16 + gl * 32);
+            const int nlev = __builtin_amdgcn_readfirstlane(bk[0]), lagbits = __builtin_amdgcn_readfirstlane(bk[7]);
+            const uint32_t winbase = wset ? RUN_WIN1_OFS : RUN_WIN0_OFS;
             const int rx = rt_now.x - (now.wxw << 15);  // window-local fixed point
-            const int ry = rt_now.y - (now.wy0 << 10);
-            const uint32_t cnt = band_words_s(rx, ry, c0, c1, c2, nlev_blk, lagbits);
-            out[r] = (uint16_t)cnt;
+            const int ry = rt_now.y - (now.wy0 << 10) + (int)((winbase / 4) << 10);
+            const uint32_t tabv = tset ? RUN_TAB1_OFS : RUN_TAB0_OFS;
+            const uint32_t metav = RUN_META_OFS + tset * (RUN_K * 8);
+            const uint32_t cnt = band_words_s(rx, ry, tabv, metav, c0, c1, c2, nlev, lagbits);
+            // two u16 row counts per dword: the lanes of a pair add into the same dword
+            __hip_atomic_fetch_add((lds_u32 *)(uintptr_t)(hrow_lane + (uint32_t)(band * (RUN_BAND * 2))), cnt << hrow_shift,
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
         RUN_STAMP(3)
         // the 3-plane counters hold at most 7 rows per lane: reduce them across lanes in time
-        if (++bands_pending == RUN_FLUSH_BANDS || !more) {
+        const bool group_done = band == NB - 1;
+        if (++bands_pending == RUN_FLUSH_BANDS || group_done) {
             bands_pending = 0;
-            if (!(RUN_DBG(p) & 4)) flush_columns(lds, c0, c1, c2, colacc, tid);
-            RUN_STAMP(4)
+            __syncthreads();  // every wave is done with this step's window: it becomes the parking space
+            acc = flush_columns(wset ? RUN_WIN1_OFS : RUN_WIN0_OFS, c0, c1, c2, tid, acc);
+            if (group_done) {
+                // column counts of this wave's 16 columns over ALL rows: one plain store each
+                const int col = ((g_begin + gl) * RUN_K + (wave >> 1)) * 32 + ((wave & 1) ? 0 : 16) + lane;
+                if (lane < 16 && col < p.NC) {
+                    uint32_t *dst = vproj + ((int64_t)zscan * p.A + a) * p.NC + col;
+                    if (p.RCH == 1) *dst = acc;
+                    else atomicAdd(dst, acc);  // vproj was zeroed before the launch
+                }
+                acc = 0;
+            }
         }
-        if (more && !(RUN_DBG(p) & 2)) fetch(cur);  // next window: in flight across the loop-top barrier
+        RUN_STAMP(4)
+        // geometry two steps ahead (LDS reads only)
+        if (s + 2 < nsteps) {
+            int gl_nn = gl_n, band_nn = band_n + 1;
+            if (band_nn == NB) band_nn = 0, gl_nn = gl_n + 1;
+            nxt = geometry(gl_nn, band_nn);
+        }
+        gl = gl_n, band = band_n;
     }
     __syncthreads();
-    // column counts of this block's (up to) 256 columns over ALL rows: one plain store each
-    if (tid < RUN_K * 32 && c_first + tid < p.NC)
-        vproj[((int64_t)zscan * p.A + a) * p.NC + c_first + tid] = colacc[tid];
-    if (stamp && tid == 0) {
-        for (int i = 0; i < 5; i++) atomicAdd(&g_run_stamps[i], st_acc[i]);
-        atomicAdd(&g_run_stamps[5], run_clock() - st_t0);
-        atomicAdd(&g_run_stamps[6], 1ull);
-    }
-#undef RUN_STAMP
+    // row counts of this chunk of word groups: u16 partials, two per dword
+    uint32_t *__restrict__ out = (uint32_t *)(p.part + (((int64_t)zscan * p.A + a) * p.P + pc) * p.NRp + row0);
+    for (int i = tid; i < NRh; i += RUN_BAND) out[i] = *(const uint32_t *)(lds + RUN_HROW_OFS + i * 4);
+    RUN_STAMP_END
 }
 
+#ifdef OMR_RUNS_DEBUG
 hipError_t debug_runs_stamps(unsigned long long out[8], bool reset)
 {
-#ifndef OMR_RUNS_DEBUG
-    (void)out;
-    (void)reset;
-    return hipErrorNotSupported;  // release build: no stamp variant is compiled in
-#endif
     hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_run_stamps), 8 * sizeof(unsigned long long));
     if (e == hipSuccess && reset) {
         unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -798,51 +855,46 @@ hipError_t debug_runs_stamps(unsigned long long out[8], bool reset)
     }
     return e;
 }
+#endif
 
 hipError_t launch_runs(const RunPass &p0, const int32_t *d_list, int n_list, int32_t *d_guard, uint32_t *d_vproj,
                        hipStream_t s)
 {
     if (n_list <= 0) return hipSuccess;
     RunPass p = p0;
-#ifdef OMR_RUNS_DEBUG
-    {
-        const char *e = getenv("OMR_RUNS_DBG");
-        p.dbg = e ? atoi(e) : 0;
-    }
-    auto *kern = (p.dbg & 8) ? runs_kernel<true> : runs_kernel<false>;
-#else
-    p.dbg = 0;
-    auto *kern = runs_kernel<false>;
-#endif
+    if (p.RB < 1 || p.RB * RUN_BAND > OMR_RUN_MAX_ROWS || p.RCH < 1 || p.RCH * p.RB * RUN_BAND < p.NR || p.GC < 1 ||
+        p.GC > OMR_RUN_GC || (p.NRp & 1) || p.NRp < p.NR)
+        return hipErrorInvalidValue;
     // per device and idempotent; cheap enough to repeat (the batch entry points use every device)
-    hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, RUN_LDS_BYTES);
+    hipError_t e = hipFuncSetAttribute((const void *)runs_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, RUN_LDS_BYTES);
     if (e != hipSuccess) return e;
     if (p.scans < 1) p.scans = 1;
-    hipLaunchKernelGGL(kern, dim3(p.scans, p.G, n_list), dim3(RUN_BAND), RUN_LDS_BYTES, s, p, d_list, d_guard, d_vproj);
+    hipLaunchKernelGGL(runs_kernel, dim3(p.scans, p.P * p.RCH, n_list), dim3(RUN_BAND), RUN_LDS_BYTES, s, p, d_list, d_guard,
+                       d_vproj);
     return hipGetLastError();
 }
 
-// proj[a][r] = sum_g part[a][g][r] for the listed candidates
-__global__ __launch_bounds__(256) void fold_parts_kernel(const uint16_t *__restrict__ part, int G, int NR,
+// proj[a][r] = sum_p part[a][p][r] for the listed candidates
+__global__ __launch_bounds__(256) void fold_parts_kernel(const uint16_t *__restrict__ part, int P, int NR, int NRp,
                                                          const int32_t *__restrict__ list,
                                                          uint32_t *__restrict__ proj, int A)
 {
-    part += (int64_t)blockIdx.z * A * G * NR;  // blockIdx.z = scan of the launch
+    part += (int64_t)blockIdx.z * A * P * NRp;  // blockIdx.z = scan of the launch
     proj += (int64_t)blockIdx.z * A * NR;
     const int a = list[blockIdx.y];
     const int r = blockIdx.x * 256 + threadIdx.x;
     if (r >= NR) return;
     uint32_t s = 0;
-    for (int g = 0; g < G; g++) s += part[((int64_t)a * G + g) * NR + r];
+    for (int q = 0; q < P; q++) s += part[((int64_t)a * P + q) * NRp + r];
     proj[(int64_t)a * NR + r] = s;
 }
 
-hipError_t launch_fold_parts(const uint16_t *d_part, int G, int NR, const int32_t *d_list, int n_list,
+hipError_t launch_fold_parts(const uint16_t *d_part, int P, int NR, int NRp, const int32_t *d_list, int n_list,
                              uint32_t *d_proj, hipStream_t s, int scans, int A)
 {
     if (n_list <= 0 || scans <= 0) return hipSuccess;
-    hipLaunchKernelGGL(fold_parts_kernel, dim3((NR + 255) / 256, n_list, scans), dim3(256), 0, s, d_part, G, NR, d_list,
-                       d_proj, A);
+    hipLaunchKernelGGL(fold_parts_kernel, dim3((NR + 255) / 256, n_list, scans), dim3(256), 0, s, d_part, P, NR, NRp,
+                       d_list, d_proj, A);
     return hipGetLastError();
 }
 
