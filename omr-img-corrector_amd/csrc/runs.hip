@@ -14,13 +14,14 @@
 // stores the <= 33 distinct mask tuples (RunTab).  Per word the kernel then needs two byte look-ups,
 // one 32-bit unaligned window per source row (two LDS dwords + v_alignbit), and one and/or per row.
 //
-// Round-3 structure: nothing on the way into LDS passes through registers.
-// The scan's bit image is kept TRANSPOSED in HBM (word column x = rows contiguous dwords), the window
-// of a band is column-major in LDS, so one `buffer_load_dwordx4 ... lds` moves 256 rows of one word
-// column as whole cache lines, lane = row reads are bank-conflict free at any window height, and the
-// windows and run tables of the NEXT step are in flight while the current one is computed (two
-// window buffers, two table buffers, one barrier per band).  A workgroup walks a chunk of word
-// groups of one candidate, so the row counts stay in LDS until the chunk is done.
+// Round-3 structure: nothing on the way into LDS passes through registers and
+// the waves of a workgroup run free.  The scan's bit image is kept TRANSPOSED in HBM (word column x =
+// rows contiguous dwords); every WAVE owns the source window of its 64 destination rows, column-major
+// in LDS, filled by `buffer_load_dwordx4 ... lds` (whole cache lines, no bank conflicts for lane = row
+// at any window height) and waited for with the wave's own vmcnt -- no workgroup barrier per band.
+// The run tables of the next word group arrive by LDS-DMA while the current group is swept (two table
+// sets).  A workgroup walks a chunk of word groups of one candidate, so the row counts stay in LDS
+// until the chunk is done; the waves meet only when a group's column counters are reduced.
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
 
@@ -32,8 +33,10 @@ namespace omr {
 
 #define RUN_K OMR_RUN_K    // destination words per word group (kernels.hpp)
 #define RUN_BAND 512       // destination rows per band (8 waves x 64 lanes)
-#define RUN_WCOLS 9        // window: word columns ...
-#define RUN_WROWS 576      // ... of this many rows each (column-major, 16-byte pieces of 4 rows)
+#define RUN_WAVES 8
+#define RUN_WCOLS 7        // a wave's window: word columns ...
+#define RUN_WROWS 112      // ... of this many rows each (column-major, 16-byte pieces of 4 rows)
+#define RUN_WPIECES (RUN_WROWS / 4)
 #define RUN_WIN_BYTES (RUN_WCOLS * RUN_WROWS * 4)
 #define RUN_TAB_BYTES 3648
 #define RUN_TUPHI_OFS 640
@@ -41,26 +44,22 @@ namespace omr {
 #define RUN_IDXY_OFS 1600
 #define RUN_IDXX_OFS 2624
 #define RUN_TABSET_BYTES (RUN_K * RUN_TAB_BYTES)
-// LDS map.  The two table sets start at multiples of 1024 (a set's base is OR-ed under the 10-bit
+// LDS map.  The two table sets start at multiples of 1024 (a set's base is added under the 10-bit
 // fraction / the shifted tuple id, the word's offset is the ds_read immediate).
 #define RUN_TAB0_OFS 0
 #define RUN_META_OFS RUN_TABSET_BYTES                       // [2 sets][RUN_K] (ca0, cb0)
 #define RUN_TAB1_OFS 15360
-#define RUN_WIN0_OFS (RUN_TAB1_OFS + RUN_TABSET_BYTES)      // 29952
-#define RUN_WIN1_OFS (RUN_WIN0_OFS + RUN_WIN_BYTES)         // 50688
-#define RUN_GEO_OFS (RUN_WIN1_OFS + RUN_WIN_BYTES)          // 71424: band corners + word-group constants
-#define RUN_GEO_BANDS 12
-#define RUN_GEO_BYTES (RUN_GEO_BANDS * 16 + OMR_RUN_GC * 32)
-#define RUN_HROW_OFS (RUN_GEO_OFS + 1024)                   // row counts of the chunk, two u16 per dword
-#define RUN_LDS_BYTES (RUN_HROW_OFS + OMR_RUN_MAX_ROWS * 2)
+#define RUN_WIN_OFS (RUN_TAB1_OFS + RUN_TABSET_BYTES)       // 29952: one window per wave
+#define RUN_PARK_OFS (RUN_WIN_OFS + RUN_WAVES * RUN_WIN_BYTES)  // column counters of a flush: [word][plane][wave][32 pairs]
+#define RUN_PARK_BYTES (RUN_K * 4 * 256 * 4)
+#define RUN_HROW_OFS (RUN_PARK_OFS + RUN_PARK_BYTES)        // row counts of the chunk, two u16 per dword
+#define RUN_GEO_OFS (RUN_HROW_OFS + OMR_RUN_MAX_ROWS * 2)   // word-group constants of the chunk
+#define RUN_LDS_BYTES (RUN_GEO_OFS + OMR_RUN_GC * 32)
 static_assert(RUN_K == 4, "one (word, 16-column half) per wave in the column reduction");
 static_assert(RUN_META_OFS + 2 * RUN_K * 8 <= RUN_TAB1_OFS, "meta fits the gap between the table sets");
 static_assert(RUN_TAB1_OFS % 1024 == 0 && RUN_TAB0_OFS % 1024 == 0, "table sets are 1024-aligned");
-static_assert(RUN_GEO_BYTES <= 1024, "geometry scratch");
-static_assert(OMR_RUN_MAX_ROWS <= RUN_GEO_BANDS * RUN_BAND, "bands of the tallest image");
 static_assert(2 * RUN_LDS_BYTES <= 160 * 1024, "two workgroups per CU");
-static_assert(RUN_WROWS % 64 == 0, "a 16-byte piece never straddles two columns");
-static_assert(RUN_K * 4 * 256 * 4 <= RUN_WIN_BYTES, "the column counters of a flush park in a window buffer");
+static_assert(RUN_WROWS % 4 == 0 && 2 * RUN_WPIECES <= 64, "two window columns per wave-instruction");
 
 static_assert(sizeof(RunTab) == RUN_TAB_BYTES, "RunTab layout");
 static_assert(sizeof(RunMeta) == 32, "RunMeta layout");
@@ -433,16 +432,19 @@ __device__ __forceinline__ void count_columns(uint32_t &c0, uint32_t &c1, uint32
 // look-ups and all 2 x NLEV window reads are issued before anything is consumed (LDS latency hiding at
 // 4 waves per SIMD).  Padding words were built with empty level masks, the last word's masks carry the
 // row-end mask (runtab_kernel), rows past the end of the image are EXEC-masked by the caller: nothing
-// to mask here.  `tabv` is the byte address of the step's table set (a multiple of 1024), `metav` of
-// its (ca0, cb0) pairs; the window's base and first row are folded into (rx, ry) by the caller.
+// to mask here.  `tabv` is the byte address of the group's table set (a multiple of 1024); (ca0, cb0) of
+// the group's words sit in registers; the window's base and first row are folded into (rx, ry) by the
+// caller.
+struct RunWordK {
+    int ca0, cb0;
+};
 template <int NLEV, int SMAX, int K>
-__device__ __forceinline__ uint32_t pair_words(const int rx, const int ry, const uint32_t tabv, const uint32_t metav,
+__device__ __forceinline__ uint32_t pair_words(const int rx, const int ry, const uint32_t tabv, const RunWordK (&wk)[RUN_K],
                                                uint32_t (&c0)[RUN_K], uint32_t (&c1)[RUN_K], uint32_t (&c2)[RUN_K])
 {
     constexpr int k = K;
     constexpr uint32_t ta = k * RUN_TAB_BYTES, tb = ta + RUN_TAB_BYTES;
-    const int4 m = ldsr_i4(metav + k * 8);  // (ca0, cb0) of both words: same address in every lane
-    const int A0a = rx + m.x, B0a = ry + m.y, A0b = rx + m.z, B0b = ry + m.w;
+    const int A0a = rx + wk[k].ca0, B0a = ry + wk[k].cb0, A0b = rx + wk[k + 1].ca0, B0b = ry + wk[k + 1].cb0;
     uint32_t Da, Db;
     const uint32_t idya = ldsr_u8((((uint32_t)B0a & 1023u) | tabv) + (ta + RUN_IDXY_OFS));
     const uint32_t idyb = ldsr_u8((((uint32_t)B0b & 1023u) | tabv) + (tb + RUN_IDXY_OFS));
@@ -452,7 +454,7 @@ __device__ __forceinline__ uint32_t pair_words(const int rx, const int ry, const
         idxb = ldsr_u8((((uint32_t)A0b & 1023u) | tabv) + (tb + RUN_IDXX_OFS));
     }
     // window byte address: (word column * RUN_WROWS + row) * 4, column-major; window-local coordinates
-    // are >= 0 and the buffer's base rides in ry
+    // are >= 0 and the window's base rides in ry
     const uint32_t addra = (uint32_t)__mul24(A0a >> 15, RUN_WROWS * 4) + (((uint32_t)B0a >> 8) & ~3u);
     const uint32_t addrb = (uint32_t)__mul24(A0b >> 15, RUN_WROWS * 4) + (((uint32_t)B0b >> 8) & ~3u);
     uint2 wa[NLEV], wb[NLEV];
@@ -485,44 +487,44 @@ __device__ __forceinline__ uint32_t pair_words(const int rx, const int ry, const
 // A pair's column lag bound (0, 1 or 2; wave-uniform) picks its specialisation: most words of a
 // candidate need no lag handling even when some word of the group does.
 template <int NLEV, int K>
-__device__ __forceinline__ uint32_t pair_dispatch(const int rx, const int ry, const uint32_t tabv, const uint32_t metav,
+__device__ __forceinline__ uint32_t pair_dispatch(const int rx, const int ry, const uint32_t tabv, const RunWordK (&wk)[RUN_K],
                                                   uint32_t (&c0)[RUN_K], uint32_t (&c1)[RUN_K], uint32_t (&c2)[RUN_K],
                                                   const int lagbits)
 {
     // keep the pairs apart: without this fence the scheduler hoists both pairs' loads
     __builtin_amdgcn_sched_barrier(0);
     const int lag = (lagbits >> K) & 3;
-    if (lag == 0) return pair_words<NLEV, 0, K>(rx, ry, tabv, metav, c0, c1, c2);
-    if (lag == 1) return pair_words<NLEV, 1, K>(rx, ry, tabv, metav, c0, c1, c2);
-    return pair_words<NLEV, 2, K>(rx, ry, tabv, metav, c0, c1, c2);
+    if (lag == 0) return pair_words<NLEV, 0, K>(rx, ry, tabv, wk, c0, c1, c2);
+    if (lag == 1) return pair_words<NLEV, 1, K>(rx, ry, tabv, wk, c0, c1, c2);
+    return pair_words<NLEV, 2, K>(rx, ry, tabv, wk, c0, c1, c2);
 }
 
 // The RUN_K words of one band for one wave.  NLEV is uniform for the whole group (maximum over its
 // words; unused levels have empty masks), so the wave dispatches once per band to a straight-line
 // specialisation.
 template <int NLEV>
-__device__ __forceinline__ uint32_t band_words(const int rx, const int ry, const uint32_t tabv, const uint32_t metav,
+__device__ __forceinline__ uint32_t band_words(const int rx, const int ry, const uint32_t tabv, const RunWordK (&wk)[RUN_K],
                                                uint32_t (&c0)[RUN_K], uint32_t (&c1)[RUN_K], uint32_t (&c2)[RUN_K],
                                                const int lagbits)
 {
-    uint32_t cnt = pair_dispatch<NLEV, 0>(rx, ry, tabv, metav, c0, c1, c2, lagbits);
-    cnt += pair_dispatch<NLEV, 2>(rx, ry, tabv, metav, c0, c1, c2, lagbits);
+    uint32_t cnt = pair_dispatch<NLEV, 0>(rx, ry, tabv, wk, c0, c1, c2, lagbits);
+    cnt += pair_dispatch<NLEV, 2>(rx, ry, tabv, wk, c0, c1, c2, lagbits);
     return cnt;
 }
 
-__device__ __forceinline__ uint32_t band_words_s(const int rx, const int ry, const uint32_t tabv, const uint32_t metav,
+__device__ __forceinline__ uint32_t band_words_s(const int rx, const int ry, const uint32_t tabv, const RunWordK (&wk)[RUN_K],
                                                  uint32_t (&c0)[RUN_K], uint32_t (&c1)[RUN_K], uint32_t (&c2)[RUN_K],
                                                  const int nlev, const int lagbits)
 {
     switch (nlev) {
-    case 1: return band_words<1>(rx, ry, tabv, metav, c0, c1, c2, lagbits);
-    case 2: return band_words<2>(rx, ry, tabv, metav, c0, c1, c2, lagbits);
-    case 3: return band_words<3>(rx, ry, tabv, metav, c0, c1, c2, lagbits);
-    case 4: return band_words<4>(rx, ry, tabv, metav, c0, c1, c2, lagbits);
-    case 5: return band_words<5>(rx, ry, tabv, metav, c0, c1, c2, lagbits);
-    case 6: return band_words<6>(rx, ry, tabv, metav, c0, c1, c2, lagbits);
-    case 7: return band_words<7>(rx, ry, tabv, metav, c0, c1, c2, lagbits);
-    default: return band_words<8>(rx, ry, tabv, metav, c0, c1, c2, lagbits);
+    case 1: return band_words<1>(rx, ry, tabv, wk, c0, c1, c2, lagbits);
+    case 2: return band_words<2>(rx, ry, tabv, wk, c0, c1, c2, lagbits);
+    case 3: return band_words<3>(rx, ry, tabv, wk, c0, c1, c2, lagbits);
+    case 4: return band_words<4>(rx, ry, tabv, wk, c0, c1, c2, lagbits);
+    case 5: return band_words<5>(rx, ry, tabv, wk, c0, c1, c2, lagbits);
+    case 6: return band_words<6>(rx, ry, tabv, wk, c0, c1, c2, lagbits);
+    case 7: return band_words<7>(rx, ry, tabv, wk, c0, c1, c2, lagbits);
+    default: return band_words<8>(rx, ry, tabv, wk, c0, c1, c2, lagbits);
     }
 }
 
@@ -543,17 +545,17 @@ __device__ __forceinline__ void bs_add(uint32_t (&a)[6], const uint32_t (&b)[6])
 
 // Column counts of one word group.  Every lane holds a 3-plane bit-sliced counter per word (its rows of
 // the last <= 7 bands).  Lane pairs add their counters (4 planes, DPP), the even lane parks the sum in
-// `park` (a window buffer nobody reads any more): [word][plane][wave][32 pairs].  After the barrier
-// wave w owns (word w / 2, columns 16 (1 - w % 2) .. + 15): lanes 0-31 add the parked numbers of waves
-// 0-3, lanes 32-63 those of waves 4-7 (6 planes), the 64 lanes are summed with shl1_sum6 -- one column
-// per step, most significant bit first -- and the 16 column totals are added to lanes 0-15 of `acc`.
+// LDS: [word][plane][wave][32 pairs].  After the barrier wave w owns (word w / 2, columns
+// 16 (1 - w % 2) .. + 15): lanes 0-31 add the parked numbers of waves 0-3, lanes 32-63 those of waves 4-7
+// (6 planes), the 64 lanes are summed with shl1_sum6 -- one column per step, most significant bit first --
+// and the 16 column totals are added to lanes 0-15 of `acc`.
 // (Deliberately NOT inlined: its scalar totals and asm temporaries would otherwise raise the register
 // pressure of the band loop.)
-__device__ __noinline__ uint32_t reduce_columns(const uint32_t park, const int tid, uint32_t acc)
+__device__ __noinline__ uint32_t reduce_columns(const int tid, uint32_t acc)
 {
     const int lane = tid & 63, wave = tid >> 6;
     const int k = wave >> 1, hh = wave & 1;
-    const uint32_t base = park + (uint32_t)(((k * 4) * 256 + (lane >> 5) * 128 + (lane & 31)) * 4);
+    const uint32_t base = RUN_PARK_OFS + (uint32_t)(((k * 4) * 256 + (lane >> 5) * 128 + (lane & 31)) * 4);
     uint32_t x[4][6];
 #pragma unroll
     for (int j = 0; j < 4; j++) {
@@ -583,11 +585,15 @@ __device__ __forceinline__ uint32_t dpp_pair_swap(uint32_t v)
     return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1 /* quad_perm [1,0,3,2] */, 0xF, 0xF, true);
 }
 
-__device__ __forceinline__ uint32_t flush_columns(const uint32_t park, uint32_t (&c0)[RUN_K], uint32_t (&c1)[RUN_K],
-                                                  uint32_t (&c2)[RUN_K], const int tid, uint32_t acc)
+// The waves run free between flushes, so two barriers frame the parking: the first says that every wave
+// has finished the PREVIOUS reduction (its reads of the park) and this group's sweep, the second that
+// every wave has parked.
+__device__ __forceinline__ uint32_t flush_columns(uint32_t (&c0)[RUN_K], uint32_t (&c1)[RUN_K], uint32_t (&c2)[RUN_K],
+                                                  const int tid, uint32_t acc)
 {
     const int lane = tid & 63, wave = tid >> 6;
-    const uint32_t mine = park + (uint32_t)((wave * 32 + (lane >> 1)) * 4);
+    const uint32_t mine = RUN_PARK_OFS + (uint32_t)((wave * 32 + (lane >> 1)) * 4);
+    __syncthreads();
 #pragma unroll
     for (int k = 0; k < RUN_K; k++) {
         // this lane's 3-plane counter + its neighbour's -> 4 planes (the same in both lanes of the pair)
@@ -604,20 +610,19 @@ __device__ __forceinline__ uint32_t flush_columns(const uint32_t park, uint32_t 
         c0[k] = c1[k] = c2[k] = 0;
     }
     __syncthreads();
-    return reduce_columns(park, tid, acc);
+    return reduce_columns(tid, acc);
 }
 
 #define RUN_FLUSH_BANDS 7  // 3-plane counters hold up to 7 rows per lane
 
-struct RunGeom {  // source window of one step (wave-uniform)
+struct RunGeom {  // source window of one wave and band (wave-uniform)
     int wxw;      // first word column
     int wy0;      // first row, a multiple of 4
-    int nrows;    // rows that hold samples (<= RUN_WROWS)
     bool fits;
 };
 
 // Diagnostic build only (make debug, -DOMR_RUNS_DEBUG): per-block phase clocks of wave 0, summed into a global
-// array [prologue, wait + barrier, issue of the next step, compute, flush, total, blocks]; read back with
+// array [prologue, wait for the window, compute, issue of the next window, flush, total, blocks]; read back with
 // omr_debug_runs_stamps().  No stamp exists in the release library.
 #ifdef OMR_RUNS_DEBUG
 __device__ unsigned long long g_run_stamps[8];
@@ -672,42 +677,34 @@ __global__ __launch_bounds__(RUN_BAND, 4) void runs_kernel(const RunPass p, cons
     // the chunks then meet in vproj by atomics
     const int band0 = rc * p.RB, row0 = band0 * RUN_BAND;
     const int NB = min(p.RB, (p.NR + RUN_BAND - 1) / RUN_BAND - band0);  // bands per word group in this chunk
-    const int nsteps = ngroups * NB;
-    const int NRh = (min(p.NRp - row0, p.RB * RUN_BAND) + 1) >> 1;  // dwords of the row-count array
+    const int NRh = (min(p.NRp - row0, p.RB * RUN_BAND) + 1) >> 1;      // dwords of the row-count array
     const int2_t *__restrict__ RT = p.RT + (int64_t)a * p.NR;
-    // per-row (X0, Y0): one 8-byte buffer load per lane and band, offset = an SGPR + tid * 8
-    const __amdgpu_buffer_rsrc_t rs_rt = __builtin_amdgcn_make_buffer_rsrc((void *)RT, 0, p.NR * 8, 0x00020000);
-    const int tid8 = tid * 8;
-    auto load_rt = [&](const int row_first) -> int2_t {
-        const v2u32 v = __builtin_bit_cast(v2u32, __builtin_amdgcn_raw_buffer_load_b64(rs_rt, tid8 + row_first * 8, 0, 0));
-        return int2_t{(int32_t)v.x, (int32_t)v.y};
-    };
 
     // ---- descriptors (wave-uniform): the scan's transposed bit image, the candidate's run tables
     const v4u32 rs_img = make_rsrc(p.srcT + (int64_t)zscan * p.NWt * p.rowsT, (uint32_t)p.NWt * (uint32_t)p.rowsT * 4u);
     const char *tab_base = (const char *)(p.tabs + ((int64_t)a * p.NWp + (int64_t)g_begin * RUN_K));
     const char *met_base = (const char *)(p.metac + ((int64_t)a * p.NWp + (int64_t)g_begin * RUN_K));
+    // per-row (X0, Y0): one 8-byte buffer load per lane and band; the last row stands in for rows past the end
+    const __amdgpu_buffer_rsrc_t rs_rt = __builtin_amdgcn_make_buffer_rsrc((void *)RT, 0, p.NR * 8, 0x00020000);
+    auto load_rt = [&](const int band) -> int2_t {
+        const int r = min(row0 + band * RUN_BAND + tid, p.NR - 1);
+        const v2u32 v = __builtin_bit_cast(v2u32, __builtin_amdgcn_raw_buffer_load_b64(rs_rt, r * 8, 0, 0));
+        return int2_t{(int32_t)v.x, (int32_t)v.y};
+    };
 
-    // ---- prologue: band corners and word-group constants go to LDS once
-    if (tid < NB) {
-        const int yb = row0 + tid * RUN_BAND;
-        const int2_t t0 = RT[yb], t1 = RT[min(p.NR, yb + RUN_BAND) - 1];
-        *(int4 *)(lds + RUN_GEO_OFS + tid * 16) = make_int4(t0.x, t0.y, t1.x, t1.y);
-    }
-    if (tid >= 64 && tid < 64 + ngroups * 8) {
-        const int i = tid - 64;
+    // ---- prologue: the chunk's word-group constants go to LDS, the row counts start at 0
+    if (tid < ngroups * 8) {
         const int32_t *src = (const int32_t *)(p.blk + ((int64_t)a * p.G + g_begin));
-        *(int32_t *)(lds + RUN_GEO_OFS + RUN_GEO_BANDS * 16 + i * 4) = src[i];
+        *(int32_t *)(lds + RUN_GEO_OFS + tid * 4) = src[tid];
     }
     for (int i = tid; i < NRh; i += RUN_BAND) *(uint32_t *)(lds + RUN_HROW_OFS + i * 4) = 0u;
 
-    // source bounding box of a band x word group: the map is monotone in r and in c, so the four corner
-    // samples bound it
-    auto geometry = [&](const int gl, const int band) -> RunGeom {
-        const int4 cn = *(const int4 *)(lds + RUN_GEO_OFS + band * 16);
-        const int32_t *bk = (const int32_t *)(lds + RUN_GEO_OFS + RUN_GEO_BANDS * 16 + gl * 32);
-        const int t0x = __builtin_amdgcn_readfirstlane(cn.x), t0y = __builtin_amdgcn_readfirstlane(cn.y);
-        const int t1x = __builtin_amdgcn_readfirstlane(cn.z), t1y = __builtin_amdgcn_readfirstlane(cn.w);
+    // Source bounding box of this wave's 64 rows x a word group: the map is monotone in r and in c, so the
+    // four corner samples bound it.  The corner rows are the wave's own first and last lane.
+    auto geometry = [&](const int2_t rtv, const int gl) -> RunGeom {
+        const int32_t *bk = (const int32_t *)(lds + RUN_GEO_OFS + gl * 32);
+        const int t0x = __builtin_amdgcn_readlane(rtv.x, 0), t0y = __builtin_amdgcn_readlane(rtv.y, 0);
+        const int t1x = __builtin_amdgcn_readlane(rtv.x, 63), t1y = __builtin_amdgcn_readlane(rtv.y, 63);
         const int ca_min = __builtin_amdgcn_readfirstlane(bk[3]), ca_max = __builtin_amdgcn_readfirstlane(bk[4]);
         const int cb_min = __builtin_amdgcn_readfirstlane(bk[5]), cb_max = __builtin_amdgcn_readfirstlane(bk[6]);
         RunGeom q;
@@ -717,34 +714,28 @@ __global__ __launch_bounds__(RUN_BAND, 4) void runs_kernel(const RunPass p, cons
         const int maxrow = (max(t0y, t1y) + cb_max) >> 10;
         q.wxw = minbit >> 5;
         q.wy0 = (minrow - 7) & ~3;  // a word reads up to 7 rows beside its true samples; pieces are 4 rows
-        q.nrows = maxrow + 8 - q.wy0;
         // every selected sample lies in word columns wxw .. maxbit >> 5; the column after a sample's is
         // read too but none of its bits is ever selected: it only has to exist
-        q.fits = (maxbit >> 5) - q.wxw + 2 <= RUN_WCOLS && q.nrows <= RUN_WROWS;
+        q.fits = (maxbit >> 5) - q.wxw + 2 <= RUN_WCOLS && maxrow + 8 - q.wy0 <= RUN_WROWS;
         return q;
     };
-    // window of one step -> LDS, column-major, 16-byte pieces of 4 rows.  Wave w moves word column w (256 rows
-    // per wave-instruction, the column's base in an SGPR) and an eighth of the last column, so a piece costs
-    // four VALU operations: its row, the range test of that row (rows outside the image must land as zeros,
-    // and so must every row of a column outside it), the offset.
-    const int lane4 = lane * 4;
-    auto fetch_pieces = [&](const RunGeom &q, const int col, const int row_first, const int nlanes, const uint32_t ldsb) {
-        const int x = q.wxw + col;                         // word column of the image (wave-uniform)
-        const int y0 = q.wy0 + row_first;                  // image row of lane 0's piece
-        const uint32_t xb = (uint32_t)x < (uint32_t)p.NWt ? (uint32_t)(x * p.rowsT) * 4u : 0x80000000u;
-        const uint32_t y = (uint32_t)(y0 + lane4);
-        const uint32_t voff = (y < (uint32_t)p.rowsT && xb != 0x80000000u) ? xb + y * 4u : 0x80000000u;
-        if (lane < nlanes) dma_b128(rs_img, voff, ldsb);
+    // This wave's window -> LDS, column-major, 16-byte pieces of 4 rows, two word columns per
+    // wave-instruction (lanes 0-27 and 28-55).  Rows outside the image must land as zeros, and so must every
+    // row of a column outside it: such lanes get an offset outside the descriptor's range.
+    const int lane_hi = lane >= RUN_WPIECES ? 1 : 0, lane_rr4 = (lane - lane_hi * RUN_WPIECES) * 4;
+    const uint32_t winbase = RUN_WIN_OFS + (uint32_t)wave * RUN_WIN_BYTES;
+    auto fetch_window = [&](const RunGeom &q) {
+        const uint32_t y = (uint32_t)(q.wy0 + lane_rr4);
+        const bool y_in = y < (uint32_t)p.rowsT;
+#pragma unroll
+        for (int n = 0; n < (RUN_WCOLS + 1) / 2; n++) {
+            const int x = q.wxw + 2 * n + lane_hi;
+            const uint32_t voff = (y_in && (uint32_t)x < (uint32_t)p.NWt) ? (uint32_t)(x * p.rowsT) * 4u + y * 4u : 0x80000000u;
+            const int nl = 2 * n + 1 < RUN_WCOLS ? 2 * RUN_WPIECES : RUN_WPIECES;
+            if (lane < nl) dma_b128(rs_img, voff, winbase + (uint32_t)(2 * n * RUN_WROWS * 4));
+        }
     };
-    auto fetch_window = [&](const RunGeom &q, const uint32_t winbase) {
-        static_assert(RUN_WCOLS == 9 && RUN_WROWS == 576 && RUN_BAND == 512, "eight waves, nine columns");
-        const uint32_t colb = winbase + (uint32_t)(wave * RUN_WROWS * 4);
-        fetch_pieces(q, wave, 0, 64, colb);
-        if (q.nrows > 256) fetch_pieces(q, wave, 256, 64, colb + 256 * 4);
-        if (q.nrows > 512) fetch_pieces(q, wave, 512, 16, colb + 512 * 4);
-        if (wave * 72 < q.nrows) fetch_pieces(q, 8, wave * 72, 18, winbase + (uint32_t)((8 * RUN_WROWS + wave * 72) * 4));
-    };
-    // run tables + (ca0, cb0) pairs of one word group -> LDS
+    // run tables + (ca0, cb0) pairs of one word group -> LDS (all waves share the work)
     auto fetch_tables = [&](const int gl, const int set) {
         const v4u32 rs_tab = make_rsrc(tab_base + (int64_t)gl * RUN_TABSET_BYTES, RUN_TABSET_BYTES);
         const v4u32 rs_met = make_rsrc(met_base + (int64_t)gl * (RUN_K * 8), RUN_K * 8);
@@ -757,87 +748,87 @@ __global__ __launch_bounds__(RUN_BAND, 4) void runs_kernel(const RunPass p, cons
         if (tid < RUN_K * 2) dma_b32(rs_met, (uint32_t)(tid * 4), (uint32_t)(RUN_META_OFS + set * (RUN_K * 8)));
     };
 
-    __syncthreads();  // corners / word-group constants are in LDS
-    RunGeom cur = geometry(0, 0);
-    RunGeom nxt = cur;
-    if (nsteps > 1) nxt = NB > 1 ? geometry(0, 1) : geometry(1, 0);
+    __syncthreads();  // word-group constants are in LDS
     fetch_tables(0, 0);
-    if (cur.fits) fetch_window(cur, RUN_WIN0_OFS);
-    int2_t rt = load_rt(row0);
+    int2_t rt = load_rt(0);                      // this band's rows
+    int2_t rt_n = NB > 1 ? load_rt(1) : rt;      // the next band's (the next group starts over at band 0)
+    RunGeom cur = geometry(rt, 0);
+    if (cur.fits) fetch_window(cur);
     const uint32_t hrow_lane = RUN_HROW_OFS + (uint32_t)(tid >> 1) * 4u, hrow_shift = (uint32_t)(tid & 1) * 16u;
 
     uint32_t c0[RUN_K], c1[RUN_K], c2[RUN_K];
 #pragma unroll
     for (int k = 0; k < RUN_K; k++) c0[k] = c1[k] = c2[k] = 0;
     uint32_t acc = 0;  // lanes 0-15: column totals of this wave's (word, half) of the current group
-
-    int gl = 0, band = 0, bands_pending = 0;
+    bool bad = false;
     RUN_STAMP(0)
-    for (int s = 0; s < nsteps; s++) {
-        const int wset = s & 1, tset = gl & 1;
-        // every DMA this wave issued for this step has landed; after the barrier so have the other waves',
-        // and nobody reads the buffers of step s - 1 any more
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        RUN_STAMP(1)
-        const RunGeom now = cur;
-        const int2_t rt_now = rt;
-        // ---- next step: its window (and, at the start of a group, the next group's tables) go out now
-        int gl_n = gl, band_n = band + 1;
-        if (band_n == NB) band_n = 0, gl_n = gl + 1;
-        const bool more = s + 1 < nsteps;
-        if (more) {
-            cur = nxt;
-            rt = load_rt(row0 + band_n * RUN_BAND);
-            if (cur.fits) fetch_window(cur, wset ? RUN_WIN0_OFS : RUN_WIN1_OFS);
-        }
-        if (band == 0 && gl + 1 < ngroups) fetch_tables(gl + 1, tset ^ 1);
-        if (!now.fits && tid == 0) guard[a] = 1;
-        RUN_STAMP(2)
 
-        // ---- this step.  Rows past the end of the image are masked off by EXEC for the whole compute
-        // phase (their counters must not move); the barriers are outside this branch
-        const int r = band * RUN_BAND + tid;  // row within the chunk
-        if (now.fits && row0 + r < p.NR) {
-            const int32_t *bk = (const int32_t *)(lds + RUN_GEO_OFS + RUN_GEO_BANDS * 16 + gl * 32);
-            const int nlev = __builtin_amdgcn_readfirstlane(bk[0]), lagbits = __builtin_amdgcn_readfirstlane(bk[7]);
-            const uint32_t winbase = wset ? RUN_WIN1_OFS : RUN_WIN0_OFS;
-            const int rx = rt_now.x - (now.wxw << 15);  // window-local fixed point
-            const int ry = rt_now.y - (now.wy0 << 10) + (int)((winbase / 4) << 10);
-            const uint32_t tabv = tset ? RUN_TAB1_OFS : RUN_TAB0_OFS;
-            const uint32_t metav = RUN_META_OFS + tset * (RUN_K * 8);
-            const uint32_t cnt = band_words_s(rx, ry, tabv, metav, c0, c1, c2, nlev, lagbits);
-            // two u16 row counts per dword: the lanes of a pair add into the same dword
-            __hip_atomic_fetch_add((lds_u32 *)(uintptr_t)(hrow_lane + (uint32_t)(band * (RUN_BAND * 2))), cnt << hrow_shift,
-                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    for (int gl = 0; gl < ngroups; gl++) {
+        const int tset = gl & 1;
+        // the group's tables: this wave's share has landed; after the barrier every wave's has (the first
+        // group's barrier is this one, later groups met at the end of the previous group's flush)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (gl == 0) __syncthreads();
+        if (gl + 1 < ngroups) fetch_tables(gl + 1, tset ^ 1);  // every wave has left the other set behind
+        const uint32_t tabv = tset ? RUN_TAB1_OFS : RUN_TAB0_OFS;
+        RunWordK wk[RUN_K];
+#pragma unroll
+        for (int k = 0; k < RUN_K; k++) {
+            const int2 m = *(const int2 *)(lds + RUN_META_OFS + tset * (RUN_K * 8) + k * 8);
+            wk[k].ca0 = m.x, wk[k].cb0 = m.y;
         }
-        RUN_STAMP(3)
-        // the 3-plane counters hold at most 7 rows per lane: reduce them across lanes in time
-        const bool group_done = band == NB - 1;
-        if (++bands_pending == RUN_FLUSH_BANDS || group_done) {
-            bands_pending = 0;
-            __syncthreads();  // every wave is done with this step's window: it becomes the parking space
-            acc = flush_columns(wset ? RUN_WIN1_OFS : RUN_WIN0_OFS, c0, c1, c2, tid, acc);
-            if (group_done) {
-                // column counts of this wave's 16 columns over ALL rows: one plain store each
-                const int col = ((g_begin + gl) * RUN_K + (wave >> 1)) * 32 + ((wave & 1) ? 0 : 16) + lane;
-                if (lane < 16 && col < p.NC) {
-                    uint32_t *dst = vproj + ((int64_t)zscan * p.A + a) * p.NC + col;
-                    if (p.RCH == 1) *dst = acc;
-                    else atomicAdd(dst, acc);  // vproj was zeroed before the launch
-                }
-                acc = 0;
+        const int32_t *bk = (const int32_t *)(lds + RUN_GEO_OFS + gl * 32);
+        const int nlev = __builtin_amdgcn_readfirstlane(bk[0]), lagbits = __builtin_amdgcn_readfirstlane(bk[7]);
+        int bands_pending = 0;
+        for (int band = 0; band < NB; band++) {
+            // ---- this wave's window of (group, band) has landed (its own DMA: no barrier)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            RUN_STAMP(1)
+            const RunGeom now = cur;
+            bad |= !now.fits;
+            const int r = band * RUN_BAND + tid;  // row within the chunk
+            // rows past the end of the image are masked off by EXEC for the whole compute phase (their
+            // counters must not move)
+            if (now.fits && row0 + r < p.NR) {
+                const int rx = rt.x - (now.wxw << 15);  // window-local fixed point
+                const int ry = rt.y - (now.wy0 << 10) + (int)((winbase / 4) << 10);
+                const uint32_t cnt = band_words_s(rx, ry, tabv, wk, c0, c1, c2, nlev, lagbits);
+                // two u16 row counts per dword: the lanes of a pair add into the same dword
+                __hip_atomic_fetch_add((lds_u32 *)(uintptr_t)(hrow_lane + (uint32_t)(band * (RUN_BAND * 2))), cnt << hrow_shift,
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
+            RUN_STAMP(2)
+            // ---- the next window of this wave goes out as soon as its own reads of this one are done
+            const bool last_band = band == NB - 1;
+            const bool more = !last_band || gl + 1 < ngroups;
+            if (more) {
+                rt = rt_n;
+                cur = geometry(rt, last_band ? gl + 1 : gl);
+                const int band_nn = last_band ? (NB > 1 ? 1 : 0) : (band + 2 < NB ? band + 2 : 0);
+                rt_n = load_rt(band_nn);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (cur.fits) fetch_window(cur);
+            }
+            RUN_STAMP(3)
+            // the 3-plane counters hold at most 7 rows per lane: reduce them across lanes in time
+            if (++bands_pending == RUN_FLUSH_BANDS || last_band) {
+                bands_pending = 0;
+                acc = flush_columns(c0, c1, c2, tid, acc);
+                if (last_band) {
+                    // column counts of this wave's 16 columns over ALL rows: one plain store each
+                    const int col = ((g_begin + gl) * RUN_K + (wave >> 1)) * 32 + ((wave & 1) ? 0 : 16) + lane;
+                    if (lane < 16 && col < p.NC) {
+                        uint32_t *dst = vproj + ((int64_t)zscan * p.A + a) * p.NC + col;
+                        if (p.RCH == 1) *dst = acc;
+                        else atomicAdd(dst, acc);  // vproj was zeroed before the launch
+                    }
+                    acc = 0;
+                }
+            }
+            RUN_STAMP(4)
         }
-        RUN_STAMP(4)
-        // geometry two steps ahead (LDS reads only)
-        if (s + 2 < nsteps) {
-            int gl_nn = gl_n, band_nn = band_n + 1;
-            if (band_nn == NB) band_nn = 0, gl_nn = gl_n + 1;
-            nxt = geometry(gl_nn, band_nn);
-        }
-        gl = gl_n, band = band_n;
     }
+    if (__ballot(bad) != 0ull && lane == 0) guard[a] = 1;
     __syncthreads();
     // row counts of this chunk of word groups: u16 partials, two per dword
     uint32_t *__restrict__ out = (uint32_t *)(p.part + (((int64_t)zscan * p.A + a) * p.P + pc) * p.NRp + row0);
