@@ -21,7 +21,9 @@
 // at any window height) and waited for with the wave's own vmcnt -- no workgroup barrier per band.
 // The run tables of the next word group arrive by LDS-DMA while the current group is swept (two table
 // sets).  A workgroup walks a chunk of word groups of one candidate, so the row counts stay in LDS
-// until the chunk is done; the waves meet only when a group's column counters are reduced.
+// until the chunk is done.  There is NO workgroup barrier in the steady state: the hand-over of the
+// table sets and of the parked column counters is counted in a few LDS words, and a wave reduces its
+// share of a group's column counters one band LATER, when the slower waves have caught up.
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
 
@@ -52,7 +54,8 @@ namespace omr {
 #define RUN_WIN_OFS (RUN_TAB1_OFS + RUN_TABSET_BYTES)       // 29952: one window per wave
 #define RUN_PARK_OFS (RUN_WIN_OFS + RUN_WAVES * RUN_WIN_BYTES)  // column counters of a flush: [word][plane][wave][32 pairs]
 #define RUN_PARK_BYTES (RUN_K * 4 * 256 * 4)
-#define RUN_HROW_OFS (RUN_PARK_OFS + RUN_PARK_BYTES)        // row counts of the chunk, two u16 per dword
+#define RUN_FLAG_OFS (RUN_PARK_OFS + RUN_PARK_BYTES)        // [0..1] table slices landed (per group parity), [2] parked, [3] reduced
+#define RUN_HROW_OFS (RUN_FLAG_OFS + 16)                    // row counts of the chunk, two u16 per dword
 #define RUN_GEO_OFS (RUN_HROW_OFS + OMR_RUN_MAX_ROWS * 2)   // word-group constants of the chunk
 #define RUN_LDS_BYTES (RUN_GEO_OFS + OMR_RUN_GC * 32)
 static_assert(RUN_K == 4, "one (word, 16-column half) per wave in the column reduction");
@@ -585,15 +588,11 @@ __device__ __forceinline__ uint32_t dpp_pair_swap(uint32_t v)
     return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1 /* quad_perm [1,0,3,2] */, 0xF, 0xF, true);
 }
 
-// The waves run free between flushes, so two barriers frame the parking: the first says that every wave
-// has finished the PREVIOUS reduction (its reads of the park) and this group's sweep, the second that
-// every wave has parked.
-__device__ __forceinline__ uint32_t flush_columns(uint32_t (&c0)[RUN_K], uint32_t (&c1)[RUN_K], uint32_t (&c2)[RUN_K],
-                                                  const int tid, uint32_t acc)
+// This wave's column counters of the last <= 7 bands -> the park (lane pairs first add theirs: 4 planes).
+__device__ __forceinline__ void park_columns(uint32_t (&c0)[RUN_K], uint32_t (&c1)[RUN_K], uint32_t (&c2)[RUN_K], const int tid)
 {
     const int lane = tid & 63, wave = tid >> 6;
     const uint32_t mine = RUN_PARK_OFS + (uint32_t)((wave * 32 + (lane >> 1)) * 4);
-    __syncthreads();
 #pragma unroll
     for (int k = 0; k < RUN_K; k++) {
         // this lane's 3-plane counter + its neighbour's -> 4 planes (the same in both lanes of the pair)
@@ -609,8 +608,6 @@ __device__ __forceinline__ uint32_t flush_columns(uint32_t (&c0)[RUN_K], uint32_
         }
         c0[k] = c1[k] = c2[k] = 0;
     }
-    __syncthreads();
-    return reduce_columns(tid, acc);
 }
 
 #define RUN_FLUSH_BANDS 7  // 3-plane counters hold up to 7 rows per lane
@@ -735,21 +732,56 @@ __global__ __launch_bounds__(RUN_BAND, 4) void runs_kernel(const RunPass p, cons
             if (lane < nl) dma_b128(rs_img, voff, winbase + (uint32_t)(2 * n * RUN_WROWS * 4));
         }
     };
-    // run tables + (ca0, cb0) pairs of one word group -> LDS (all waves share the work)
-    auto fetch_tables = [&](const int gl, const int set) {
+    // A wave's slice of the run tables + (ca0, cb0) pairs of one word group -> LDS, set gl & 1 (the caller has
+    // checked that every wave has left group gl - 2)
+    auto fetch_tables = [&](const int gl) {
         const v4u32 rs_tab = make_rsrc(tab_base + (int64_t)gl * RUN_TABSET_BYTES, RUN_TABSET_BYTES);
         const v4u32 rs_met = make_rsrc(met_base + (int64_t)gl * (RUN_K * 8), RUN_K * 8);
-        const uint32_t tabbase = set ? RUN_TAB1_OFS : RUN_TAB0_OFS;
+        const uint32_t tabbase = (gl & 1) ? RUN_TAB1_OFS : RUN_TAB0_OFS;
 #pragma unroll
         for (int n = 0; n < (RUN_TABSET_BYTES / 16 + RUN_BAND - 1) / RUN_BAND; n++) {
             const int i = n * RUN_BAND + tid;
             if (i < RUN_TABSET_BYTES / 16) dma_b128(rs_tab, (uint32_t)(i * 16), tabbase + (uint32_t)(n * RUN_BAND * 16 + wave * 1024));
         }
-        if (tid < RUN_K * 2) dma_b32(rs_met, (uint32_t)(tid * 4), (uint32_t)(RUN_META_OFS + set * (RUN_K * 8)));
+        if (tid < RUN_K * 2) dma_b32(rs_met, (uint32_t)(tid * 4), (uint32_t)(RUN_META_OFS + (gl & 1) * (RUN_K * 8)));
+    };
+    // ---- the waves of a workgroup meet through four LDS counters instead of barriers.
+    //   landed[g & 1] += 1 per wave once its slice of group g's tables is in LDS (after its vmcnt(0)); a wave
+    //                    enters group g when landed[g & 1] >= 8 (g / 2 + 1)
+    //   parked        += 1 per wave and flush event f = 0, 1, .. once its column counters of the event are in the
+    //                    park.  Event f may be REDUCED when parked >= 8 (f + 1); with E events per group every wave
+    //                    has left group g when parked >= 8 E (g + 1), and then set g & 1 may take group g + 2's tables
+    //   reduced       += 1 per wave and event once it has summed its (word, half) of the event out of the park; the
+    //                    park may take event f + 1 when reduced >= 8 (f + 1)
+    // A wave reduces event f one band AFTER it parked (the band in between gives the slower waves time to park), so
+    // in the steady state nobody waits.  Every wait is on waves that are BEHIND the waiting one: the slowest wave
+    // never waits.  The polls are bounded all the same (a timeout hands the candidate to the gather kernel).
+    auto f_landed = [&](const int g) { return (lds_u32 *)(uintptr_t)(RUN_FLAG_OFS + (g & 1) * 4); };
+    lds_u32 *const f_parked = (lds_u32 *)(uintptr_t)(RUN_FLAG_OFS + 8), *const f_reduced = (lds_u32 *)(uintptr_t)(RUN_FLAG_OFS + 12);
+    auto peek = [&](lds_u32 *f) -> uint32_t {
+        return __builtin_amdgcn_readfirstlane(__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP));
+    };
+    auto poll = [&](lds_u32 *f, const uint32_t want) -> bool {
+        for (int it = 0; it < (1 << 22); it++) {
+            if (peek(f) >= want) return true;
+            __builtin_amdgcn_s_sleep(2);
+        }
+        return false;
+    };
+    auto bump = [&](lds_u32 *f) {
+        if (lane == 0) __hip_atomic_fetch_add(f, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
+    const int EV = (NB + RUN_FLUSH_BANDS - 1) / RUN_FLUSH_BANDS;  // flush events per group
+    int t_issued = 0, t_pub = 0;  // groups whose table slice this wave has issued / reported as landed
+    auto publish = [&]() {        // call right after this wave's s_waitcnt vmcnt(0)
+        for (; t_pub < t_issued; t_pub++) bump(f_landed(t_pub));
     };
 
-    __syncthreads();  // word-group constants are in LDS
-    fetch_tables(0, 0);
+    if (tid < 4) *(uint32_t *)(lds + RUN_FLAG_OFS + tid * 4) = 0u;
+    __syncthreads();  // word-group constants, zeroed counters (the only barrier before the epilogue)
+    fetch_tables(0);
+    if (ngroups > 1) fetch_tables(1);
+    t_issued = min(ngroups, 2);
     int2_t rt = load_rt(0);                      // this band's rows
     int2_t rt_n = NB > 1 ? load_rt(1) : rt;      // the next band's (the next group starts over at band 0)
     RunGeom cur = geometry(rt, 0);
@@ -759,22 +791,47 @@ __global__ __launch_bounds__(RUN_BAND, 4) void runs_kernel(const RunPass p, cons
     uint32_t c0[RUN_K], c1[RUN_K], c2[RUN_K];
 #pragma unroll
     for (int k = 0; k < RUN_K; k++) c0[k] = c1[k] = c2[k] = 0;
-    uint32_t acc = 0;  // lanes 0-15: column totals of this wave's (word, half) of the current group
-    bool bad = false;
+    uint32_t acc = 0;      // lanes 0-15: column totals of this wave's (word, half) of the group being reduced
+    bool bad = false;      // a window did not fit (the sweep goes on; the candidate is handed to the gather kernel)
+    bool timeout = false;  // a poll ran out (cannot happen unless the protocol is broken): leave
+    int ev_parked = 0;     // flush events this wave has parked
+    int pend_group = -1;   // >= 0: an event is parked but not reduced yet; its group, and whether it closed the group
+    bool pend_close = false;
+    // sum this wave's (word, half) of the parked event out of the park; at the end of a group write the totals out
+    auto reduce_pending = [&]() {
+        if (!poll(f_parked, (uint32_t)(RUN_WAVES * ev_parked))) timeout = true;
+        acc = reduce_columns(tid, acc);
+        bump(f_reduced);
+        if (pend_close) {
+            // column counts of this wave's 16 columns over ALL rows: one plain store each
+            const int col = ((g_begin + pend_group) * RUN_K + (wave >> 1)) * 32 + ((wave & 1) ? 0 : 16) + lane;
+            if (lane < 16 && col < p.NC) {
+                uint32_t *dst = vproj + ((int64_t)zscan * p.A + a) * p.NC + col;
+                if (p.RCH == 1) *dst = acc;
+                else atomicAdd(dst, acc);  // vproj was zeroed before the launch
+            }
+            acc = 0;
+        }
+        pend_group = -1;
+    };
     RUN_STAMP(0)
 
-    for (int gl = 0; gl < ngroups; gl++) {
-        const int tset = gl & 1;
-        // the group's tables: this wave's share has landed; after the barrier every wave's has (the first
-        // group's barrier is this one, later groups met at the end of the previous group's flush)
+    for (int gl = 0; gl < ngroups && !timeout; gl++) {
+        // ---- the group's tables: issue this wave's slice if the set was not free earlier, wait for every wave's
+        if (t_issued <= gl) {
+            if (!poll(f_parked, (uint32_t)(RUN_WAVES * EV * (gl - 1)))) timeout = true;
+            fetch_tables(gl);
+            t_issued = gl + 1;
+        }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (gl == 0) __syncthreads();
-        if (gl + 1 < ngroups) fetch_tables(gl + 1, tset ^ 1);  // every wave has left the other set behind
-        const uint32_t tabv = tset ? RUN_TAB1_OFS : RUN_TAB0_OFS;
+        publish();
+        if (!poll(f_landed(gl), (uint32_t)(RUN_WAVES * ((gl >> 1) + 1)))) timeout = true;
+        if (timeout) break;
+        const uint32_t tabv = (gl & 1) ? RUN_TAB1_OFS : RUN_TAB0_OFS;
         RunWordK wk[RUN_K];
 #pragma unroll
         for (int k = 0; k < RUN_K; k++) {
-            const int2 m = *(const int2 *)(lds + RUN_META_OFS + tset * (RUN_K * 8) + k * 8);
+            const int2 m = *(const int2 *)(lds + RUN_META_OFS + (gl & 1) * (RUN_K * 8) + k * 8);
             wk[k].ca0 = m.x, wk[k].cb0 = m.y;
         }
         const int32_t *bk = (const int32_t *)(lds + RUN_GEO_OFS + gl * 32);
@@ -783,6 +840,12 @@ __global__ __launch_bounds__(RUN_BAND, 4) void runs_kernel(const RunPass p, cons
         for (int band = 0; band < NB; band++) {
             // ---- this wave's window of (group, band) has landed (its own DMA: no barrier)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            publish();
+            // the next group's tables go out as soon as their set is free (every wave has left group gl - 1)
+            if (t_issued == gl + 1 && t_issued < ngroups && peek(f_parked) >= (uint32_t)(RUN_WAVES * EV * gl)) {
+                fetch_tables(gl + 1);
+                t_issued = gl + 2;
+            }
             RUN_STAMP(1)
             const RunGeom now = cur;
             bad |= !now.fits;
@@ -810,25 +873,24 @@ __global__ __launch_bounds__(RUN_BAND, 4) void runs_kernel(const RunPass p, cons
                 if (cur.fits) fetch_window(cur);
             }
             RUN_STAMP(3)
-            // the 3-plane counters hold at most 7 rows per lane: reduce them across lanes in time
+            // ---- the event parked one band ago: by now the other waves have parked theirs
+            if (pend_group >= 0) reduce_pending();
+            // the 3-plane counters hold at most 7 rows per lane: park them in time
             if (++bands_pending == RUN_FLUSH_BANDS || last_band) {
                 bands_pending = 0;
-                acc = flush_columns(c0, c1, c2, tid, acc);
-                if (last_band) {
-                    // column counts of this wave's 16 columns over ALL rows: one plain store each
-                    const int col = ((g_begin + gl) * RUN_K + (wave >> 1)) * 32 + ((wave & 1) ? 0 : 16) + lane;
-                    if (lane < 16 && col < p.NC) {
-                        uint32_t *dst = vproj + ((int64_t)zscan * p.A + a) * p.NC + col;
-                        if (p.RCH == 1) *dst = acc;
-                        else atomicAdd(dst, acc);  // vproj was zeroed before the launch
-                    }
-                    acc = 0;
-                }
+                if (!poll(f_reduced, (uint32_t)(RUN_WAVES * ev_parked))) timeout = true;  // the park is free again
+                park_columns(c0, c1, c2, tid);
+                bump(f_parked);
+                ev_parked++;
+                pend_group = gl;
+                pend_close = last_band;
             }
             RUN_STAMP(4)
+            if (timeout) break;
         }
     }
-    if (__ballot(bad) != 0ull && lane == 0) guard[a] = 1;
+    if (pend_group >= 0 && !timeout) reduce_pending();
+    if ((__ballot(bad) != 0ull || timeout) && lane == 0) guard[a] = 1;
     __syncthreads();
     // row counts of this chunk of word groups: u16 partials, two per dword
     uint32_t *__restrict__ out = (uint32_t *)(p.part + (((int64_t)zscan * p.A + a) * p.P + pc) * p.NRp + row0);
