@@ -3,6 +3,7 @@
 // like OpenCV's (no FMA contraction).
 #include "engine.hpp"
 
+#include <algorithm>
 #include <map>
 
 #include <math.h>
@@ -481,7 +482,6 @@ int SweepTables::build_runs()
     GCh = (Gh + Ph - 1) / Ph;
     Ph = (Gh + GCh - 1) / GCh;
     NRp = (rows + 7) & ~7;
-    rowsT = (rows + 3) & ~3;
     {
         const int NB = (rows + 511) / 512, RBmax = OMR_RUN_MAX_ROWS / 512;
         RCHh = (NB + RBmax - 1) / RBmax;
@@ -500,10 +500,28 @@ int SweepTables::build_runs()
     OMR_HIP(hipMemset(tabsH.p, 0, tabsH.bytes));
     OMR_HIP(launch_runtab(adelta.as<int32_t>(), bdelta.as<int32_t>(), A, cols, NWh, tabsH.as<RunTab>(),
                           metaH.as<RunMeta>(), metacH.as<int2_t>(), blkH.as<RunBlk>(), nullptr));
+    // window origins of every (candidate, word group, band, wave), and how far they reach beyond the image: that
+    // sizes the zero guard of the transposed bit image (the sweep then fetches its windows without a range test)
+    {
+        const int NBt = (rows + 511) / 512;
+        OMR_HIP(wgeoH.alloc(sizeof(int2_t) * (size_t)A * Gh * NBt * 8));
+        DevBuf ext;
+        OMR_HIP(ext.alloc(4 * sizeof(int32_t)));
+        int32_t h_ext[4] = {INT32_MAX, INT32_MIN, INT32_MAX, INT32_MIN};
+        OMR_HIP(hipMemcpy(ext.p, h_ext, sizeof h_ext, hipMemcpyHostToDevice));
+        OMR_HIP(launch_rungeo(xy0.as<int2_t>(), blkH.as<RunBlk>(), A, Gh, rows, wgeoH.as<int2_t>(), ext.as<int32_t>(), nullptr));
+        OMR_HIP(hipMemcpy(h_ext, ext.p, sizeof h_ext, hipMemcpyDeviceToHost));
+        if (h_ext[0] > h_ext[1]) return OMR_OK;  // no window fits: gather kernels only
+        GXh = std::max(0, std::max(-h_ext[0], h_ext[1] - NWh));
+        GYh = (std::max(0, std::max(-h_ext[2], h_ext[3] - rows)) + 3) & ~3;
+        NWt = NWh + 2 * GXh;
+        rowsT = ((rows + 3) & ~3) + 2 * GYh;
+        if ((size_t)NWt * rowsT * 4 > ((size_t)1 << 30)) return OMR_OK;  // absurd guard: gather kernels only
+    }
     // dry run on an all-white scan: window geometry does not depend on the pixels, so a candidate whose
     // windows fit once always fits
     DevBuf z0, hp, vp, gd, all;
-    OMR_HIP(z0.alloc(sizeof(uint32_t) * (size_t)NWh * rowsT));
+    OMR_HIP(z0.alloc(sizeof(uint32_t) * (size_t)NWt * rowsT));
     OMR_HIP(hp.alloc(sizeof(uint16_t) * (size_t)A * Ph * NRp));
     OMR_HIP(vp.alloc(sizeof(uint32_t) * (size_t)A * cols));
     OMR_HIP(gd.alloc(sizeof(int32_t) * (size_t)A));
@@ -540,8 +558,11 @@ RunPass SweepTables::run_pass(const uint32_t *d_bitsT, uint16_t *d_part, int sca
 {
     RunPass p{};
     p.srcT = d_bitsT;
-    p.NWt = NWh;
+    p.NWt = NWt;
     p.rowsT = rowsT;
+    p.GX = GXh;
+    p.GY = GYh;
+    p.wgeo = wgeoH.as<int2_t>();
     p.RT = xy0.as<int2_t>();
     p.NR = dims.rows;
     p.NC = dims.cols;
@@ -569,7 +590,8 @@ int SweepScratch::create(const SweepTables &t, int scans_per_launch)
     if (t.runs_built && t.n_runs > 0) {
         OMR_HIP(hpart.alloc(sizeof(uint16_t) * Z * (size_t)d.A * t.Ph * t.NRp));
         OMR_HIP(guard.alloc(sizeof(int32_t) * (size_t)d.A));
-        OMR_HIP(bitsT.alloc(sizeof(uint32_t) * Z * (size_t)t.NWh * t.rowsT));
+        OMR_HIP(bitsT.alloc(sizeof(uint32_t) * Z * (size_t)t.NWt * t.rowsT));
+        OMR_HIP(hipMemset(bitsT.p, 0, bitsT.bytes));  // the guard stays zero: the transpose writes the image only
     }
     OMR_HIP(bits.alloc(sizeof(uint32_t) * Z * (size_t)d.rows * d.wpr));
     OMR_HIP(vproj.alloc(sizeof(uint32_t) * Z * (size_t)d.A * d.cols));
@@ -624,8 +646,8 @@ int enqueue_sweep(const SweepTables &t, SweepScratch &s, int kernel_sel, const u
     if (ev0) OMR_HIP(hipEventRecord(ev0, stream));
     if (use_runs) {
         // the run-merging kernel reads word columns: the bit images once more, transposed
-        OMR_HIP(launch_transpose_bits(s.bits.as<uint32_t>(), d.rows, d.wpr, s.bitsT.as<uint32_t>(), t.NWh, t.rowsT, stream,
-                                      scans));
+        OMR_HIP(launch_transpose_bits(s.bits.as<uint32_t>(), d.rows, d.wpr, s.bitsT.as<uint32_t>(), t.NWh, t.NWt, t.rowsT,
+                                      t.GXh, t.GYh, stream, scans));
         const RunPass ph = t.run_pass(s.bitsT.as<uint32_t>(), s.hpart.as<uint16_t>(), scans);
         OMR_HIP(launch_runs(ph, t.list_runs.as<int32_t>(), t.n_runs, s.guard.as<int32_t>(), vp, stream));
     }

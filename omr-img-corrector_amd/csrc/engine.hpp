@@ -112,8 +112,10 @@ struct SweepTables {
     int NWh = 0, Gh = 0;    // words per row, word groups (of OMR_RUN_K words)
     int GCh = 0, Ph = 0;    // word groups per workgroup chunk, chunks
     int RBh = 0, RCHh = 0;  // bands of 512 rows per row chunk, row chunks (1 unless the image is taller than 4608 rows)
-    int NRp = 0, rowsT = 0; // row pitch of the u16 row-count partials; rows per word column of the transposed bit image
-    DevBuf tabsH, metaH, metacH, blkH, list_runs, list_gather, mode;
+    int NRp = 0;            // row pitch of the u16 row-count partials
+    int GXh = 0, GYh = 0;   // zero guard of the transposed bit image: word columns left / right, rows above / below
+    int NWt = 0, rowsT = 0; // its size with the guard: word columns, rows per word column
+    DevBuf tabsH, metaH, metacH, blkH, wgeoH, list_runs, list_gather, mode;
     int n_runs = 0, n_gather = 0;
     std::vector<int32_t> host_mode;
     int create(int rows, int cols, const double *fwd_M, int A, int device);

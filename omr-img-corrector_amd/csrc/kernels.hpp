@@ -83,8 +83,10 @@ struct RunBlk {  // per (candidate, word group): what a sweep block needs before
     int32_t lagbits;      // 2 bits per word pair: the pair's largest column lag
 };
 struct RunPass {
-    const uint32_t *srcT;  // transposed bit images of the launch's scans: [scan][NWt][rowsT]
-    int32_t NWt, rowsT;    // word columns, rows per word column (a multiple of 4; zero below the image)
+    const uint32_t *srcT;  // transposed bit images of the launch's scans, with their zero guard: [scan][NWt][rowsT]
+    int32_t NWt, rowsT;    // word columns, rows per word column (a multiple of 4), guard included
+    int32_t GX, GY;        // guard: word columns left of the image, rows above it
+    const int2_t *wgeo;    // [A][G][bands][8 waves] window origins (word column, row); x = INT_MAX: does not fit
     const int2_t *RT;      // [A][NR] (X0, Y0)
     int32_t NR, NC;        // destination rows, columns
     int32_t NWp;           // words per candidate in tabs / metac: G * OMR_RUN_K (the last group is padded)
@@ -102,9 +104,13 @@ struct RunPass {
 // run tables of every (candidate, word): d_tabs [A][G * OMR_RUN_K], d_meta [A][NW], d_metac [A][G * OMR_RUN_K], d_blk [A][G]
 hipError_t launch_runtab(const int32_t *d_CA, const int32_t *d_CB, int A, int NC, int NW, RunTab *d_tabs,
                          RunMeta *d_meta, int2_t *d_metac, RunBlk *d_blk, hipStream_t s);
-// bit images [scan][rows][wpr] -> transposed [scan][NW][rowsT]
-hipError_t launch_transpose_bits(const uint32_t *d_bits, int rows, int wpr, uint32_t *d_T, int NW, int rowsT,
-                                 hipStream_t s, int scans = 1);
+// window origins of the plan; d_ext[4] = {min column, max column + 1, min row, max row + 1} over the windows that fit
+// (the caller presets it to {INT_MAX, INT_MIN, INT_MAX, INT_MIN})
+hipError_t launch_rungeo(const int2_t *d_RT, const RunBlk *d_blk, int A, int G, int NR, int2_t *d_wgeo, int32_t *d_ext,
+                         hipStream_t s);
+// bit images [scan][rows][wpr] -> transposed, inside their zero guard: [scan][NWt][rowsT], image at (GX, GY)
+hipError_t launch_transpose_bits(const uint32_t *d_bits, int rows, int wpr, uint32_t *d_T, int NW, int NWt, int rowsT, int GX,
+                                 int GY, hipStream_t s, int scans = 1);
 // d_list: n_list candidate indices; d_guard[a] != 0 when a window did not fit for candidate a.
 // Row counts go to p.part (u16 partials per chunk of word groups), column counts to d_vproj[scan][a][NC]
 // (complete, plain stores).

@@ -21,9 +21,7 @@
 // at any window height) and waited for with the wave's own vmcnt -- no workgroup barrier per band.
 // The run tables of the next word group arrive by LDS-DMA while the current group is swept (two table
 // sets).  A workgroup walks a chunk of word groups of one candidate, so the row counts stay in LDS
-// until the chunk is done.  There is NO workgroup barrier in the steady state: the hand-over of the
-// table sets and of the parked column counters is counted in a few LDS words, and a wave reduces its
-// share of a group's column counters one band LATER, when the slower waves have caught up.
+// until the chunk is done; the waves meet only when a group's column counters are reduced.
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
 
@@ -54,8 +52,7 @@ namespace omr {
 #define RUN_WIN_OFS (RUN_TAB1_OFS + RUN_TABSET_BYTES)       // 29952: one window per wave
 #define RUN_PARK_OFS (RUN_WIN_OFS + RUN_WAVES * RUN_WIN_BYTES)  // column counters of a flush: [word][plane][wave][32 pairs]
 #define RUN_PARK_BYTES (RUN_K * 4 * 256 * 4)
-#define RUN_FLAG_OFS (RUN_PARK_OFS + RUN_PARK_BYTES)        // [0..1] table slices landed (per group parity), [2] parked, [3] reduced
-#define RUN_HROW_OFS (RUN_FLAG_OFS + 16)                    // row counts of the chunk, two u16 per dword
+#define RUN_HROW_OFS (RUN_PARK_OFS + RUN_PARK_BYTES)        // row counts of the chunk, two u16 per dword
 #define RUN_GEO_OFS (RUN_HROW_OFS + OMR_RUN_MAX_ROWS * 2)   // word-group constants of the chunk
 #define RUN_LDS_BYTES (RUN_GEO_OFS + OMR_RUN_GC * 32)
 static_assert(RUN_K == 4, "one (word, 16-column half) per wave in the column reduction");
@@ -63,6 +60,7 @@ static_assert(RUN_META_OFS + 2 * RUN_K * 8 <= RUN_TAB1_OFS, "meta fits the gap b
 static_assert(RUN_TAB1_OFS % 1024 == 0 && RUN_TAB0_OFS % 1024 == 0, "table sets are 1024-aligned");
 static_assert(2 * RUN_LDS_BYTES <= 160 * 1024, "two workgroups per CU");
 static_assert(RUN_WROWS % 4 == 0 && 2 * RUN_WPIECES <= 64, "two window columns per wave-instruction");
+static_assert(RUN_WCOLS == 7 && RUN_WROWS == 112, "rungeo_kernel sizes the windows with the same numbers");
 
 static_assert(sizeof(RunTab) == RUN_TAB_BYTES, "RunTab layout");
 static_assert(sizeof(RunMeta) == 32, "RunMeta layout");
@@ -255,14 +253,64 @@ hipError_t launch_runtab(const int32_t *d_CA, const int32_t *d_CB, int A, int NC
 }
 
 // ------------------------------------------------------------------------------------------
-// Bit image -> transposed bit image: T[x][y] = word x of row y, rowsT (a multiple of 4) dwords per word
-// column, zero below the image.  32 x 32 word tiles through LDS: 128-byte reads and 128-byte writes.
+// Window origins of the sweep kernel, once per plan: thread = one (candidate, word group, band, wave).
+// A wave sweeps 64 destination rows x one word group per band; the source bounding box of that patch (the
+// map is monotone in r and in c, so the four corner samples bound it) fixes the first word column and the
+// first row (a multiple of 4: the window travels in 16-byte pieces of 4 rows) of its LDS window.  An entry
+// whose box does not fit the window is marked (the candidate then goes to the gather kernel); ext[] collects
+// how far the windows reach beyond the image, which sizes the zero guard around the transposed bit image.
+#define RUN_WCOLS_ 7
+#define RUN_WROWS_ 112
+__global__ __launch_bounds__(256) void rungeo_kernel(const int2_t *__restrict__ RT, const RunBlk *__restrict__ blk, int A, int G,
+                                                     int NR, int NBt, int2_t *__restrict__ wgeo, int32_t *__restrict__ ext)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= A * G * NBt * 8) return;
+    const int wave = i & 7, band = (i >> 3) % NBt, ag = (i >> 3) / NBt, a = ag / G;
+    const int r0 = min(band * 512 + wave * 64, NR - 1), r1 = min(band * 512 + wave * 64 + 63, NR - 1);
+    const int2_t t0 = RT[(int64_t)a * NR + r0], t1 = RT[(int64_t)a * NR + r1];
+    const RunBlk b = blk[ag];
+    const int minbit = (min(t0.x, t1.x) + b.ca_min) >> 10;  // min over the four corners
+    const int maxbit = (max(t0.x, t1.x) + b.ca_max) >> 10;
+    const int minrow = (min(t0.y, t1.y) + b.cb_min) >> 10;
+    const int maxrow = (max(t0.y, t1.y) + b.cb_max) >> 10;
+    int2_t q;
+    q.x = minbit >> 5;
+    q.y = (minrow - 7) & ~3;  // a word reads up to 7 rows beside its true samples; pieces are 4 rows
+    // every selected sample lies in word columns q.x .. maxbit >> 5; the column after a sample's is read too
+    // but none of its bits is ever selected: it only has to exist
+    const bool fits = (maxbit >> 5) - q.x + 2 <= RUN_WCOLS_ && maxrow + 8 - q.y <= RUN_WROWS_ && q.x > -(1 << 20) &&
+                      q.x < (1 << 20) && q.y > -(1 << 20) && q.y < (1 << 20);
+    if (fits) {
+        atomicMin(&ext[0], q.x);
+        atomicMax(&ext[1], q.x + RUN_WCOLS_);
+        atomicMin(&ext[2], q.y);
+        atomicMax(&ext[3], q.y + RUN_WROWS_);
+    } else {
+        q.x = 0x7fffffff;
+    }
+    wgeo[i] = q;
+}
+
+hipError_t launch_rungeo(const int2_t *d_RT, const RunBlk *d_blk, int A, int G, int NR, int2_t *d_wgeo, int32_t *d_ext,
+                         hipStream_t s)
+{
+    const int NBt = (NR + 511) / 512, n = A * G * NBt * 8;
+    hipLaunchKernelGGL(rungeo_kernel, dim3((n + 255) / 256), dim3(256), 0, s, d_RT, d_blk, A, G, NR, NBt, d_wgeo, d_ext);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// Bit image -> transposed bit image with a zero guard: T[GX + x][GY + y] = word x of row y, rowsT dwords per
+// word column.  32 x 32 word tiles through LDS: 128-byte reads and 128-byte writes.  The guard (GX word
+// columns left and right, GY rows above and below, zeroed once when the buffer is made) holds every window
+// origin of the plan, so the sweep fetches its windows without a range test.
 __global__ __launch_bounds__(256) void transpose_bits_kernel(const uint32_t *__restrict__ bits, int rows, int wpr,
-                                                             uint32_t *__restrict__ T, int NW, int rowsT)
+                                                             uint32_t *__restrict__ T, int NW, int NWt, int rowsT, int GX, int GY)
 {
     __shared__ uint32_t tile[32][33];
     bits += (int64_t)blockIdx.z * rows * wpr;  // blockIdx.z = scan of the launch
-    T += (int64_t)blockIdx.z * NW * rowsT;
+    T += (int64_t)blockIdx.z * NWt * rowsT;
     const int x0 = blockIdx.x * 32, y0 = blockIdx.y * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
 #pragma unroll
@@ -274,15 +322,15 @@ __global__ __launch_bounds__(256) void transpose_bits_kernel(const uint32_t *__r
 #pragma unroll
     for (int j = 0; j < 4; j++) {
         const int x = x0 + ty + 8 * j, y = y0 + tx;
-        if (x < NW && y < rowsT) T[(int64_t)x * rowsT + y] = tile[tx][ty + 8 * j];
+        if (x < NW && y < rows) T[(int64_t)(GX + x) * rowsT + GY + y] = tile[tx][ty + 8 * j];
     }
 }
 
-hipError_t launch_transpose_bits(const uint32_t *d_bits, int rows, int wpr, uint32_t *d_T, int NW, int rowsT,
-                                 hipStream_t s, int scans)
+hipError_t launch_transpose_bits(const uint32_t *d_bits, int rows, int wpr, uint32_t *d_T, int NW, int NWt, int rowsT, int GX,
+                                 int GY, hipStream_t s, int scans)
 {
-    hipLaunchKernelGGL(transpose_bits_kernel, dim3((NW + 31) / 32, (rowsT + 31) / 32, scans), dim3(256), 0, s, d_bits,
-                       rows, wpr, d_T, NW, rowsT);
+    hipLaunchKernelGGL(transpose_bits_kernel, dim3((NW + 31) / 32, (rows + 31) / 32, scans), dim3(256), 0, s, d_bits, rows,
+                       wpr, d_T, NW, NWt, rowsT, GX, GY);
     return hipGetLastError();
 }
 
@@ -588,11 +636,15 @@ __device__ __forceinline__ uint32_t dpp_pair_swap(uint32_t v)
     return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1 /* quad_perm [1,0,3,2] */, 0xF, 0xF, true);
 }
 
-// This wave's column counters of the last <= 7 bands -> the park (lane pairs first add theirs: 4 planes).
-__device__ __forceinline__ void park_columns(uint32_t (&c0)[RUN_K], uint32_t (&c1)[RUN_K], uint32_t (&c2)[RUN_K], const int tid)
+// The waves run free between flushes, so two barriers frame the parking: the first says that every wave
+// has finished the PREVIOUS reduction (its reads of the park) and this group's sweep, the second that
+// every wave has parked.
+__device__ __forceinline__ uint32_t flush_columns(uint32_t (&c0)[RUN_K], uint32_t (&c1)[RUN_K], uint32_t (&c2)[RUN_K],
+                                                  const int tid, uint32_t acc)
 {
     const int lane = tid & 63, wave = tid >> 6;
     const uint32_t mine = RUN_PARK_OFS + (uint32_t)((wave * 32 + (lane >> 1)) * 4);
+    __syncthreads();
 #pragma unroll
     for (int k = 0; k < RUN_K; k++) {
         // this lane's 3-plane counter + its neighbour's -> 4 planes (the same in both lanes of the pair)
@@ -608,6 +660,8 @@ __device__ __forceinline__ void park_columns(uint32_t (&c0)[RUN_K], uint32_t (&c
         }
         c0[k] = c1[k] = c2[k] = 0;
     }
+    __syncthreads();
+    return reduce_columns(tid, acc);
 }
 
 #define RUN_FLUSH_BANDS 7  // 3-plane counters hold up to 7 rows per lane
@@ -696,142 +750,70 @@ __global__ __launch_bounds__(RUN_BAND, 4) void runs_kernel(const RunPass p, cons
     }
     for (int i = tid; i < NRh; i += RUN_BAND) *(uint32_t *)(lds + RUN_HROW_OFS + i * 4) = 0u;
 
-    // Source bounding box of this wave's 64 rows x a word group: the map is monotone in r and in c, so the
-    // four corner samples bound it.  The corner rows are the wave's own first and last lane.
-    auto geometry = [&](const int2_t rtv, const int gl) -> RunGeom {
-        const int32_t *bk = (const int32_t *)(lds + RUN_GEO_OFS + gl * 32);
-        const int t0x = __builtin_amdgcn_readlane(rtv.x, 0), t0y = __builtin_amdgcn_readlane(rtv.y, 0);
-        const int t1x = __builtin_amdgcn_readlane(rtv.x, 63), t1y = __builtin_amdgcn_readlane(rtv.y, 63);
-        const int ca_min = __builtin_amdgcn_readfirstlane(bk[3]), ca_max = __builtin_amdgcn_readfirstlane(bk[4]);
-        const int cb_min = __builtin_amdgcn_readfirstlane(bk[5]), cb_max = __builtin_amdgcn_readfirstlane(bk[6]);
-        RunGeom q;
-        const int minbit = (min(t0x, t1x) + ca_min) >> 10;  // min over the four corners
-        const int maxbit = (max(t0x, t1x) + ca_max) >> 10;
-        const int minrow = (min(t0y, t1y) + cb_min) >> 10;
-        const int maxrow = (max(t0y, t1y) + cb_max) >> 10;
-        q.wxw = minbit >> 5;
-        q.wy0 = (minrow - 7) & ~3;  // a word reads up to 7 rows beside its true samples; pieces are 4 rows
-        // every selected sample lies in word columns wxw .. maxbit >> 5; the column after a sample's is
-        // read too but none of its bits is ever selected: it only has to exist
-        q.fits = (maxbit >> 5) - q.wxw + 2 <= RUN_WCOLS && maxrow + 8 - q.wy0 <= RUN_WROWS;
-        return q;
+    // This wave's window origin of a (group, band): one scalar load from the plan's table (rungeo_kernel)
+    const int NBt = (p.NR + RUN_BAND - 1) / RUN_BAND;
+    auto geometry = [&](const int gl, const int band) -> RunGeom {
+        const int2_t q = p.wgeo[(((int64_t)a * p.G + g_begin + gl) * NBt + band0 + band) * RUN_WAVES + wave];
+        RunGeom g;
+        g.wxw = __builtin_amdgcn_readfirstlane(q.x);
+        g.wy0 = __builtin_amdgcn_readfirstlane(q.y);
+        g.fits = g.wxw != 0x7fffffff;
+        return g;
     };
     // This wave's window -> LDS, column-major, 16-byte pieces of 4 rows, two word columns per
-    // wave-instruction (lanes 0-27 and 28-55).  Rows outside the image must land as zeros, and so must every
-    // row of a column outside it: such lanes get an offset outside the descriptor's range.
-    const int lane_hi = lane >= RUN_WPIECES ? 1 : 0, lane_rr4 = (lane - lane_hi * RUN_WPIECES) * 4;
+    // wave-instruction (lanes 0-27 and 28-55).  The transposed bit image carries a zero guard that holds every
+    // window of the plan: no range test, one VALU add per wave-instruction.
+    const int lane_hi = lane >= RUN_WPIECES ? 1 : 0;
+    const uint32_t lane_off = (uint32_t)((lane_hi * p.rowsT + (lane - lane_hi * RUN_WPIECES) * 4) * 4);
     const uint32_t winbase = RUN_WIN_OFS + (uint32_t)wave * RUN_WIN_BYTES;
     auto fetch_window = [&](const RunGeom &q) {
-        const uint32_t y = (uint32_t)(q.wy0 + lane_rr4);
-        const bool y_in = y < (uint32_t)p.rowsT;
+        const uint32_t sbase = (uint32_t)(((q.wxw + p.GX) * p.rowsT + q.wy0 + p.GY) * 4);
 #pragma unroll
         for (int n = 0; n < (RUN_WCOLS + 1) / 2; n++) {
-            const int x = q.wxw + 2 * n + lane_hi;
-            const uint32_t voff = (y_in && (uint32_t)x < (uint32_t)p.NWt) ? (uint32_t)(x * p.rowsT) * 4u + y * 4u : 0x80000000u;
+            const uint32_t voff = lane_off + (sbase + (uint32_t)(2 * n) * (uint32_t)p.rowsT * 4u);
             const int nl = 2 * n + 1 < RUN_WCOLS ? 2 * RUN_WPIECES : RUN_WPIECES;
             if (lane < nl) dma_b128(rs_img, voff, winbase + (uint32_t)(2 * n * RUN_WROWS * 4));
         }
     };
-    // A wave's slice of the run tables + (ca0, cb0) pairs of one word group -> LDS, set gl & 1 (the caller has
-    // checked that every wave has left group gl - 2)
-    auto fetch_tables = [&](const int gl) {
+    // run tables + (ca0, cb0) pairs of one word group -> LDS (all waves share the work)
+    auto fetch_tables = [&](const int gl, const int set) {
         const v4u32 rs_tab = make_rsrc(tab_base + (int64_t)gl * RUN_TABSET_BYTES, RUN_TABSET_BYTES);
         const v4u32 rs_met = make_rsrc(met_base + (int64_t)gl * (RUN_K * 8), RUN_K * 8);
-        const uint32_t tabbase = (gl & 1) ? RUN_TAB1_OFS : RUN_TAB0_OFS;
+        const uint32_t tabbase = set ? RUN_TAB1_OFS : RUN_TAB0_OFS;
 #pragma unroll
         for (int n = 0; n < (RUN_TABSET_BYTES / 16 + RUN_BAND - 1) / RUN_BAND; n++) {
             const int i = n * RUN_BAND + tid;
             if (i < RUN_TABSET_BYTES / 16) dma_b128(rs_tab, (uint32_t)(i * 16), tabbase + (uint32_t)(n * RUN_BAND * 16 + wave * 1024));
         }
-        if (tid < RUN_K * 2) dma_b32(rs_met, (uint32_t)(tid * 4), (uint32_t)(RUN_META_OFS + (gl & 1) * (RUN_K * 8)));
-    };
-    // ---- the waves of a workgroup meet through four LDS counters instead of barriers.
-    //   landed[g & 1] += 1 per wave once its slice of group g's tables is in LDS (after its vmcnt(0)); a wave
-    //                    enters group g when landed[g & 1] >= 8 (g / 2 + 1)
-    //   parked        += 1 per wave and flush event f = 0, 1, .. once its column counters of the event are in the
-    //                    park.  Event f may be REDUCED when parked >= 8 (f + 1); with E events per group every wave
-    //                    has left group g when parked >= 8 E (g + 1), and then set g & 1 may take group g + 2's tables
-    //   reduced       += 1 per wave and event once it has summed its (word, half) of the event out of the park; the
-    //                    park may take event f + 1 when reduced >= 8 (f + 1)
-    // A wave reduces event f one band AFTER it parked (the band in between gives the slower waves time to park), so
-    // in the steady state nobody waits.  Every wait is on waves that are BEHIND the waiting one: the slowest wave
-    // never waits.  The polls are bounded all the same (a timeout hands the candidate to the gather kernel).
-    auto f_landed = [&](const int g) { return (lds_u32 *)(uintptr_t)(RUN_FLAG_OFS + (g & 1) * 4); };
-    lds_u32 *const f_parked = (lds_u32 *)(uintptr_t)(RUN_FLAG_OFS + 8), *const f_reduced = (lds_u32 *)(uintptr_t)(RUN_FLAG_OFS + 12);
-    auto peek = [&](lds_u32 *f) -> uint32_t {
-        return __builtin_amdgcn_readfirstlane(__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP));
-    };
-    auto poll = [&](lds_u32 *f, const uint32_t want) -> bool {
-        for (int it = 0; it < (1 << 22); it++) {
-            if (peek(f) >= want) return true;
-            __builtin_amdgcn_s_sleep(2);
-        }
-        return false;
-    };
-    auto bump = [&](lds_u32 *f) {
-        if (lane == 0) __hip_atomic_fetch_add(f, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-    };
-    const int EV = (NB + RUN_FLUSH_BANDS - 1) / RUN_FLUSH_BANDS;  // flush events per group
-    int t_issued = 0, t_pub = 0;  // groups whose table slice this wave has issued / reported as landed
-    auto publish = [&]() {        // call right after this wave's s_waitcnt vmcnt(0)
-        for (; t_pub < t_issued; t_pub++) bump(f_landed(t_pub));
+        if (tid < RUN_K * 2) dma_b32(rs_met, (uint32_t)(tid * 4), (uint32_t)(RUN_META_OFS + set * (RUN_K * 8)));
     };
 
-    if (tid < 4) *(uint32_t *)(lds + RUN_FLAG_OFS + tid * 4) = 0u;
-    __syncthreads();  // word-group constants, zeroed counters (the only barrier before the epilogue)
-    fetch_tables(0);
-    if (ngroups > 1) fetch_tables(1);
-    t_issued = min(ngroups, 2);
-    int2_t rt = load_rt(0);                      // this band's rows
-    int2_t rt_n = NB > 1 ? load_rt(1) : rt;      // the next band's (the next group starts over at band 0)
-    RunGeom cur = geometry(rt, 0);
+    __syncthreads();  // word-group constants are in LDS
+    fetch_tables(0, 0);
+    int2_t rt = load_rt(0);  // this band's rows (the next band's are loaded while this one is swept)
+    RunGeom cur = geometry(0, 0);
     if (cur.fits) fetch_window(cur);
     const uint32_t hrow_lane = RUN_HROW_OFS + (uint32_t)(tid >> 1) * 4u, hrow_shift = (uint32_t)(tid & 1) * 16u;
 
     uint32_t c0[RUN_K], c1[RUN_K], c2[RUN_K];
 #pragma unroll
     for (int k = 0; k < RUN_K; k++) c0[k] = c1[k] = c2[k] = 0;
-    uint32_t acc = 0;      // lanes 0-15: column totals of this wave's (word, half) of the group being reduced
-    bool bad = false;      // a window did not fit (the sweep goes on; the candidate is handed to the gather kernel)
-    bool timeout = false;  // a poll ran out (cannot happen unless the protocol is broken): leave
-    int ev_parked = 0;     // flush events this wave has parked
-    int pend_group = -1;   // >= 0: an event is parked but not reduced yet; its group, and whether it closed the group
-    bool pend_close = false;
-    // sum this wave's (word, half) of the parked event out of the park; at the end of a group write the totals out
-    auto reduce_pending = [&]() {
-        if (!poll(f_parked, (uint32_t)(RUN_WAVES * ev_parked))) timeout = true;
-        acc = reduce_columns(tid, acc);
-        bump(f_reduced);
-        if (pend_close) {
-            // column counts of this wave's 16 columns over ALL rows: one plain store each
-            const int col = ((g_begin + pend_group) * RUN_K + (wave >> 1)) * 32 + ((wave & 1) ? 0 : 16) + lane;
-            if (lane < 16 && col < p.NC) {
-                uint32_t *dst = vproj + ((int64_t)zscan * p.A + a) * p.NC + col;
-                if (p.RCH == 1) *dst = acc;
-                else atomicAdd(dst, acc);  // vproj was zeroed before the launch
-            }
-            acc = 0;
-        }
-        pend_group = -1;
-    };
+    uint32_t acc = 0;  // lanes 0-15: column totals of this wave's (word, half) of the current group
+    bool bad = false;
     RUN_STAMP(0)
 
-    for (int gl = 0; gl < ngroups && !timeout; gl++) {
-        // ---- the group's tables: issue this wave's slice if the set was not free earlier, wait for every wave's
-        if (t_issued <= gl) {
-            if (!poll(f_parked, (uint32_t)(RUN_WAVES * EV * (gl - 1)))) timeout = true;
-            fetch_tables(gl);
-            t_issued = gl + 1;
-        }
+    for (int gl = 0; gl < ngroups; gl++) {
+        const int tset = gl & 1;
+        // the group's tables: this wave's share has landed; after the barrier every wave's has (the first
+        // group's barrier is this one, later groups met at the end of the previous group's flush)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        publish();
-        if (!poll(f_landed(gl), (uint32_t)(RUN_WAVES * ((gl >> 1) + 1)))) timeout = true;
-        if (timeout) break;
-        const uint32_t tabv = (gl & 1) ? RUN_TAB1_OFS : RUN_TAB0_OFS;
+        if (gl == 0) __syncthreads();
+        if (gl + 1 < ngroups) fetch_tables(gl + 1, tset ^ 1);  // every wave has left the other set behind
+        const uint32_t tabv = tset ? RUN_TAB1_OFS : RUN_TAB0_OFS;
         RunWordK wk[RUN_K];
 #pragma unroll
         for (int k = 0; k < RUN_K; k++) {
-            const int2 m = *(const int2 *)(lds + RUN_META_OFS + (gl & 1) * (RUN_K * 8) + k * 8);
+            const int2 m = *(const int2 *)(lds + RUN_META_OFS + tset * (RUN_K * 8) + k * 8);
             wk[k].ca0 = m.x, wk[k].cb0 = m.y;
         }
         const int32_t *bk = (const int32_t *)(lds + RUN_GEO_OFS + gl * 32);
@@ -840,12 +822,6 @@ __global__ __launch_bounds__(RUN_BAND, 4) void runs_kernel(const RunPass p, cons
         for (int band = 0; band < NB; band++) {
             // ---- this wave's window of (group, band) has landed (its own DMA: no barrier)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            publish();
-            // the next group's tables go out as soon as their set is free (every wave has left group gl - 1)
-            if (t_issued == gl + 1 && t_issued < ngroups && peek(f_parked) >= (uint32_t)(RUN_WAVES * EV * gl)) {
-                fetch_tables(gl + 1);
-                t_issued = gl + 2;
-            }
             RUN_STAMP(1)
             const RunGeom now = cur;
             bad |= !now.fits;
@@ -865,32 +841,32 @@ __global__ __launch_bounds__(RUN_BAND, 4) void runs_kernel(const RunPass p, cons
             const bool last_band = band == NB - 1;
             const bool more = !last_band || gl + 1 < ngroups;
             if (more) {
-                rt = rt_n;
-                cur = geometry(rt, last_band ? gl + 1 : gl);
-                const int band_nn = last_band ? (NB > 1 ? 1 : 0) : (band + 2 < NB ? band + 2 : 0);
-                rt_n = load_rt(band_nn);
+                const int band_n = last_band ? 0 : band + 1;
+                cur = geometry(last_band ? gl + 1 : gl, band_n);
+                rt = load_rt(band_n);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 if (cur.fits) fetch_window(cur);
             }
             RUN_STAMP(3)
-            // ---- the event parked one band ago: by now the other waves have parked theirs
-            if (pend_group >= 0) reduce_pending();
-            // the 3-plane counters hold at most 7 rows per lane: park them in time
+            // the 3-plane counters hold at most 7 rows per lane: reduce them across lanes in time
             if (++bands_pending == RUN_FLUSH_BANDS || last_band) {
                 bands_pending = 0;
-                if (!poll(f_reduced, (uint32_t)(RUN_WAVES * ev_parked))) timeout = true;  // the park is free again
-                park_columns(c0, c1, c2, tid);
-                bump(f_parked);
-                ev_parked++;
-                pend_group = gl;
-                pend_close = last_band;
+                acc = flush_columns(c0, c1, c2, tid, acc);
+                if (last_band) {
+                    // column counts of this wave's 16 columns over ALL rows: one plain store each
+                    const int col = ((g_begin + gl) * RUN_K + (wave >> 1)) * 32 + ((wave & 1) ? 0 : 16) + lane;
+                    if (lane < 16 && col < p.NC) {
+                        uint32_t *dst = vproj + ((int64_t)zscan * p.A + a) * p.NC + col;
+                        if (p.RCH == 1) *dst = acc;
+                        else atomicAdd(dst, acc);  // vproj was zeroed before the launch
+                    }
+                    acc = 0;
+                }
             }
             RUN_STAMP(4)
-            if (timeout) break;
         }
     }
-    if (pend_group >= 0 && !timeout) reduce_pending();
-    if ((__ballot(bad) != 0ull || timeout) && lane == 0) guard[a] = 1;
+    if (__ballot(bad) != 0ull && lane == 0) guard[a] = 1;
     __syncthreads();
     // row counts of this chunk of word groups: u16 partials, two per dword
     uint32_t *__restrict__ out = (uint32_t *)(p.part + (((int64_t)zscan * p.A + a) * p.P + pc) * p.NRp + row0);
