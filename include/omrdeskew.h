@@ -176,6 +176,25 @@ int omr_batch_info(const omr_batch_ctx *ctx, int32_t *n_runs, int32_t *n_gather)
  * timed since the last call (timing must be enabled with omr_batch_set_timing).  Synchronises. */
 int omr_batch_set_timing(omr_batch_ctx *ctx, int32_t enabled);
 int omr_batch_kernel_ms(omr_batch_ctx *ctx, double *sum_ms, int32_t *launches);
+/* The reference's whole unit of work for a batch (omr.rs:339-452 correct_default; core/src/main.rs:69-92): detect
+ * every scan's angle, then rotate the scan by it with CONTAIN geometry (transfer.rs:487-519), border_value
+ * outside.  Sweep, arg-max and warp stay on the device: the warp reads the winning candidate's index there, and
+ * its fixed-point tables exist per candidate (matrices from the host's libm, like omr_rotate*).  interp is
+ * OMR_INTER_NEAREST (omr.rs:408-445) or OMR_INTER_LINEAR (core/src/main.rs:72-81).  Scan i's canvas fills the
+ * top-left dst_rows x dst_cols pixels of d_out + i * out_stride_bytes (rows out_step_bytes apart) and its size
+ * lands in d_out_size[2 i] (rows) and [2 i + 1] (cols); every slot must hold the largest canvas of the candidate
+ * set, omr_batch_deskew_canvas().  The result is what omr_rotate_device(angle = (best_idx - N) * step, scale 1,
+ * OMR_CLIP_CONTAIN) writes for the same scan, bit for bit.  d_best_idx (n int32) and d_out_size (2 n int32) may be
+ * NULL.  Returns after enqueueing, like omr_batch_run_device. */
+int omr_batch_deskew_canvas(omr_batch_ctx *ctx, int32_t *max_rows, int32_t *max_cols);
+int omr_batch_deskew_device(omr_batch_ctx *ctx, const uint8_t *d_scans, int64_t scan_stride_bytes,
+                            int64_t step_bytes, int32_t n, int32_t black_max, int32_t interp,
+                            uint8_t border_value, uint8_t *d_out, int64_t out_stride_bytes,
+                            int64_t out_step_bytes, int32_t *d_out_size, int32_t *d_best_idx);
+/* Streams and pinned staging blocks the per-call entry points lease from a bounded per-device pool (a host
+ * that runs every task on a fresh OS thread, thread_pool.rs:41-88, must not leak one of each per call):
+ * slots that exist, slots idle in the pool, pinned bytes held by idle slots.  Pointers may be NULL. */
+int omr_call_pool_stats(int32_t device, int32_t *live_slots, int32_t *idle_slots, int64_t *idle_pinned_bytes);
 
 /* Host-buffer batch over the visible devices (SURVEY.md 8b `omr_sweep_batch`): scans[i] goes
  * to device i % n_devices (pinned staging ring, copy / sweep overlapped, four scans per launch);

@@ -504,12 +504,12 @@ int SweepTables::build_runs()
     // sizes the zero guard of the transposed bit image (the sweep then fetches its windows without a range test)
     {
         const int NBt = (rows + 511) / 512;
-        OMR_HIP(wgeoH.alloc(sizeof(int2_t) * (size_t)A * Gh * NBt * 8));
+        OMR_HIP(wgeoH.alloc(sizeof(int4_t) * (size_t)A * Gh * NBt * 8));
         DevBuf ext;
         OMR_HIP(ext.alloc(4 * sizeof(int32_t)));
         int32_t h_ext[4] = {INT32_MAX, INT32_MIN, INT32_MAX, INT32_MIN};
         OMR_HIP(hipMemcpy(ext.p, h_ext, sizeof h_ext, hipMemcpyHostToDevice));
-        OMR_HIP(launch_rungeo(xy0.as<int2_t>(), blkH.as<RunBlk>(), A, Gh, rows, wgeoH.as<int2_t>(), ext.as<int32_t>(), nullptr));
+        OMR_HIP(launch_rungeo(xy0.as<int2_t>(), blkH.as<RunBlk>(), A, Gh, rows, wgeoH.as<int4_t>(), ext.as<int32_t>(), nullptr));
         OMR_HIP(hipMemcpy(h_ext, ext.p, sizeof h_ext, hipMemcpyDeviceToHost));
         if (h_ext[0] > h_ext[1]) return OMR_OK;  // no window fits: gather kernels only
         GXh = std::max(0, std::max(-h_ext[0], h_ext[1] - NWh));
@@ -562,7 +562,7 @@ RunPass SweepTables::run_pass(const uint32_t *d_bitsT, uint16_t *d_part, int sca
     p.rowsT = rowsT;
     p.GX = GXh;
     p.GY = GYh;
-    p.wgeo = wgeoH.as<int2_t>();
+    p.wgeo = wgeoH.as<int4_t>();
     p.RT = xy0.as<int2_t>();
     p.NR = dims.rows;
     p.NC = dims.cols;
@@ -982,12 +982,62 @@ int omr_batch_set_timing(omr_batch_ctx *ctx, int32_t enabled)
     return OMR_OK;
 }
 
-int omr_batch_run_device(omr_batch_ctx *ctx, const uint8_t *d_scans, int64_t scan_stride, int64_t step_bytes,
-                         int32_t n, int32_t black_max, int32_t *d_best_idx, double *d_v_sd, double *d_h_sd)
+namespace {
+struct DeskewOut {  // omr_batch_deskew_device's extra stage
+    int interp;
+    int border;
+    uint8_t *d_out;
+    int64_t out_stride, out_step;
+    int32_t *d_out_size;
+};
+
+// per candidate: CONTAIN canvas + warpAffine's tables of its rotation (transfer.rs:487-519), once per context
+int build_deskew_tables(omr_batch_ctx *ctx)
 {
-    if (!ctx || !d_scans || n < 0) return fail(OMR_ERR_BADARG, "bad batch arguments");
-    std::lock_guard<std::mutex> lk(ctx->mu);
-    OMR_HIP(hipSetDevice(ctx->tables.device));
+    if (ctx->dk_built) return OMR_OK;
+    NoPoolScope ctx_owned;
+    const SweepDims &d = ctx->tables.dims;
+    const int A = d.A;
+    std::vector<double> minv((size_t)A * 6);
+    std::vector<int32_t> size((size_t)A * 2);
+    int DR = 0, DC = 0;
+    for (int i = 0; i < A; i++) {
+        double M[6];
+        int dr, dc;
+        int rc = rotate_geometry(d.rows, d.cols, (double)(i - ctx->N) * ctx->step, 1.0, OMR_CLIP_CONTAIN, M, &dr, &dc);
+        if (rc) return rc;
+        invert_affine(M, &minv[6 * (size_t)i]);
+        size[2 * (size_t)i] = dr;
+        size[2 * (size_t)i + 1] = dc;
+        DR = std::max(DR, dr);
+        DC = std::max(DC, dc);
+    }
+    DC = (DC + 3) & ~3;
+    DevBuf d_minv, ovf;
+    OMR_HIP(d_minv.alloc(sizeof(double) * minv.size()));
+    OMR_HIP(ovf.alloc(sizeof(int32_t)));
+    OMR_HIP(ctx->dk_size.alloc(sizeof(int32_t) * size.size()));
+    OMR_HIP(ctx->dk_adelta.alloc(sizeof(int32_t) * (size_t)A * DC));
+    OMR_HIP(ctx->dk_bdelta.alloc(sizeof(int32_t) * (size_t)A * DC));
+    OMR_HIP(ctx->dk_xy0.alloc(sizeof(int2_t) * (size_t)A * DR));
+    OMR_HIP(hipMemcpy(d_minv.p, minv.data(), sizeof(double) * minv.size(), hipMemcpyHostToDevice));
+    OMR_HIP(hipMemcpy(ctx->dk_size.p, size.data(), sizeof(int32_t) * size.size(), hipMemcpyHostToDevice));
+    OMR_HIP(hipMemset(ovf.p, 0, sizeof(int32_t)));
+    SweepDims td{DR, DC, A, 0};
+    OMR_HIP(launch_tables(d_minv.as<double>(), td, 0, ctx->dk_adelta.as<int32_t>(), ctx->dk_bdelta.as<int32_t>(),
+                          ctx->dk_xy0.as<int2_t>(), ovf.as<int32_t>(), nullptr));
+    int32_t h_ovf = 0;
+    OMR_HIP(hipMemcpy(&h_ovf, ovf.p, sizeof h_ovf, hipMemcpyDeviceToHost));  // also: the tables are complete
+    if (h_ovf) return fail(OMR_ERR_BADARG, "affine map leaves the 32-bit fixed-point range of warpAffine");
+    ctx->dk_rows = DR;
+    ctx->dk_cols = DC;
+    ctx->dk_built = true;
+    return OMR_OK;
+}
+
+int batch_run(omr_batch_ctx *ctx, const uint8_t *d_scans, int64_t scan_stride, int64_t step_bytes, int32_t n,
+              int32_t black_max, int32_t *d_best_idx, double *d_v_sd, double *d_h_sd, const DeskewOut *dk)
+{
     const int S = (int)ctx->streams.size();
     const int A = ctx->tables.dims.A;
     for (int i = 0, launch = 0; i < n; launch++) {
@@ -1007,21 +1057,92 @@ int omr_batch_run_device(omr_batch_ctx *ctx, const uint8_t *d_scans, int64_t sca
         }
         const int set = 2 * k + (int)(ctx->issued[k] & 1);
         ctx->issued[k]++;
-        // this scratch set's previous std-dev / arg-max must have read its projections
+        // this scratch set's previous std-dev / arg-max (/ warp) must have read its projections (/ best indices)
         if (ctx->post_pending[set]) OMR_HIP(hipStreamWaitEvent(ctx->streams[k], ctx->ev_post[set], 0));
+        // the warp reads the winners on the device: the caller's array, or the scratch set's
+        int32_t *best = d_best_idx ? d_best_idx + i : (dk ? ctx->scratch[set]->best.as<int32_t>() : nullptr);
         int rc = enqueue_sweep(ctx->tables, *ctx->scratch[set], KERNEL_AUTO, d_scans + (size_t)i * scan_stride,
                                step_bytes, black_max, ctx->streams[k], nullptr, nullptr,
-                               d_v_sd ? d_v_sd + (size_t)i * A : nullptr, d_h_sd ? d_h_sd + (size_t)i * A : nullptr,
-                               d_best_idx ? d_best_idx + i : nullptr, e0, e1, false, ctx->post_streams[k],
-                               ctx->ev_mid[set], z, scan_stride);
-        if (!rc) {
-            if (hipEventRecord(ctx->ev_post[set], ctx->post_streams[k]) != hipSuccess)
-                return fail(OMR_ERR_GPU, "hipEventRecord failed");
-            ctx->post_pending[set] = 1;
-        }
+                               d_v_sd ? d_v_sd + (size_t)i * A : nullptr, d_h_sd ? d_h_sd + (size_t)i * A : nullptr, best, e0,
+                               e1, false, ctx->post_streams[k], ctx->ev_mid[set], z, scan_stride);
         if (rc) return rc;
+        if (dk) {  // after the arg-max, on the post stream: overlaps the next group's sweep
+            DeskewPass p{};
+            p.src = d_scans + (size_t)i * scan_stride;
+            p.scan_stride = scan_stride;
+            p.sstep = step_bytes;
+            p.srows = ctx->tables.dims.rows;
+            p.scols = ctx->tables.dims.cols;
+            p.dst = dk->d_out + (size_t)i * dk->out_stride;
+            p.out_stride = dk->out_stride;
+            p.dstep = dk->out_step;
+            p.best = best;
+            p.wsize = ctx->dk_size.as<int32_t>();
+            p.adelta = ctx->dk_adelta.as<int32_t>();
+            p.bdelta = ctx->dk_bdelta.as<int32_t>();
+            p.xy0 = ctx->dk_xy0.as<int2_t>();
+            p.DC = ctx->dk_cols;
+            p.DR = ctx->dk_rows;
+            p.border = dk->border;
+            p.out_size = dk->d_out_size ? dk->d_out_size + 2 * (size_t)i : nullptr;
+            OMR_HIP(launch_deskew_warp(p, z, dk->interp, ctx->post_streams[k]));
+        }
+        if (hipEventRecord(ctx->ev_post[set], ctx->post_streams[k]) != hipSuccess)
+            return fail(OMR_ERR_GPU, "hipEventRecord failed");
+        ctx->post_pending[set] = 1;
         i += z;
     }
+    return OMR_OK;
+}
+}  // namespace
+
+int omr_batch_run_device(omr_batch_ctx *ctx, const uint8_t *d_scans, int64_t scan_stride, int64_t step_bytes,
+                         int32_t n, int32_t black_max, int32_t *d_best_idx, double *d_v_sd, double *d_h_sd)
+{
+    if (!ctx || !d_scans || n < 0) return fail(OMR_ERR_BADARG, "bad batch arguments");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    OMR_HIP(hipSetDevice(ctx->tables.device));
+    return batch_run(ctx, d_scans, scan_stride, step_bytes, n, black_max, d_best_idx, d_v_sd, d_h_sd, nullptr);
+}
+
+int omr_batch_deskew_canvas(omr_batch_ctx *ctx, int32_t *max_rows, int32_t *max_cols)
+{
+    if (!ctx) return fail(OMR_ERR_BADARG, "null ctx");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    OMR_HIP(hipSetDevice(ctx->tables.device));
+    int rc = build_deskew_tables(ctx);
+    if (rc) return rc;
+    if (max_rows) *max_rows = ctx->dk_rows;
+    if (max_cols) *max_cols = ctx->dk_cols;
+    return OMR_OK;
+}
+
+int omr_batch_deskew_device(omr_batch_ctx *ctx, const uint8_t *d_scans, int64_t scan_stride, int64_t step_bytes, int32_t n,
+                            int32_t black_max, int32_t interp, uint8_t border_value, uint8_t *d_out, int64_t out_stride,
+                            int64_t out_step, int32_t *d_out_size, int32_t *d_best_idx)
+{
+    if (!ctx || !d_scans || !d_out || n < 0) return fail(OMR_ERR_BADARG, "bad batch arguments");
+    if (interp != OMR_INTER_NEAREST && interp != OMR_INTER_LINEAR)
+        return fail(OMR_ERR_NOTIMPL, "interpolation flag %d is not implemented", interp);
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    OMR_HIP(hipSetDevice(ctx->tables.device));
+    int rc = build_deskew_tables(ctx);
+    if (rc) return rc;
+    if (out_step < ctx->dk_cols || out_stride < (int64_t)ctx->dk_rows * out_step)
+        return fail(OMR_ERR_BADARG, "every output slot must hold the largest canvas, %d x %d (omr_batch_deskew_canvas)",
+                    ctx->dk_cols, ctx->dk_rows);
+    DeskewOut dk{interp, (int)border_value, d_out, out_stride, out_step, d_out_size};
+    return batch_run(ctx, d_scans, scan_stride, step_bytes, n, black_max, d_best_idx, nullptr, nullptr, &dk);
+}
+
+int omr_call_pool_stats(int32_t device, int32_t *live_slots, int32_t *idle_slots, int64_t *idle_pinned_bytes)
+{
+    int live = 0, idle = 0;
+    size_t pinned = 0;
+    call_slot_stats(device, &live, &idle, &pinned);
+    if (live_slots) *live_slots = live;
+    if (idle_slots) *idle_slots = idle;
+    if (idle_pinned_bytes) *idle_pinned_bytes = (int64_t)pinned;
     return OMR_OK;
 }
 

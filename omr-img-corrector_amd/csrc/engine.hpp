@@ -97,6 +97,8 @@ void rotation_matrix_2d(float cx, float cy, double angle_deg, double scale, doub
 void invert_affine(const double M[6], double Minv[6]);
 int candidate_count(uint16_t max_angle, double step, int *N_out);  // projection.rs:36-38
 void sweep_matrices(int rows, int cols, int N, double step, double scale, double *M_out);
+// rotate_mat's forward matrix and canvas (transfer.rs:459-523; oics_host.cpp)
+int rotate_geometry(int rows, int cols, double angle_deg, double scale, int clip, double M[6], int *drows, int *dcols);
 
 // Immutable per-(shape, matrices) state: inverse matrices, fixed-point tables, LDS tiling.
 struct SweepTables {
@@ -171,6 +173,10 @@ struct omr_batch_ctx {
     size_t events_used = 0;
     bool timing = false;
     int group = 1;  // scans per kernel launch (omr_batch_set_group)
+    // final deskew (omr_batch_deskew_device): per candidate the CONTAIN canvas and warpAffine's fixed-point tables
+    bool dk_built = false;
+    int dk_rows = 0, dk_cols = 0;  // largest canvas (cols rounded up to 4)
+    omr::DevBuf dk_size, dk_adelta, dk_bdelta, dk_xy0;
     std::mutex mu;
     ~omr_batch_ctx();
 };

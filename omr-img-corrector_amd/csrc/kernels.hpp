@@ -8,6 +8,9 @@ namespace omr {
 struct int2_t {
     int32_t x, y;
 };
+struct int4_t {
+    int32_t x, y, z, w;
+};
 
 // Sweep geometry shared by host and device.
 struct SweepDims {
@@ -86,7 +89,8 @@ struct RunPass {
     const uint32_t *srcT;  // transposed bit images of the launch's scans, with their zero guard: [scan][NWt][rowsT]
     int32_t NWt, rowsT;    // word columns, rows per word column (a multiple of 4), guard included
     int32_t GX, GY;        // guard: word columns left of the image, rows above it
-    const int2_t *wgeo;    // [A][G][bands][8 waves] window origins (word column, row); x = INT_MAX: does not fit
+    const int4_t *wgeo;    // [A][G][bands][8 waves] windows: first word column, first row, (first piece | pieces << 8 |
+                           // columns << 16) to fetch; x = INT_MAX: does not fit
     const int2_t *RT;      // [A][NR] (X0, Y0)
     int32_t NR, NC;        // destination rows, columns
     int32_t NWp;           // words per candidate in tabs / metac: G * OMR_RUN_K (the last group is padded)
@@ -106,7 +110,7 @@ hipError_t launch_runtab(const int32_t *d_CA, const int32_t *d_CB, int A, int NC
                          RunMeta *d_meta, int2_t *d_metac, RunBlk *d_blk, hipStream_t s);
 // window origins of the plan; d_ext[4] = {min column, max column + 1, min row, max row + 1} over the windows that fit
 // (the caller presets it to {INT_MAX, INT_MIN, INT_MAX, INT_MIN})
-hipError_t launch_rungeo(const int2_t *d_RT, const RunBlk *d_blk, int A, int G, int NR, int2_t *d_wgeo, int32_t *d_ext,
+hipError_t launch_rungeo(const int2_t *d_RT, const RunBlk *d_blk, int A, int G, int NR, int4_t *d_wgeo, int32_t *d_ext,
                          hipStream_t s);
 // bit images [scan][rows][wpr] -> transposed, inside their zero guard: [scan][NWt][rowsT], image at (GX, GY)
 hipError_t launch_transpose_bits(const uint32_t *d_bits, int rows, int wpr, uint32_t *d_T, int NW, int NWt, int rowsT, int GX,
@@ -159,6 +163,23 @@ hipError_t launch_warp_nn(const uint8_t *d_src, int64_t sstep, int srows, int sc
 hipError_t launch_warp_linear(const uint8_t *d_src, int64_t sstep, int srows, int scols, int cn,
                               uint8_t *d_dst, int64_t dstep, int drows, int dcols,
                               const double *d_Minv, uint32_t border_rgba, hipStream_t s);
+
+// ---- batched final deskew (deskew.hip): scan z is rotated by the candidate best[z]'s angle, CONTAIN geometry
+struct DeskewPass {
+    const uint8_t *src;       // scans, 1 channel: scan_stride bytes apart, sstep bytes per row
+    int64_t scan_stride, sstep;
+    int32_t srows, scols;
+    uint8_t *dst;             // canvases: out_stride bytes apart, dstep bytes per row, each holds DR x DC pixels
+    int64_t out_stride, dstep;
+    const int32_t *best;      // [scans] winning candidate per scan (device)
+    const int32_t *wsize;     // [A][2] canvas rows, cols per candidate
+    const int32_t *adelta, *bdelta;  // [A][DC] warpAffine's column tables of the candidate's CONTAIN matrix
+    const int2_t *xy0;        // [A][DR] its row tables, without the round delta
+    int32_t DC, DR;           // largest canvas over the candidates (DC a multiple of 4)
+    int32_t border;           // border value (0..255)
+    int32_t *out_size;        // [scans][2] canvas rows, cols of every scan (device), or null
+};
+hipError_t launch_deskew_warp(const DeskewPass &p, int scans, int interp, hipStream_t s);
 
 // ---- tuned single-channel stage kernels (stages.hip); each falls back to the generic form -------
 hipError_t launch_rgb2gray_fast(const uint8_t *d_src, int64_t sstep, int rows, int cols, int cn, uint8_t *d_dst,

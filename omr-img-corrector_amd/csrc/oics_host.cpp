@@ -496,7 +496,7 @@ int omr_rgb_to_gray(const omr_image *src, uint8_t *dst, int64_t dst_step)
 }
 
 // transfer.rs:459-523: forward matrix and canvas of rotate_mat
-static int rotate_geometry(int rows, int cols, double angle_deg, double scale, int clip, double M[6], int *drows,
+static int rotate_geometry_impl(int rows, int cols, double angle_deg, double scale, int clip, double M[6], int *drows,
                            int *dcols)
 {
     if (clip == OMR_CLIP_DEFAULT) {  // :472-486
@@ -549,7 +549,7 @@ int omr_rotate_size(int32_t rows, int32_t cols, double angle_deg, int32_t clip, 
     if (!dst_rows || !dst_cols || rows <= 0 || cols <= 0) return fail(OMR_ERR_BADARG, "bad arguments");
     double M[6];
     int dr, dc;
-    int rc = rotate_geometry(rows, cols, angle_deg, 1.0, clip, M, &dr, &dc);
+    int rc = rotate_geometry_impl(rows, cols, angle_deg, 1.0, clip, M, &dr, &dc);
     if (rc) return rc;
     *dst_rows = dr;
     *dst_cols = dc;
@@ -567,7 +567,7 @@ int omr_rotate_device(const uint8_t *d_src, int64_t src_step, int32_t rows, int3
         return fail(OMR_ERR_NOTIMPL, "interpolation flag %d is not implemented", interp);
     double M[6];
     int dr, dc;
-    int rc = rotate_geometry(rows, cols, angle_deg, scale, clip, M, &dr, &dc);
+    int rc = rotate_geometry_impl(rows, cols, angle_deg, scale, clip, M, &dr, &dc);
     if (rc) return rc;
     if (dr != dst_rows || dc != dst_cols) return fail(OMR_ERR_ASSERT, "destination must be %dx%d", dc, dr);
     if (src_step < (int64_t)cols * channels || dst_step < (int64_t)dc * channels) return fail(OMR_ERR_BADARG, "step too small");
@@ -588,7 +588,7 @@ int omr_rotate(const omr_image *src, double angle_deg, double scale, int32_t int
         return fail(OMR_ERR_NOTIMPL, "interpolation flag %d is not implemented", interp);
     double M[6];
     int drows, dcols;
-    if ((rc = rotate_geometry(src->rows, src->cols, angle_deg, scale, clip, M, &drows, &dcols))) return rc;
+    if ((rc = rotate_geometry_impl(src->rows, src->cols, angle_deg, scale, clip, M, &drows, &dcols))) return rc;
     int dev;
     if ((rc = current_device(&dev))) return rc;
     Stream st;
@@ -960,7 +960,7 @@ int rotate_device_to_host(const uint8_t *d_src, int rows, int cols, int cn, doub
 {
     double M[6];
     int drows, dcols, rc;
-    if ((rc = rotate_geometry(rows, cols, angle_deg, scale, clip, M, &drows, &dcols))) return rc;
+    if ((rc = rotate_geometry_impl(rows, cols, angle_deg, scale, clip, M, &drows, &dcols))) return rc;
     DevImage out;
     DevBuf keep;
     if ((rc = out.alloc(drows, dcols, cn))) return rc;
@@ -968,5 +968,9 @@ int rotate_device_to_host(const uint8_t *d_src, int rows, int cols, int cn, doub
                             dcols, s, &keep)))
         return rc;
     return give_owned(out, dst, s);
+}
+int rotate_geometry(int rows, int cols, double angle_deg, double scale, int clip, double M[6], int *drows, int *dcols)
+{
+    return rotate_geometry_impl(rows, cols, angle_deg, scale, clip, M, drows, dcols);
 }
 }  // namespace omr

@@ -152,6 +152,18 @@ class Batch:
         check(lib().omr_batch_run_device(self.handle, d_scans, scan_stride, step_bytes, n, black_max, d_best, d_v_sd,
                                          d_h_sd))
 
+    def deskew_canvas(self):
+        """(rows, cols) every output slot of deskew_device must hold: the largest CONTAIN canvas of the candidates"""
+        r, c = C.c_int32(), C.c_int32()
+        check(lib().omr_batch_deskew_canvas(self.handle, C.byref(r), C.byref(c)))
+        return r.value, c.value
+
+    def deskew_device(self, d_scans, scan_stride, step_bytes, n, black_max, interp, border, d_out, out_stride, out_step,
+                      d_out_size=None, d_best=None):
+        """omr.rs:339-452 for a batch: sweep -> arg-max -> CONTAIN warp by the detected angle, all on the device"""
+        check(lib().omr_batch_deskew_device(self.handle, d_scans, scan_stride, step_bytes, n, black_max, interp, border,
+                                            d_out, out_stride, out_step, d_out_size, d_best))
+
     def sync(self):
         check(lib().omr_batch_sync(self.handle))
 

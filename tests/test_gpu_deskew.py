@@ -1,0 +1,119 @@
+"""The batch's last stage (round-2 verdict, item 2): omr_batch_deskew_device = sweep -> arg-max -> CONTAIN warp by
+the detected angle, all on the device (omr.rs:339-452 correct_default for a batch; NEAREST as omr.rs:408-445,
+LINEAR as core/src/main.rs:72-81).  Checked against the oracle's rotate_mat on every scan of a small batch and on a
+sample of an A4 batch: NEAREST exact, LINEAR within one grey level (and bit-identical to the per-call omr_rotate,
+which the other parity tests pin).  Plus the bounded stream / pinned-memory pool behind the per-call entry points
+(round-2 advice: nothing may be owned by a host thread -- the app runs every task on a fresh one)."""
+import ctypes as C
+import threading
+
+import numpy as np
+import pytest
+
+import oics
+from oics import projection, synth, transfer
+from oics.types import RotateClipStrategy
+
+pytestmark = pytest.mark.gpu
+
+NEAREST, LINEAR = 0, 1
+
+
+def _run_batch(cards, max_angle, step, interp, group):
+    import torch
+    n, rows, cols = cards.shape
+    dev = torch.device("cuda:0")
+    scans = torch.from_numpy(cards).to(dev)
+    b = projection.Batch(rows, cols, max_angle, step, device=0, n_streams=1)
+    b.set_group(group)
+    dr, dc = b.deskew_canvas()
+    assert dc % 4 == 0
+    out = torch.full((n, dr, dc), 7, dtype=torch.uint8, device=dev)  # 7: "untouched"
+    size = torch.zeros((n, 2), dtype=torch.int32, device=dev)
+    best = torch.full((n,), -1, dtype=torch.int32, device=dev)
+    b.deskew_device(scans.data_ptr(), rows * cols, cols, n, 127, interp, 255, out.data_ptr(), dr * dc, dc, size.data_ptr(),
+                    best.data_ptr())
+    b.sync()
+    # the same scans through the angle-only entry point: same winners
+    best2 = torch.full((n,), -1, dtype=torch.int32, device=dev)
+    b.run_device(scans.data_ptr(), rows * cols, cols, n, 127, best2.data_ptr())
+    b.sync()
+    N = b.N
+    b.close()
+    assert (best.cpu().numpy() == best2.cpu().numpy()).all()
+    return out.cpu().numpy(), size.cpu().numpy(), best.cpu().numpy(), N
+
+
+@pytest.mark.parametrize("interp", [NEAREST, LINEAR])
+def test_batch_deskew_small_batch_every_scan(oracle, interp):
+    rows, cols, max_angle, step = 640, 452, 10, 0.5
+    skews = [-9.3, -4.0, -0.2, 0.0, 0.7, 3.1, 6.6, 9.4, 2.2, -7.5, 5.0]  # 11 scans: a last group of 3 at group = 4
+    cards = np.stack([synth.make_card(rows, cols, 100 + i, skew=s)[0] for i, s in enumerate(skews)])
+    out, size, best, N = _run_batch(cards, max_angle, step, interp, group=4)
+    for i in range(len(skews)):
+        angle = (int(best[i]) - N) * step
+        assert abs(angle - skews[i]) <= step, (i, angle, skews[i])
+        exp = oracle.rotate_mat(cards[i], angle, 1.0, interp, (255, 255, 255, 0), 1)
+        dr, dc = exp.shape
+        assert tuple(size[i]) == (dr, dc), (i, size[i], exp.shape)
+        got = out[i, :dr, :dc]
+        if interp == NEAREST:
+            assert (got == exp).all(), (i, int((got != exp).sum()))
+        else:
+            assert np.abs(got.astype(np.int16) - exp.astype(np.int16)).max() <= 1, i
+        # bit-identical to the per-call rotate_mat of the drop-in API on the same scan
+        per_call = transfer.rotate_mat(cards[i], angle, 1.0, interp, 0, (255.0, 255.0, 255.0, 0.0), RotateClipStrategy.CONTAIN)
+        assert (got == per_call.get_mat()).all(), i
+        # nothing outside the scan's own canvas is written
+        assert (out[i, dr:, :] == 7).all() and (out[i, :, dc:] == 7).all()
+
+
+def test_batch_deskew_a4_group_of_8(oracle):
+    rows, cols = 3508, 2480
+    cards = np.stack([synth.make_card(rows, cols, 40 + i)[0] for i in range(8)])
+    for interp in (NEAREST, LINEAR):
+        out, size, best, N = _run_batch(cards, 10, 0.05, interp, group=8)
+        for i in (0, 5):
+            angle = (int(best[i]) - N) * 0.05
+            exp = oracle.rotate_mat(cards[i], angle, 1.0, interp, (255, 255, 255, 0), 1)
+            dr, dc = exp.shape
+            assert tuple(size[i]) == (dr, dc)
+            got = out[i, :dr, :dc]
+            if interp == NEAREST:
+                assert (got == exp).all()
+            else:
+                assert np.abs(got.astype(np.int16) - exp.astype(np.int16)).max() <= 1
+
+
+def test_call_pool_is_bounded_across_short_lived_threads():
+    """One correct_default-like call per FRESH thread, as the Tauri host issues them (thread_pool.rs:41-88): the
+    streams and pinned staging blocks are leased from a bounded pool, so 60 threads leave no more slots behind than
+    ran at once."""
+    L = oics.lib()
+    img = synth.make_card(900, 700, 5)[0]
+
+    def stats():
+        live, idle, pinned = C.c_int32(), C.c_int32(), C.c_int64()
+        assert L.omr_call_pool_stats(0, C.byref(live), C.byref(idle), C.byref(pinned)) == 0
+        return live.value, idle.value, pinned.value
+
+    def one_call():
+        r = transfer.rotate_mat(img, 3.3, 1.0, LINEAR, 0, (255.0, 255.0, 255.0, 0.0), RotateClipStrategy.CONTAIN)
+        assert r.get_mat().shape[0] > 900
+
+    one_call()
+    live0, idle0, _ = stats()
+    for _ in range(60):  # strictly one after the other: every call can reuse the slot the previous one returned
+        t = threading.Thread(target=one_call)
+        t.start()
+        t.join()
+    live1, idle1, pinned1 = stats()
+    assert live1 == live0 and idle1 == live1, (live0, live1, idle1)
+    ts = [threading.Thread(target=one_call) for _ in range(24)]  # 24 at once, then all gone
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    live2, idle2, pinned2 = stats()
+    assert live2 <= live0 + 24 and idle2 == live2 and idle2 <= 32
+    assert pinned2 <= 512 << 20
