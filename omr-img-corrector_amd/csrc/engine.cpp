@@ -504,12 +504,12 @@ int SweepTables::build_runs()
     // sizes the zero guard of the transposed bit image (the sweep then fetches its windows without a range test)
     {
         const int NBt = (rows + 511) / 512;
-        OMR_HIP(wgeoH.alloc(sizeof(int4_t) * (size_t)A * Gh * NBt * 8));
+        OMR_HIP(wgeoH.alloc(sizeof(int2_t) * (size_t)A * Gh * NBt * 8));
         DevBuf ext;
         OMR_HIP(ext.alloc(4 * sizeof(int32_t)));
         int32_t h_ext[4] = {INT32_MAX, INT32_MIN, INT32_MAX, INT32_MIN};
         OMR_HIP(hipMemcpy(ext.p, h_ext, sizeof h_ext, hipMemcpyHostToDevice));
-        OMR_HIP(launch_rungeo(xy0.as<int2_t>(), blkH.as<RunBlk>(), A, Gh, rows, wgeoH.as<int4_t>(), ext.as<int32_t>(), nullptr));
+        OMR_HIP(launch_rungeo(xy0.as<int2_t>(), blkH.as<RunBlk>(), A, Gh, rows, wgeoH.as<int2_t>(), ext.as<int32_t>(), nullptr));
         OMR_HIP(hipMemcpy(h_ext, ext.p, sizeof h_ext, hipMemcpyDeviceToHost));
         if (h_ext[0] > h_ext[1]) return OMR_OK;  // no window fits: gather kernels only
         GXh = std::max(0, std::max(-h_ext[0], h_ext[1] - NWh));
@@ -562,7 +562,7 @@ RunPass SweepTables::run_pass(const uint32_t *d_bitsT, uint16_t *d_part, int sca
     p.rowsT = rowsT;
     p.GX = GXh;
     p.GY = GYh;
-    p.wgeo = wgeoH.as<int4_t>();
+    p.wgeo = wgeoH.as<int2_t>();
     p.RT = xy0.as<int2_t>();
     p.NR = dims.rows;
     p.NC = dims.cols;

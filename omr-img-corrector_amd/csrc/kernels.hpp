@@ -8,9 +8,6 @@ namespace omr {
 struct int2_t {
     int32_t x, y;
 };
-struct int4_t {
-    int32_t x, y, z, w;
-};
 
 // Sweep geometry shared by host and device.
 struct SweepDims {
@@ -89,8 +86,7 @@ struct RunPass {
     const uint32_t *srcT;  // transposed bit images of the launch's scans, with their zero guard: [scan][NWt][rowsT]
     int32_t NWt, rowsT;    // word columns, rows per word column (a multiple of 4), guard included
     int32_t GX, GY;        // guard: word columns left of the image, rows above it
-    const int4_t *wgeo;    // [A][G][bands][8 waves] windows: first word column, first row, (first piece | pieces << 8 |
-                           // columns << 16) to fetch; x = INT_MAX: does not fit
+    const int2_t *wgeo;    // [A][G][bands][8 waves] window origins (word column, row); x = INT_MAX: does not fit
     const int2_t *RT;      // [A][NR] (X0, Y0)
     int32_t NR, NC;        // destination rows, columns
     int32_t NWp;           // words per candidate in tabs / metac: G * OMR_RUN_K (the last group is padded)
@@ -110,7 +106,7 @@ hipError_t launch_runtab(const int32_t *d_CA, const int32_t *d_CB, int A, int NC
                          RunMeta *d_meta, int2_t *d_metac, RunBlk *d_blk, hipStream_t s);
 // window origins of the plan; d_ext[4] = {min column, max column + 1, min row, max row + 1} over the windows that fit
 // (the caller presets it to {INT_MAX, INT_MIN, INT_MAX, INT_MIN})
-hipError_t launch_rungeo(const int2_t *d_RT, const RunBlk *d_blk, int A, int G, int NR, int4_t *d_wgeo, int32_t *d_ext,
+hipError_t launch_rungeo(const int2_t *d_RT, const RunBlk *d_blk, int A, int G, int NR, int2_t *d_wgeo, int32_t *d_ext,
                          hipStream_t s);
 // bit images [scan][rows][wpr] -> transposed, inside their zero guard: [scan][NWt][rowsT], image at (GX, GY)
 hipError_t launch_transpose_bits(const uint32_t *d_bits, int rows, int wpr, uint32_t *d_T, int NW, int NWt, int rowsT, int GX,

@@ -262,7 +262,7 @@ hipError_t launch_runtab(const int32_t *d_CA, const int32_t *d_CB, int A, int NC
 #define RUN_WCOLS_ 7
 #define RUN_WROWS_ 112
 __global__ __launch_bounds__(256) void rungeo_kernel(const int2_t *__restrict__ RT, const RunBlk *__restrict__ blk, int A, int G,
-                                                     int NR, int NBt, int4 *__restrict__ wgeo, int32_t *__restrict__ ext)
+                                                     int NR, int NBt, int2_t *__restrict__ wgeo, int32_t *__restrict__ ext)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= A * G * NBt * 8) return;
@@ -274,16 +274,13 @@ __global__ __launch_bounds__(256) void rungeo_kernel(const int2_t *__restrict__ 
     const int maxbit = (max(t0.x, t1.x) + b.ca_max) >> 10;
     const int minrow = (min(t0.y, t1.y) + b.cb_min) >> 10;
     const int maxrow = (max(t0.y, t1.y) + b.cb_max) >> 10;
-    int4 q;
+    int2_t q;
     q.x = minbit >> 5;
     q.y = (minrow - 7) & ~3;  // a word reads up to 7 rows beside its true samples; pieces are 4 rows
-    // Every selected sample lies in word columns q.x .. maxbit >> 5 and rows minrow .. maxrow.  A word also READS
-    // the column after a sample's and up to 7 rows beside its samples, but selects none of their bits: those
-    // cells only have to exist in the LDS window, they are not fetched (the fetch, not the arithmetic, bounds the
-    // sweep: DESIGN.md section 6a).  z = first piece | pieces << 8 | columns << 16 to fetch.
-    const int pr0 = (minrow - q.y) >> 2, pr1 = (maxrow - q.y) >> 2;
-    q.z = pr0 | ((pr1 - pr0 + 1) << 8) | (((maxbit >> 5) - q.x + 1) << 16);
-    q.w = 0;
+    // every selected sample lies in word columns q.x .. maxbit >> 5; the column after a sample's is read too
+    // but none of its bits is ever selected: it only has to exist.  (Fetching only the pieces and columns that
+    // hold samples -- a third fewer bytes -- was measured: 2 % SLOWER, the lane masks cost more VALU cycles than
+    // the bytes save; the sweep is bound by VALU cycles)
     const bool fits = (maxbit >> 5) - q.x + 2 <= RUN_WCOLS_ && maxrow + 8 - q.y <= RUN_WROWS_ && q.x > -(1 << 20) &&
                       q.x < (1 << 20) && q.y > -(1 << 20) && q.y < (1 << 20);
     if (fits) {
@@ -297,11 +294,11 @@ __global__ __launch_bounds__(256) void rungeo_kernel(const int2_t *__restrict__ 
     wgeo[i] = q;
 }
 
-hipError_t launch_rungeo(const int2_t *d_RT, const RunBlk *d_blk, int A, int G, int NR, int4_t *d_wgeo, int32_t *d_ext,
+hipError_t launch_rungeo(const int2_t *d_RT, const RunBlk *d_blk, int A, int G, int NR, int2_t *d_wgeo, int32_t *d_ext,
                          hipStream_t s)
 {
     const int NBt = (NR + 511) / 512, n = A * G * NBt * 8;
-    hipLaunchKernelGGL(rungeo_kernel, dim3((n + 255) / 256), dim3(256), 0, s, d_RT, d_blk, A, G, NR, NBt, (int4 *)d_wgeo, d_ext);
+    hipLaunchKernelGGL(rungeo_kernel, dim3((n + 255) / 256), dim3(256), 0, s, d_RT, d_blk, A, G, NR, NBt, d_wgeo, d_ext);
     return hipGetLastError();
 }
 
@@ -688,8 +685,6 @@ __device__ __forceinline__ uint32_t flush_columns(uint32_t (&c0)[RUN_K], uint32_
 struct RunGeom {  // source window of one wave and band (wave-uniform)
     int wxw;      // first word column
     int wy0;      // first row, a multiple of 4
-    int pr0, np;  // pieces of 4 rows that hold samples: first, count
-    int nc;       // word columns that hold samples
     bool fits;
 };
 
@@ -773,41 +768,36 @@ __global__ __launch_bounds__(RUN_BAND, 4) void runs_kernel(const RunPass p, cons
 
     // This wave's window origin of a (group, band): one scalar load from the plan's table (rungeo_kernel)
     const int NBt = (p.NR + RUN_BAND - 1) / RUN_BAND;
-    const int4_t *__restrict__ wgeo_a = p.wgeo + ((int64_t)a * p.G + g_begin) * NBt * RUN_WAVES;
+    const int2_t *__restrict__ wgeo_a = p.wgeo + ((int64_t)a * p.G + g_begin) * NBt * RUN_WAVES;
     // (an s_load spelled out: the compiler will not use the scalar unit for a pointer out of the argument struct,
     // and a vector load costs a dozen VALU operations of address arithmetic and a vmcnt wait.  The result is valid
     // after the caller's next `s_waitcnt lgkmcnt(0)`.)
-    auto geometry_issue = [&](const int gl, const int band) -> v4u32 {
-        const uint32_t off = (uint32_t)__builtin_amdgcn_readfirstlane((((gl * NBt) + band0 + band) * RUN_WAVES + wave) * 16);
-        v4u32 q;
-        asm volatile("s_load_dwordx4 %0, %1, %2" : "=&s"(q) : "s"(wgeo_a), "s"(off) : "memory");
+    auto geometry_issue = [&](const int gl, const int band) -> unsigned long long {
+        const uint32_t off = (uint32_t)__builtin_amdgcn_readfirstlane((((gl * NBt) + band0 + band) * RUN_WAVES + wave) * 8);
+        unsigned long long q;
+        asm volatile("s_load_dwordx2 %0, %1, %2" : "=&s"(q) : "s"(wgeo_a), "s"(off) : "memory");
         return q;
     };
-    auto geometry_take = [&](const v4u32 q) -> RunGeom {
+    auto geometry_take = [&](const unsigned long long q) -> RunGeom {
         RunGeom g;
-        g.wxw = (int)q.x;
-        g.wy0 = (int)q.y;
-        g.pr0 = (int)(q.z & 255u);
-        g.np = (int)((q.z >> 8) & 255u);
-        g.nc = (int)(q.z >> 16);
+        g.wxw = (int)(uint32_t)q;
+        g.wy0 = (int)(uint32_t)(q >> 32);
         g.fits = g.wxw != 0x7fffffff;
         return g;
     };
     // This wave's window -> LDS, column-major, 16-byte pieces of 4 rows, two word columns per
     // wave-instruction (lanes 0-27 and 28-55).  The transposed bit image carries a zero guard that holds every
     // window of the plan: no range test, one VALU add per wave-instruction.
-    // Only the pieces (rows) and columns that hold samples travel; the rest of the window keeps what it had.
-    const int lane_hi = lane >= RUN_WPIECES ? 1 : 0, lane_rr = lane - lane_hi * RUN_WPIECES;
-    const uint32_t lane_off = (uint32_t)((lane_hi * p.rowsT + lane_rr * 4) * 4);
+    const int lane_hi = lane >= RUN_WPIECES ? 1 : 0;
+    const uint32_t lane_off = (uint32_t)((lane_hi * p.rowsT + (lane - lane_hi * RUN_WPIECES) * 4) * 4);
     const uint32_t winbase = RUN_WIN_OFS + (uint32_t)wave * RUN_WIN_BYTES;
     auto fetch_window = [&](const RunGeom &q) {
         const uint32_t sbase = (uint32_t)(((q.wxw + p.GX) * p.rowsT + q.wy0 + p.GY) * 4);
-        const bool rows_in = (uint32_t)(lane_rr - q.pr0) < (uint32_t)q.np && lane < 2 * RUN_WPIECES;
 #pragma unroll
         for (int n = 0; n < (RUN_WCOLS + 1) / 2; n++) {
-            if (2 * n >= q.nc) break;  // wave-uniform
             const uint32_t voff = lane_off + (sbase + (uint32_t)(2 * n) * (uint32_t)p.rowsT * 4u);
-            if (rows_in && 2 * n + lane_hi < q.nc) dma_b128(rs_img, voff, winbase + (uint32_t)(2 * n * RUN_WROWS * 4));
+            const int nl = 2 * n + 1 < RUN_WCOLS ? 2 * RUN_WPIECES : RUN_WPIECES;
+            if (lane < nl) dma_b128(rs_img, voff, winbase + (uint32_t)(2 * n * RUN_WROWS * 4));
         }
     };
     // run tables + (ca0, cb0) pairs of one word group -> LDS (all waves share the work)
@@ -826,7 +816,7 @@ __global__ __launch_bounds__(RUN_BAND, 4) void runs_kernel(const RunPass p, cons
     __syncthreads();  // word-group constants are in LDS
     fetch_tables(0, 0);
     int2_t rt = load_rt(0);  // this band's rows (the next band's are loaded while this one is swept)
-    v4u32 gq = geometry_issue(0, 0);
+    unsigned long long gq = geometry_issue(0, 0);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     RunGeom cur = geometry_take(gq);
     if (cur.fits) fetch_window(cur);

@@ -25,7 +25,7 @@ b.run_device(buf.data_ptr(), ROWS * COLS, COLS, G * REPS, 127, best.data_ptr());
 ms, k = b.kernel_ms()
 L.omr_debug_runs_stamps(out, 1)
 n = out[6]
-names = ["prologue", "wait for window (+tables)", "compute", "issue next window", "reduce + park", "total"]
+names = ["prologue", "wait for the window", "compute", "issue of the next window", "flush (park, barriers, reduce)", "total"]
 tot = out[5]
 print("sweep stage %.3f ms per launch of %d scans (debug build, stamps on)" % (ms / k, G))
 for i, nm in enumerate(names):
