@@ -49,8 +49,9 @@ MAX_ANGLE, STEP = 10, 0.05
 # /opt/skills/guides/MI355X_MICROARCH.md
 HBM_PEAK_GBPS = 8000.0   # 8.0 TB/s spec
 N_CU, N_SIMD, CLOCK_GHZ = 256, 1024, 2.4
-VALU_ISSUE_CYCLES = 2.0  # cycles a wave64 VALU op holds its SIMD-32 with >= 2 waves resident (constants table;
-#                          re-measured for this kernel's instruction mix: tools/valu_issue.py, profiles/r02_valu_issue.md)
+VALU_ISSUE_CYCLES = 2.0  # cycles a plain wave64 VOP2 holds its SIMD with >= 2 waves resident (constants table)
+VALU_MIX_CYCLES = 3.86   # the same for THIS kernel's instruction mix (v_alignbit, v_bfi, v_and_or, v_lshlrev, VOP3 forms take 4:
+#                          tools/valu_issue.hip "sweep-kernel mix", profiles/r02_valu_issue.md): what `bound` is decided with
 METRIC = "deskewed images/sec, 2480x3508 gray, +-10deg@0.05deg sweep; HBM GB/s vs roofline"
 
 
@@ -70,6 +71,7 @@ def parse_args(argv=None):
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="wall-clock budget of the CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pmc", action="store_true", help="skip the in-run rocprofv3 counter passes")
+    ap.add_argument("--no-deskew", action="store_true", help="skip the legs that also produce the deskewed images")
     ap.add_argument("--dry-run", action="store_true", help="CPU rehearsal of the N-rank launch (gloo, no GPU work)")
     ap.add_argument("--share-gpus", action="store_true",
                     help="rehearsal on a box with fewer GPUs than ranks: rank r computes on device r %% device_count and the "
@@ -90,23 +92,54 @@ def free_port():
 
 
 def launch_ranks(args, argv):
-    """Parent of N rank processes.  It never imports torch / touches HIP: it only spawns, waits,
-    relays rank 0's JSON line and the worst exit code."""
+    """Parent of N rank processes.  It never imports torch / touches HIP: it only spawns, watches ALL of them,
+    relays rank 0's JSON line and the worst exit code.  A rank that dies early (bad device, out of memory, RCCL
+    initialisation) would leave the others in init_process_group / a barrier until the store times out, minutes
+    later: the first non-zero exit ends the run -- the survivors are terminated, nothing is retried."""
+    import threading
     n = args.gpus
     port = free_port()
     procs = []
     for r in range(n):
         env = dict(os.environ)
+        # the host driver of this pool only supports dmabuf IPC: without HSA_ENABLE_IPC_MODE_LEGACY=0 RCCL's
+        # hipIpcGetMemHandle fails with "invalid argument" (task environment notes); an explicit setting wins
         env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                    HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
                                       stdout=subprocess.PIPE if r == 0 else sys.stderr, stderr=sys.stderr))
-    out0, _ = procs[0].communicate()
-    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    if any(codes):
-        sys.stderr.write("bench.py: rank exit codes %s\n" % codes)
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    deadline = time.monotonic() + float(os.environ.get("OMR_BENCH_TIMEOUT_S", "3000"))
+    failed = None
+    while True:
+        codes = [p.poll() for p in procs]
+        bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+        if bad:
+            failed = "rank %d exited with code %d" % bad[0]
+        elif time.monotonic() > deadline:
+            failed = "timeout"
+        if failed or all(c == 0 for c in codes):
+            break
+        time.sleep(0.2)
+    if failed:
+        for p in procs:  # exactly the children started above, by handle
+            if p.poll() is None:
+                p.terminate()
+        t_kill = time.monotonic() + 10
+        for p in procs:
+            try:
+                p.wait(timeout=max(0.1, t_kill - time.monotonic()))
+            except subprocess.TimeoutExpired:
+                p.kill()
+    reader.join(timeout=10)
+    out0 = b"".join(c for c in chunks if c)
+    codes = [p.poll() for p in procs]
+    if failed:
+        sys.stderr.write("bench.py: %s; rank exit codes %s\n" % (failed, codes))
         sys.stdout.write(out0.decode("utf-8", "replace"))
-        raise SystemExit(max(abs(c) for c in codes) or 1)
+        raise SystemExit(max([abs(c) for c in codes if c] or [1]))
     line = None
     for ln in out0.decode("utf-8", "replace").splitlines():
         if ln.startswith("{"):
@@ -152,6 +185,8 @@ def dry_run(args):
     from oics import dist as odist
     if int(os.environ.get("WORLD_SIZE", "1")) != args.gpus:  # before the rendezvous: a mismatch must not hang
         raise SystemExit("--gpus %d does not match WORLD_SIZE %s" % (args.gpus, os.environ.get("WORLD_SIZE", "1")))
+    if os.environ.get("OMR_BENCH_TEST_FAIL_RANK") == os.environ.get("RANK", "0"):  # tests: a rank that dies before the rendezvous
+        raise SystemExit(3)
     rank, local_rank, world = odist.init(backend="gloo")
     B = args.scans
     n_total = B * world
@@ -266,9 +301,11 @@ def pmc_passes(args, cards_path, workdir):
         if k is None:
             res["passes"][name] = {"error": "sweep kernel not in the counter file"}
             continue
-        vals = {n: pmc.mean(v[1:] if len(v) > 2 else v) for n, v in c[k].items()}  # first dispatch = plan dry run
+        # first dispatch = the plan's dry run on one white scan: dropped from the counters AND from the durations
+        vals = {n: pmc.mean(v[1:] if len(v) > 2 else v) for n, v in c[k].items()}
+        durs = d.get(k, [])
         res["passes"][name] = {"kernel": k, "dispatches": len(next(iter(c[k].values()))), "per_launch": vals,
-                               "kernel_us_profiled": pmc.mean(d.get(k, []))}
+                               "kernel_us_profiled": pmc.mean(durs[1:] if len(durs) > 2 else durs)}
     return res
 
 
@@ -363,6 +400,31 @@ def main():
     # a real batch job where it happens once)
     all_best = odist.gather_results(best.to(xdev), B * world, rank, world)
 
+    # ---- the whole unit of work of the reference (omr.rs:339-452, core/src/main.rs:69-92): the same steps with the
+    # deskewed image produced INSIDE the timed region -- sweep -> arg-max -> CONTAIN warp by the detected angle
+    # (LINEAR as core/src/main.rs:72-81; NEAREST as omr.rs:408-445), winners read on the device.  `value` stays the
+    # angle-detection rate (comparable across rounds); these are reported beside it.
+    deskew = {}
+    if not args.no_deskew:
+        dr, dc = batch.deskew_canvas()
+        canvases = torch.empty((B, dr, dc), dtype=torch.uint8, device=dev)
+        sizes = torch.zeros((B, 2), dtype=torch.int32, device=dev)
+        for name, interp in (("linear", 1), ("nearest", 0)):
+            def dstep():
+                batch.deskew_device(scans.data_ptr(), ROWS * COLS, COLS, B, 127, interp, 255, canvases.data_ptr(), dr * dc, dc,
+                                    sizes.data_ptr(), best.data_ptr())
+            dstep()
+            fence()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                dstep()
+            fence()
+            d_el = odist.barrier_max_seconds(time.perf_counter() - t0, xdev)
+            deskew[name] = B * world * args.steps / d_el
+        sz = sizes.cpu().numpy().astype(np.int64)
+        deskew["canvas_bytes_per_scan_mean"] = float((sz[:, 0] * sz[:, 1]).mean())
+        del canvases
+
     # roofline leg: duration of the sweep stage of a launch group (G scans) from HIP events recorded on
     # the stream the kernels are launched on, over min(K, 50) more steps.  The stage is `launches` kernel
     # launches: the run-merging kernel (G scans, both projections, one launch) plus one gather launch
@@ -388,6 +450,13 @@ def main():
         detected = [(int(k) - N) * STEP for k in best.cpu().tolist()]
         acc_ok = all(abs(d - thetas[i % D]) < 0.5 for i, d in enumerate(detected))  # lib.rs:103-113
         out = base_record(args, world, value, elapsed, B, A, G, D)
+        if deskew:
+            out["deskew_images_per_s"] = deskew["linear"]
+            out["deskew"] = {"what": "sweep -> arg-max -> CONTAIN warp of every scan by its detected angle inside the timed "
+                                     "region (omr_batch_deskew_device), same steps / warmup as `value`",
+                             "linear_images_per_s": deskew["linear"], "nearest_images_per_s": deskew["nearest"],
+                             "linear_over_value": deskew["linear"] / value, "nearest_over_value": deskew["nearest"] / value,
+                             "warp_hbm_bytes_per_scan": float(ROWS * COLS) + deskew["canvas_bytes_per_scan_mean"]}
         roof = {"kernel": "omr::runs_kernel (run-merging rotate+project, both projections per launch)"
                           if n_runs > 0 else "omr::sweep_lds_kernel (gather rotate+project)",
                 "kernel_ms": kernel_ms, "scans_per_launch": G, "launches_per_group": launches,
@@ -436,15 +505,20 @@ def main():
             c = sq["per_launch"]
             t_prof = sq["kernel_us_profiled"] * 1e-6  # the counters belong to the profiled launch: use ITS duration
             valu_rate = c["SQ_INSTS_VALU"] / t_prof            # wave-instructions / s
-            valu_peak = N_SIMD * CLOCK_GHZ * 1e9 / VALU_ISSUE_CYCLES
+            valu_peak = N_SIMD * CLOCK_GHZ * 1e9 / VALU_MIX_CYCLES  # at this kernel's measured cycles per instruction
             lds_rate = c["SQ_LDS_IDX_ACTIVE"] / t_prof          # LDS-array cycles / s, summed over CUs
             lds_peak = N_CU * CLOCK_GHZ * 1e9
-            roof.update(valu_issue_frac=valu_rate / valu_peak, lds_busy_frac=lds_rate / lds_peak,
+            roof.update(valu_issue_frac=valu_rate / valu_peak,
+                        valu_issue_frac_at_2_cycles=valu_rate / (N_SIMD * CLOCK_GHZ * 1e9 / VALU_ISSUE_CYCLES),
+                        lds_busy_frac=lds_rate / lds_peak,
                         lds_conflict_frac=c["SQ_LDS_BANK_CONFLICT"] / max(1.0, c["SQ_LDS_IDX_ACTIVE"]),
                         sq_counters_per_launch=c, kernel_us_under_profiler=sq["kernel_us_profiled"],
                         valu_insts_per_dst_word=c["SQ_INSTS_VALU"] * 64.0 / (G * A * ROWS * ((COLS + 31) // 32)),
-                        peaks="VALU: %d SIMDs x %.1f GHz / %.0f cycles per wave64 op; LDS: %d CUs x %.1f GHz array cycles "
-                              "(MI355X_MICROARCH.md)" % (N_SIMD, CLOCK_GHZ, VALU_ISSUE_CYCLES, N_CU, CLOCK_GHZ))
+                        peaks="VALU: %d SIMDs x %.1f GHz / %.2f cycles per wave64 op of this kernel's mix (2 for a plain "
+                              "VOP2: valu_issue_frac_at_2_cycles); LDS: %d CUs x %.1f GHz array cycles (MI355X_MICROARCH.md). "
+                              "The clock the chip holds in this kernel is below the nominal %.1f GHz (SQ_BUSY_CU_CYCLES / 256 / "
+                              "kernel time, profiles/): both fractions are that much higher against the held clock"
+                              % (N_SIMD, CLOCK_GHZ, VALU_MIX_CYCLES, N_CU, CLOCK_GHZ, CLOCK_GHZ))
             if roof["valu_issue_frac"] >= roof["lds_busy_frac"]:
                 roof.update(bound="valu", achieved=valu_rate / 1e9, peak=valu_peak / 1e9, unit="G wave-instr/s",
                             frac=valu_rate / valu_peak)

@@ -51,3 +51,16 @@ def test_launcher_parent_never_touches_the_gpu():
     assert "import torch" not in head and "oics.lib()" not in head
     body = src.split("def launch_ranks", 1)[1].split("\ndef ", 1)[0]
     assert "import torch" not in body and "import oics" not in body and "from oics" not in body
+
+
+def test_a_rank_that_dies_ends_the_run_at_once():
+    """Round-2 advice: rank 1 dies before the rendezvous (a bad device, an allocation failure).  Rank 0 would sit in
+    init_process_group until the store times out (minutes); the launcher watches every child, so the run ends with a
+    non-zero code within seconds and the survivor is terminated."""
+    import time
+    t0 = time.monotonic()
+    p = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--dry-run", "--scans", "5", "--steps", "3"],
+                       env=_env(OMR_BENCH_TEST_FAIL_RANK="1"), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+    assert p.returncode != 0
+    assert time.monotonic() - t0 < 60
+    assert b"rank 1 exited with code 3" in p.stderr
