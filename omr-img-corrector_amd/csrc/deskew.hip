@@ -12,8 +12,10 @@
 namespace omr {
 
 #define DW_TW 128  // destination tile: 128 x 32 pixels per 256-thread workgroup, 4 x 4 pixels per thread
-#define DW_TH 32
-#define DW_LDS 24576
+// tile height: 64 rows for NEAREST (the fixed chain of memory round trips per tile is spread over more pixels),
+// 32 for LINEAR (four taps per pixel: at 64 rows the pixels in flight cost 200 VGPRs)
+#define DW_TH (LINEAR ? 32 : 64)
+#define DW_LDS 16384
 
 __device__ __forceinline__ uint8_t dw_sat_u8(int v) { return (uint8_t)(v < 0 ? 0 : v > 255 ? 255 : v); }
 
@@ -42,7 +44,9 @@ __device__ __forceinline__ int dw_tap_global(const uint8_t *__restrict__ src, in
 // grid = (tiles across the largest canvas, tiles down it, scans of the launch); a tile outside its scan's canvas
 // leaves at once.  The source bounding box of a tile (four corner samples; one pixel of slack for the rounding of
 // the fixed-point tables, one more for the bilinear taps) is staged in LDS with row-contiguous dword loads, border
-// value outside the image, so a tap is one LDS byte read with no bounds test.
+// value outside the image, so a tap is one LDS byte read with no bounds test.  The kernel is a chain of dependent
+// memory round trips (winner -> canvas size -> table entries of the corners -> box -> taps), so everything that
+// does not depend on the box -- the thread's own column and row table entries -- is requested before the box is.
 template <bool LINEAR>
 __global__ __launch_bounds__(256) void deskew_warp_kernel(const DeskewPass p)
 {
@@ -62,10 +66,17 @@ __global__ __launch_bounds__(256) void deskew_warp_kernel(const DeskewPass p)
     const int2_t *__restrict__ XY = p.xy0 + (int64_t)a * p.DR;
     const int rd = LINEAR ? 16 : 512;
     const int tx1 = min(dcols, tx0 + DW_TW) - 1, ty1 = min(drows, ty0 + DW_TH) - 1;
-    // fixed-point source coordinates of the tile's corner samples: wave-uniform.  X0(y) and adelta(x) are both
-    // monotone, so the four corners bound every sample of the tile.
+    // ---- requests that need nothing but the tile position: the corners' and this thread's table entries
     const int2_t r0 = XY[ty0], r1 = XY[ty1];
     const int a0 = AD[tx0], a1 = AD[tx1], b0 = BD[tx0], b1 = BD[tx1];
+    const int lx = (threadIdx.x & 31) * 4, x0 = tx0 + lx, yq = ty0 + (threadIdx.x >> 5);
+    const int xl = min(x0, p.DC - 4);  // DC is a multiple of 4 and the tables are 16-byte aligned
+    const int4 ad = *(const int4 *)(AD + xl), bd = *(const int4 *)(BD + xl);
+    int2_t rows[DW_TH / 8];
+#pragma unroll
+    for (int k = 0; k < DW_TH / 8; k++) rows[k] = XY[min(yq + 8 * k, p.DR - 1)];
+    // ---- the box: fixed-point source coordinates of the tile's corner samples (wave-uniform).  X0(y) and
+    // adelta(x) are both monotone, so the four corners bound every sample of the tile.
     const int cx[4] = {(r0.x + rd + a0) >> 10, (r0.x + rd + a1) >> 10, (r1.x + rd + a0) >> 10, (r1.x + rd + a1) >> 10};
     const int cy[4] = {(r0.y + rd + b0) >> 10, (r0.y + rd + b1) >> 10, (r1.y + rd + b0) >> 10, (r1.y + rd + b1) >> 10};
     const int bx0 = min(min(cx[0], cx[1]), min(cx[2], cx[3])) - 1;
@@ -78,70 +89,102 @@ __global__ __launch_bounds__(256) void deskew_warp_kernel(const DeskewPass p)
                         by1 < 30000;
     const uint32_t border4 = (uint32_t)p.border * 0x01010101u;
     if (staged) {
-        const int bq = bwb >> 2;
+        // the box as dwords, thread t takes dwords t, t + 256, ..: ALL loads are issued before the first LDS write
+        // (a load -> wait -> write loop pays a memory round trip per dword).  (row, dword in row) of a thread's next
+        // piece follows from the previous one without a division.
+        constexpr int NP = DW_LDS / 4 / 256;  // 16 pieces per thread at most
+        const int bq = bwb >> 2, total = bq * bh;
         const bool aligned = ((p.sstep | p.scan_stride | (int64_t)(uintptr_t)p.src) & 3) == 0;
-        for (int i = threadIdx.x; i < bq * bh; i += 256) {
-            const int ly = i / bq, lq = i - ly * bq;
-            const int gy = by0 + ly, gb = bb0 + lq * 4;
-            uint32_t v;
-            if (aligned && (unsigned)gy < (unsigned)p.srows && gb >= 0 && gb + 4 <= p.scols) {
-                v = *(const uint32_t *)(src + (int64_t)gy * p.sstep + gb);
-            } else if ((unsigned)gy >= (unsigned)p.srows || gb + 4 <= 0 || gb >= p.scols) {
-                v = border4;
-            } else {
-                v = 0;
-                for (int j = 0; j < 4; j++) {
-                    const int b = gb + j;
-                    const uint32_t px = (b >= 0 && b < p.scols) ? src[(int64_t)gy * p.sstep + b] : (uint32_t)p.border;
-                    v |= px << (8 * j);
+        const int dq = 256 / bq, dr = 256 - dq * bq;  // 256 = dq * bq + dr
+        int ly = (int)threadIdx.x / bq, lq = (int)threadIdx.x - ly * bq;
+        uint32_t v[NP];
+#pragma unroll
+        for (int n = 0; n < NP; n++) {
+            v[n] = border4;
+            if ((int)threadIdx.x + n * 256 < total) {
+                const int gy = by0 + ly, gb = bb0 + lq * 4;
+                if (aligned && (unsigned)gy < (unsigned)p.srows && gb >= 0 && gb + 4 <= p.scols) {
+                    v[n] = *(const uint32_t *)(src + (int64_t)gy * p.sstep + gb);
+                } else if ((unsigned)gy < (unsigned)p.srows && gb + 4 > 0 && gb < p.scols) {
+                    uint32_t t = 0;
+                    for (int j = 0; j < 4; j++) {
+                        const int b = gb + j;
+                        const uint32_t px = (b >= 0 && b < p.scols) ? src[(int64_t)gy * p.sstep + b] : (uint32_t)p.border;
+                        t |= px << (8 * j);
+                    }
+                    v[n] = t;
                 }
             }
-            *(uint32_t *)&box[ly * bwb + lq * 4] = v;
+            ly += dq, lq += dr;
+            if (lq >= bq) lq -= bq, ly++;
         }
+#pragma unroll
+        for (int n = 0; n < NP; n++)
+            if ((int)threadIdx.x + n * 256 < total) *(uint32_t *)&box[((int)threadIdx.x + n * 256) * 4] = v[n];
     }
     __syncthreads();
-    const int lx = (threadIdx.x & 31) * 4, x0 = tx0 + lx;
     if (x0 >= dcols) return;
-    // the thread's four columns: DC is a multiple of 4 and the tables are 16-byte aligned
-    const int4 ad = *(const int4 *)(AD + x0), bd = *(const int4 *)(BD + x0);
     const int adv[4] = {ad.x, ad.y, ad.z, ad.w}, bdv[4] = {bd.x, bd.y, bd.z, bd.w};
-#pragma unroll
-    for (int k = 0; k < DW_TH / 8; k++) {
-        const int y = ty0 + (threadIdx.x >> 5) + 8 * k;
-        if (y >= drows) break;
-        const int2_t r = XY[y];
-        const int X0 = r.x + rd, Y0 = r.y + rd;
-        uint32_t out = 0;
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const int Xf = X0 + adv[j], Yf = Y0 + bdv[j];
-            int v;
-            if (!staged) {
-                v = dw_tap_global<LINEAR>(src, p.sstep, p.srows, p.scols, Xf, Yf, p.border);
-            } else if (!LINEAR) {
-                v = box[((Yf >> 10) - by0) * bwb + (Xf >> 10) - bb0];
-            } else {
-                const int X = Xf >> 5, Y = Yf >> 5;
-                const int fx = X & 31, fy = Y & 31;
-                const uint8_t *B = &box[((Y >> 5) - by0) * bwb + (X >> 5) - bb0];
-                const int w0 = (32 - fy) * (32 - fx) * 32, w1 = (32 - fy) * fx * 32, w2 = fy * (32 - fx) * 32, w3 = fy * fx * 32;
-                v = dw_sat_u8((B[0] * w0 + B[1] * w1 + B[bwb] * w2 + B[bwb + 1] * w3 + (1 << 14)) >> 15);
-            }
-            out |= (uint32_t)v << (8 * j);
-        }
+    const int org = -by0 * bwb - bb0;  // box[(sy - by0) * bwb + sx - bb0] = box[sy * bwb + sx + org]
+    auto store4 = [&](const int y, const uint32_t out) {
         uint8_t *D = dst + (int64_t)y * p.dstep + x0;
         if (x0 + 4 <= dcols && ((uintptr_t)D & 3) == 0) {
             *(uint32_t *)D = out;
         } else {
             for (int j = 0; j < 4 && x0 + j < dcols; j++) D[j] = (uint8_t)(out >> (8 * j));
         }
+    };
+    if (!staged) {  // workgroup-uniform: a box too large for LDS (strong shear); taps from global memory
+        for (int k = 0; k < DW_TH / 8; k++) {
+            const int y = yq + 8 * k;
+            if (y >= drows) break;
+            uint32_t out = 0;
+            for (int j = 0; j < 4; j++)
+                out |= (uint32_t)dw_tap_global<LINEAR>(src, p.sstep, p.srows, p.scols, rows[k].x + rd + adv[j],
+                                                       rows[k].y + rd + bdv[j], p.border)
+                       << (8 * j);
+            store4(y, out);
+        }
+        return;
     }
+    // straight-line: the 16 pixels' taps are all requested before the first is blended
+    uint32_t outs[DW_TH / 8];
+#pragma unroll
+    for (int k = 0; k < DW_TH / 8; k++) {
+        const int X0 = rows[k].x + rd, Y0 = rows[k].y + rd;
+        uint32_t out = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int Xf = X0 + adv[j], Yf = Y0 + bdv[j];
+            // rows past the end of the canvas (clamped table entries) stay inside the box or are clamped into it:
+            // their results are never stored
+            int idx = (Yf >> 10) * bwb + (Xf >> 10) + org;
+            idx = min(max(idx, 0), DW_LDS - 2 * 1 - (LINEAR ? bwb : 0) - 1);
+            int v;
+            if (!LINEAR) {
+                v = box[idx];
+            } else {
+                // ((v0 w0 + v1 w1 + v2 w2 + v3 w3 + 2^14) >> 15 with w = 32 (32 - fy)(32 - fx), ..) as two horizontal
+                // blends and a vertical one: the same integer, and <= 255 without a clamp
+                const int fx = (Xf >> 5) & 31, fy = (Yf >> 5) & 31;
+                const uint8_t *B = &box[idx];
+                const int top = B[0] * (32 - fx) + B[1] * fx, bot = B[bwb] * (32 - fx) + B[bwb + 1] * fx;
+                v = (top * (32 - fy) + bot * fy + 512) >> 10;
+            }
+            out |= (uint32_t)v << (8 * j);
+        }
+        outs[k] = out;
+    }
+#pragma unroll
+    for (int k = 0; k < DW_TH / 8; k++)
+        if (yq + 8 * k < drows) store4(yq + 8 * k, outs[k]);
 }
 
 hipError_t launch_deskew_warp(const DeskewPass &p, int scans, int interp, hipStream_t s)
 {
     if (scans <= 0) return hipSuccess;
     if ((p.DC & 3) != 0) return hipErrorInvalidValue;
+    const bool LINEAR = interp != 0;
     dim3 grid((p.DC + DW_TW - 1) / DW_TW, (p.DR + DW_TH - 1) / DW_TH, scans);
     if (interp == 0) hipLaunchKernelGGL(deskew_warp_kernel<false>, grid, dim3(256), 0, s, p);
     else hipLaunchKernelGGL(deskew_warp_kernel<true>, grid, dim3(256), 0, s, p);
