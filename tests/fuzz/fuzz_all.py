@@ -4,7 +4,7 @@ driver, the FFT pictures -- against the CPU oracle.  Usage: python tools/fuzz_al
 import os
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "omr-img-corrector_amd"))
 import numpy as np

@@ -5,10 +5,11 @@ tests/golden/make_dataset_pin.py for how the fixtures were made.
 
   * CPU tier : the oracle on one angle per sheet (104 cases) must reproduce the committed expectations bit
                for bit and meet the reference's criterion; the committed 936-case histogram must hold no ERROR.
-  * Criterion as asserted here: no believed case in class ERROR (distance > 0.5, lib.rs:222-223).  The
-    disabled random test's `assert < 0.5` (lib.rs:105-112) differs from that only AT 0.5: one of the 936
-    cases (image051 at 28.9 deg, detected 28.4) lands exactly there -- the reference's own comment records
-    the same experience ("one case above 0.5 was seen", lib.rs:108); the tests count such cases (<= 1).
+  * Criterion as asserted here: the reference's own `assert < 0.5` (lib.rs:105-112) for every believed case, with
+    ONE exception named explicitly -- image051 at injected 28.9 is detected at 28.4, exactly ON the bound
+    (|28.9 - 28.4| evaluates to 0.5 in f64; class NOT_SO_RIGHT by lib.rs:222-223, not ERROR).  The reference's own
+    comment records the same experience ("one case above 0.5 was seen", lib.rs:108).  Any other believed case at
+    or above 0.5 fails the tests.
   * GPU tier : all 936 cases through omr_correct_default (C ABI -> HIP kernels): the reference's criterion,
                bit-equality with the oracle's committed results, and the class histogram next to the
                reference's claim "99.9 % < 0.4 deg" (lib.rs:108), written to gpurun_out/ for DESIGN.md.
@@ -42,6 +43,16 @@ def test_fixture_is_the_whole_reference_dataset():
     assert all(-450 <= c["idx"] < 450 for c in exp["cases"])  # lib.rs:153
 
 
+# the one believed case that sits exactly on the reference's bound (see the module docstring): (sheet, injected index)
+BOUNDARY_CASE = ("image051.jpg", 289)
+
+
+def _meets_criterion(sheet, idx, injected, detected):
+    """lib.rs:105-112: assert < 0.5; the named boundary case may be equal to it."""
+    d = abs(injected - detected)
+    return d <= 0.5 if (sheet, idx) == BOUNDARY_CASE else d < 0.5
+
+
 def test_committed_histogram_meets_the_reference_criterion():
     exp = dp.load_expected()
     hist, edge = {}, 0
@@ -51,9 +62,9 @@ def test_committed_histogram_meets_the_reference_criterion():
         hist[cls] = hist.get(cls, 0) + 1
         assert cls == c["class"]
         if not c["need_check"]:
-            assert abs(inj - c["angle"]) <= 0.5, (c["sheet"], inj, c["angle"])  # lib.rs:103-113 / :222
+            assert _meets_criterion(c["sheet"], c["idx"], inj, c["angle"]), (c["sheet"], inj, c["angle"])  # lib.rs:105-112
             edge += abs(inj - c["angle"]) >= 0.5
-    assert edge <= 1  # the one boundary case (distance == 0.5 exactly)
+    assert edge == 1  # exactly the named boundary case
     assert hist == exp["histogram"] and hist.get("ERROR", 0) == 0
     believed = sum(v for k, v in hist.items() if k != "NOT_BELIEVED")
     assert believed >= 0.99 * len(exp["cases"])  # NOT_BELIEVED is rare (3 of 936 when the fixtures were made)
@@ -76,7 +87,7 @@ def test_oracle_reproduces_the_committed_results(oracle):
         for c, det, chk, pst in ex.map(one, list(first.values())):
             assert _bits(det) == c["angle_bits"] and chk == c["need_check"] and pst == c["proj_status"], c["sheet"]
             if not chk:
-                assert abs(c["idx"] * 0.1 - det) <= 0.5
+                assert _meets_criterion(c["sheet"], c["idx"], c["idx"] * 0.1, det)
 
 
 @pytest.mark.gpu
@@ -105,7 +116,7 @@ def test_correct_default_on_the_dataset_gpu(oracle):
                 n += 1
                 if not chk:
                     worst = max(worst, abs(inj - ang))
-                    assert abs(inj - ang) <= 0.5, (c["sheet"], inj, ang)  # lib.rs:103-113 / :222
+                    assert _meets_criterion(c["sheet"], c["idx"], inj, ang), (c["sheet"], inj, ang)  # lib.rs:105-112
                     edge += abs(inj - ang) >= 0.5
                 if _bits(ang) != c["angle_bits"] or chk != c["need_check"]:
                     mism.append((c["sheet"], c["idx"], ang, c["angle"], chk, c["need_check"]))

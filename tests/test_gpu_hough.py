@@ -220,10 +220,10 @@ def test_hough_lines_p_other_resolutions(oracle, theta_div, rho):
 
 
 def test_hough_lines_p_random_cases(oracle, monkeypatch):
-    """Random shapes, densities and parameters (tools/fuzz_hough.py: point counts around the 64-point draw rounds,
+    """Random shapes, densities and parameters (tests/fuzz/fuzz_hough.py: point counts around the 64-point draw rounds,
     dense rows / columns, gaps on both sides of the 64-step rule, other rho / theta): segments equal the oracle's."""
     import runpy
-    tool = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "fuzz_hough.py")
+    tool = os.path.join(os.path.dirname(os.path.abspath(__file__)), "fuzz", "fuzz_hough.py")
     monkeypatch.setattr(sys, "argv", [tool, "80", "11"])
     with pytest.raises(SystemExit) as e:
         runpy.run_path(tool, run_name="__main__")

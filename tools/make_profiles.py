@@ -1,6 +1,6 @@
 """Turn gpurun_out/<tag>/ (written on the GPU box by tools/profile_round.sh) into the committed summaries under
 profiles/<tag>_*.  Every file names the commit it measured (gpurun_out/<tag>/COMMIT, written just before the
-gpurun call).  Usage: python tools/make_profiles.py r02"""
+gpurun call).  Usage: python tools/make_profiles.py r03"""
 import csv
 import glob
 import json
@@ -13,12 +13,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "omr-img-corrector_amd"))
 from oics import pmc  # noqa: E402
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 src = os.path.join(ROOT, "gpurun_out", tag)
 dst = os.path.join(ROOT, "profiles")
 os.makedirs(dst, exist_ok=True)
 commit = open(os.path.join(src, "COMMIT")).read().strip() if os.path.exists(os.path.join(src, "COMMIT")) else "unknown"
-STAMP = "Measured at commit `%s` on one MI355X (gpurun box), `bash tools/profile_round.sh %s`.\n\n" % (commit, tag)
+STAMP = "Measured at commit `%s` on one MI355X (gpurun boxes), `bash tools/profile_round.sh %s a|b`.\n\n" % (commit, tag)
 
 
 def read(name):
@@ -65,15 +65,39 @@ def counter_table(sub, needle, f):
     return out
 
 
+def hbm_table(fetch_sub, write_sub, f, needles=None, bytes_of=None):
+    """Per kernel: FETCH_SIZE (its own pass) and WRITE_SIZE (its own pass), corrected as MI355X_MICROARCH.md's HBM
+    section prescribes ((2 x FETCH_SIZE + WRITE_SIZE) x 1024 B), over the kernel's mean duration in those passes."""
+    cf, df = pmc.read_counters(os.path.join(src, fetch_sub)), pmc.read_durations(os.path.join(src, fetch_sub))
+    cw, dw = pmc.read_counters(os.path.join(src, write_sub)), pmc.read_durations(os.path.join(src, write_sub))
+    f.write("| kernel | launches | mean us (profiled) | FETCH_SIZE KB | WRITE_SIZE KB | HBM MB per launch | HBM GB/s | of 8 TB/s |\n|---|---|---|---|---|---|---|---|\n")
+    out = {}
+    for k in sorted(cf):
+        if needles and not any(n in k for n in needles):
+            continue
+        if k not in cw or "FETCH_SIZE" not in cf[k] or "WRITE_SIZE" not in cw[k]:
+            continue
+        fe, wr = pmc.mean(cf[k]["FETCH_SIZE"]), pmc.mean(cw[k]["WRITE_SIZE"])
+        us = pmc.mean(df.get(k, []) + dw.get(k, []))
+        b = pmc.hbm_bytes(fe, wr)
+        f.write("| `%s` | %d | %.1f | %.0f | %.0f | %.2f | %.0f | %.3f |\n" % (k[:70], len(cf[k]["FETCH_SIZE"]), us, fe, wr, b / 1e6,
+                                                                              b / us / 1e3, b / us / 1e3 / 8000))
+        out[k] = (b, us)
+    return out
+
+
 # ---- bench line + kernel stats
 line = last_json(read("bench_line.json"))
 json.dump(line, open(os.path.join(dst, tag + "_bench_line.json"), "w"), indent=1)
 with open(os.path.join(dst, tag + "_rocprofv3_kernel_stats_bench.md"), "w") as f:
     f.write("# %s -- `rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline --no-pmc`\n\n" % tag + STAMP)
     f.write("Default bench: %d scans per GPU per step (%d distinct cards), %d scans per kernel launch, 1 sweep stream + 1 post "
-            "stream; `runtab_kernel` / `runblk_kernel` / `tables_kernel` are plan creation, one extra `runs_kernel` launch is the "
-            "plan's dry run.\n\n" % (line["config"]["scans_per_gpu_per_step"], line["config"]["distinct_cards_per_gpu"],
-                                      line["config"]["scans_per_kernel_launch"]))
+            "stream; the `value` leg (angle detection) is followed by the two deskew legs (`deskew_warp_kernel<true>` = LINEAR, "
+            "`<false>` = NEAREST; they share the chip with the sweep of the next launch group, so their durations here are longer "
+            "than in `%s_deskew.md`); `runtab_kernel` / `runblk_kernel` / `rungeo_kernel` / `tables_kernel` are plan creation, one "
+            "extra `runs_kernel` launch is the plan's dry run.\n\n" % (line["config"]["scans_per_gpu_per_step"],
+                                                                      line["config"]["distinct_cards_per_gpu"],
+                                                                      line["config"]["scans_per_kernel_launch"], tag))
     rows = stats_table("stats", f)
     ks = glob.glob(os.path.join(src, "stats", "**", "*kernel_stats.csv"), recursive=True)
     if ks:
@@ -85,6 +109,11 @@ with open(os.path.join(dst, tag + "_rocprofv3_kernel_stats_bench.md"), "w") as f
                 tag, line["value"], rl["kernel_ms"], rl["scans_per_launch"], rl["launch_groups_timed"], rl.get("bound"),
                 rl.get("frac") or float("nan"), rl.get("valu_issue_frac", float("nan")), rl.get("lds_busy_frac", float("nan")),
                 rl.get("lds_conflict_frac", float("nan")), rl.get("hbm_frac", float("nan"))))
+    if line.get("deskew"):
+        dk = line["deskew"]
+        f.write("With the deskewed image produced inside the timed region (`omr_batch_deskew_device`): **%.0f images/s** LINEAR "
+                "(%.3f of `value`), %.0f NEAREST (%.3f).\n" % (dk["linear_images_per_s"], dk["linear_over_value"],
+                                                               dk["nearest_images_per_s"], dk["nearest_over_value"]))
     run = [r for r in rows if "runs_kernel" in r["Name"]]
     if run:
         f.write("The profiler's average for `omr::runs_kernel` (%.1f us) must agree with `roofline.kernel_ms` (%.1f us) up to the "
@@ -107,21 +136,42 @@ with open(os.path.join(dst, tag + "_pmc_sweep.md"), "w") as f:
                    "sweep_kernel_hbm_bytes_per_launch": rl["traffic"], "scans_per_launch": rl["scans_per_launch"],
                    "correction": "gfx950: FETCH_SIZE x2 (MI355X_MICROARCH.md HBM section), WRITE_SIZE as is, x1024 B"},
                   open(os.path.join(dst, "hbm_traffic.json"), "w"), indent=1)
-    f.write("\n## Single-scan launches (tools/kbench.py), two SQ passes\n")
+    f.write("\n## Batch mode (tools/kbatch.py: 8 scans per launch), two SQ passes\n")
+    r1 = {}
     for sub in ("pmc_sq1", "pmc_sq2"):
-        counter_table(sub, "runs_kernel", f)
-    f.write("\n## Un-profiled kernel timings\n\n```\n%s```\n" % read("kbench.log").replace("/opt/amdgpu/share/libdrm/amdgpu.ids: No such file or directory\n", ""))
+        r1.update(counter_table(sub, "runs_kernel", f))
+    c1 = pmc.read_counters(os.path.join(src, "pmc_sq1"))
+    d1 = pmc.read_durations(os.path.join(src, "pmc_sq1"))
+    k = pmc.pick(c1.keys(), "runs_kernel")
+    if k and "SQ_BUSY_CU_CYCLES" in c1[k]:
+        cyc = pmc.mean(c1[k]["SQ_BUSY_CU_CYCLES"][1:]) / 256.0
+        us = pmc.mean(d1[k][1:])
+        nv = pmc.mean(c1[k]["SQ_INSTS_VALU"][1:])
+        f.write("\nClock held in the kernel: SQ_BUSY_CU_CYCLES / 256 CUs / duration = %.0f cycles / %.1f us = **%.2f GHz**.  VALU: %.3g "
+                "wave-instructions per launch = %.0f per SIMD; at the 3.86 cycles per instruction of this kernel's mix "
+                "(profiles/r02_valu_issue.md) that is %.2f of the held clock's cycles, at 2 cycles (plain VOP2) %.2f.\n"
+                % (cyc, us, cyc / us / 1e3, nv, nv / 1024, nv / 1024 * 3.86 / cyc, nv / 1024 * 2 / cyc))
+    f.write("\n## Un-profiled kernel timings\n\n`python3 tools/kbatch.py 16 8` (8 scans per launch, HIP events around the sweep stage):\n\n```\n%s```\n"
+            % read("kbatch.log").replace("/opt/amdgpu/share/libdrm/amdgpu.ids: No such file or directory\n", ""))
+    f.write("\n`python3 tools/kbench.py 20` (one scan per launch, the three sweep kernels):\n\n```\n%s```\n"
+            % read("kbench.log").replace("/opt/amdgpu/share/libdrm/amdgpu.ids: No such file or directory\n", ""))
     f.write("\n## Phase clocks of wave 0 (debug library, tools/kstamps.py)\n\n```\n%s```\n" % read("kstamps.log").replace("/opt/amdgpu/share/libdrm/amdgpu.ids: No such file or directory\n", ""))
-    f.write("\n## Ablation (debug library, tools/kdbg.py; OMR_RUNS_DBG bit 1 = no compute, 2 = no window fetch/commit, 4 = no flush)\n\n```\n%s```\n" % read("kdbg.log"))
 
-# ---- issue costs / LDS micro-benchmarks
-with open(os.path.join(dst, tag + "_valu_issue.md"), "w") as f:
-    f.write("# %s -- instruction issue cost and LDS micro-benchmarks behind DESIGN.md section 4.1\n\n" % tag + STAMP)
-    for t, what in (("valu_issue", "tools/valu_issue.hip: cycles a wave64 VALU instruction holds a SIMD-32, by resident waves per SIMD"),
-                    ("valu_ops", "tools/valu_ops.hip (generated by tools/gen_valu_ops.py): the same per opcode"),
-                    ("lds_unaligned", "tools/lds_unaligned.hip: ds_read_b64 at 4-byte-aligned addresses vs ds_read2_b32"),
-                    ("lds_bytes", "tools/lds_bytes.hip: sub-dword and tuple read patterns")):
-        f.write("## %s\n\n```\n%s```\n\n" % (what, read(t + ".log")))
+# ---- the batch warp
+with open(os.path.join(dst, tag + "_deskew.md"), "w") as f:
+    f.write("# %s -- the batch's last stage: `deskew_warp_kernel` (CONTAIN warp of 8 A4 scans per launch by their detected angles)\n\n" % tag + STAMP)
+    f.write("`python3 tools/bench_deskew.py 10` (the batch context is synchronised after every call, so the warp has the chip to itself):\n\n```\n%s```\n\n"
+            % "\n".join(l for l in read("deskew.log").splitlines() if "amdgpu.ids" not in l))
+    f.write("Kernel stats of the same script:\n\n")
+    stats_table("deskew_stats", f, 8)
+    f.write("\nHBM-side traffic (FETCH_SIZE and WRITE_SIZE each in a pass of its own) against the algorithmic bytes (scan in once + canvas out once):\n\n")
+    hbm_table("deskew_fetch", "deskew_write", f, needles=("deskew_warp_kernel",))
+
+# ---- micro-benchmark behind DESIGN.md's LDS-DMA statements
+if read("lds_dma_window.log"):
+    with open(os.path.join(dst, tag + "_lds_dma.md"), "w") as f:
+        f.write("# %s -- LDS-DMA probe behind DESIGN.md section 4.1 (tools/lds_dma_window.hip)\n\n" % tag + STAMP)
+        f.write("```\n%s```\n" % read("lds_dma_window.log"))
 
 # ---- stages / fft / hough / calls
 with open(os.path.join(dst, tag + "_stages.md"), "w") as f:
@@ -130,30 +180,41 @@ with open(os.path.join(dst, tag + "_stages.md"), "w") as f:
             "GB/s = compulsory bytes (input once + output once) / time.  The `[x9 tall]` rows run the same kernels on nine scans "
             "stacked into one image, i.e. with the launch ramp and tail amortised.\n\n```\n%s```\n" % "\n".join(
                 l for l in read("stages.log").splitlines() if not l.startswith("{") and "amdgpu.ids" not in l))
+    f.write("\nKernel stats of the same script (`rocprofv3 --kernel-trace --stats`):\n\n")
+    stats_table("stages_stats", f, 14)
+    f.write("\nMeasured HBM-side traffic per kernel (FETCH_SIZE and WRITE_SIZE each in a pass of its own; mean over ALL launches of a "
+            "kernel in the script, single scans and the nine-scan stacks alike):\n\n")
+    hbm_table("stages_fetch", "stages_write", f)
 with open(os.path.join(dst, tag + "_fft.md"), "w") as f:
     f.write("# %s -- FFT path (BASELINE config 5)\n\n" % tag + STAMP)
     j = last_json(read("fft.log"))
     if j:
-        f.write("| case | scans/s | ms/scan | algorithmic GB/s | of 8 TB/s | picture max abs diff vs numpy oracle | identical |\n|---|---|---|---|---|---|---|\n")
+        f.write("`python3 tools/bench_fft.py 64 4` (mean over the repetitions; algorithmic = SURVEY's reference formulation, 43 B/px; "
+                "kernel = what the kernels move: u8 in, half spectrum and |F| of it written and read once, two pictures out):\n\n")
+        f.write("| case | scans/s | ms/scan (mean) | best | algorithmic GB/s | of 8 TB/s | kernel-bytes GB/s | of 8 TB/s |\n|---|---|---|---|---|---|---|---|\n")
         for k, v in j.items():
-            f.write("| %s (batch %d) | %.0f | %.3f | %.0f | %.3f | %d | %.5f |\n" % (k, v["batch"], v["scans_per_s"], v["ms_per_scan"],
-                    v["algorithmic_GBps"], v["algorithmic_GBps"] / 8000, v["picture_max_abs_diff"], v["picture_identical_fraction"]))
-    f.write("\nKernel stats of the same script (`rocprofv3 --kernel-trace --stats -- python3 tools/bench_fft.py`):\n\n")
-    stats_table("fft_stats", f, 6)
+            f.write("| %s (batch %d) | %.0f | %.3f | %.3f | %.0f | %.3f | %.0f | %.3f |\n" % (
+                k, v["batch"], v["scans_per_s"], v["ms_per_scan"], v["best_ms_per_scan"], v["algorithmic_GBps"],
+                v["algorithmic_GBps"] / 8000, v["kernel_GBps"], v["kernel_GBps"] / 8000))
+    f.write("\nKernel stats (`rocprofv3 --kernel-trace --stats -- python3 tools/bench_fft.py 32 3`, both sizes):\n\n")
+    stats_table("fft_stats", f, 8)
+    for w, nm in (("c5", "4096 x 4096"), ("a4", "2480 x 3508")):
+        f.write("\nMeasured HBM-side traffic, %s, 16 scans per call (FETCH_SIZE and WRITE_SIZE each in a pass of its own):\n\n" % nm)
+        hbm_table("fft_fetch_" + w, "fft_write_" + w, f, needles=("fft_pass_kernel", "spec_pictures_kernel"))
+        counter_table("fft_sq_" + w, "fft_pass_kernel", f)
 with open(os.path.join(dst, tag + "_hough.md"), "w") as f:
     f.write("# %s -- Hough-line path (BASELINE config 4)\n\n" % tag + STAMP)
     j = last_json(read("hough.log"))
     if j:
-        f.write("`python3 tools/bench_hough.py 256 8 2`:\n\n```\n%s\n```\n\n" % json.dumps(j, indent=1))
+        f.write("`python3 tools/bench_hough.py 256 8 2` (mean over the repetitions):\n\n```\n%s\n```\n\n" % json.dumps(j, indent=1))
     j1 = last_json(read("hough_single.log"))
     if j1:
         f.write("One resident A4 scan, Canny + HoughLinesP + vote, best of 5 (`python3 tools/hough_run.py 1 1 5`): **%.4f s**\n\n" % j1["seconds"])
     ml = "\n".join(l for l in read("mem_latency.log").splitlines() if "amdgpu.ids" not in l)
     if ml:
         f.write("What one dependent memory round trip costs a lone wave (`tools/mem_latency.hip`, shader cycles):\n\n```\n%s\n```\n\n" % ml)
-    f.write("Phase clocks of one scan's sequential stage (debug library, tools/hstamps.py):\n\n```\n%s%s```\n\n" % (
-        read("hstamps_a4.log").replace("/opt/amdgpu/share/libdrm/amdgpu.ids: No such file or directory\n", ""),
-        read("hstamps_half.log").replace("/opt/amdgpu/share/libdrm/amdgpu.ids: No such file or directory\n", "")))
+    f.write("Phase clocks of one scan's sequential stage (debug library, tools/hstamps.py):\n\n```\n%s```\n\n" % (
+        read("hstamps_a4.log").replace("/opt/amdgpu/share/libdrm/amdgpu.ids: No such file or directory\n", "")))
     f.write("Kernel stats, 64 resident scans (`rocprofv3 --kernel-trace --stats -- python3 tools/hough_run.py 64 4 1`):\n\n")
     stats_table("hough_stats", f, 8)
     f.write("\nCounters of `ppht_kernel` (separate passes: FETCH_SIZE alone, WRITE_SIZE alone, eight SQ counters):\n")
@@ -170,9 +231,10 @@ with open(os.path.join(dst, tag + "_hough.md"), "w") as f:
         f.write("\n(HBM traffic not computed: %r)\n" % (e,))
 with open(os.path.join(dst, tag + "_calls.md"), "w") as f:
     f.write("# %s -- per-call latency of the host-image drivers and the host-memory batch\n\n" % tag + STAMP)
-    f.write("`python3 tools/bench_calls.py`:\n\n```\n%s```\n\n`python3 tools/bench_host.py`:\n\n```\n%s```\n" % (
+    f.write("`python3 tools/bench_calls.py`:\n\n```\n%s```\n\n`python3 tools/bench_host.py`:\n\n```\n%s```\n\n`python3 tools/bench_threads.py`:\n\n```\n%s```\n" % (
         "\n".join(l for l in read("calls.log").splitlines() if "amdgpu.ids" not in l) + "\n",
-        "\n".join(l for l in read("host.log").splitlines() if "amdgpu.ids" not in l) + "\n"))
+        "\n".join(l for l in read("host.log").splitlines() if "amdgpu.ids" not in l) + "\n",
+        "\n".join(l for l in read("threads.log").splitlines() if "amdgpu.ids" not in l) + "\n"))
 cp = "\n".join(l for l in read("core_protocol.log").splitlines() if "amdgpu.ids" not in l)
 if cp.strip():
     with open(os.path.join(dst, tag + "_core_protocol.md"), "w") as f:

@@ -1,49 +1,75 @@
 #!/bin/bash
-# Round profiling recipe (run on the GPU box through gpurun).  Everything lands under gpurun_out/<tag>/;
-# tools/make_profiles.py (run in the build container afterwards) turns it into profiles/<tag>_* stamped with the
-# commit it measured.  Rules kept: counters in their own runs with --kernel-trace only; FETCH_SIZE and WRITE_SIZE
-# each alone (TCC has 4 slots: 3 + 2); at most 8 SQ counters per pass; the program itself (python3 <script>) directly
-# after `--`; nothing under the profiler spawns a build.
-#   usage: bash tools/profile_round.sh r02
+# Round profiling recipe (run on the GPU box through gpurun, in two calls: a gpurun call lasts 20 minutes at most).
+# Everything lands under gpurun_out/<tag>/; tools/make_profiles.py (run in the build container afterwards) turns it
+# into profiles/<tag>_* stamped with the commit it measured.  Rules kept: counters in their own runs with
+# --kernel-trace only; FETCH_SIZE and WRITE_SIZE each alone (TCC has 4 slots: 3 + 2); at most 8 SQ counters per pass;
+# the program itself (python3 <script>) directly after `--`; nothing under the profiler spawns a build or a child.
+#   usage: bash tools/profile_round.sh r03 a     (bench line, sweep kernel, batch warp)
+#          bash tools/profile_round.sh r03 b     (stage kernels, FFT, Hough, per-call latencies, micro-benchmarks)
 set -eo pipefail
-TAG=${1:-r02}
+TAG=${1:-r03}
+PART=${2:-a}
 OUT=gpurun_out/$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-python3 -c "from oracle import oracle as o; o.build()" > "$OUT/oracle_build.log" 2>&1   # before anything is profiled
-# 1. the bench line exactly as the driver runs it (its own FETCH_SIZE / WRITE_SIZE / SQ child passes included)
-timeout -k 10 900 python3 bench.py > "$OUT/bench_line.json" 2> "$OUT/bench_line.err"
-rm -rf "$OUT/bench_pmc" && cp -r gpurun_out/bench_pmc "$OUT/bench_pmc" 2>/dev/null || true
-echo "[profile] bench line done"
-# 2. kernel stats of the same command (no counters in this run)
-timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python3 bench.py --no-cpu-baseline --no-pmc > "$OUT/stats.log" 2>&1
-echo "[profile] kernel stats done"
-# 3. second SQ pass of the sweep kernel (wait states), single-scan launches
-timeout -k 10 600 rocprofv3 --pmc SQ_WAIT_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAVES --kernel-trace --output-format csv -d "$OUT/pmc_sq2" -- python3 tools/kbench.py 3 > "$OUT/pmc_sq2.log" 2>&1
-timeout -k 10 600 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES --kernel-trace --output-format csv -d "$OUT/pmc_sq1" -- python3 tools/kbench.py 3 > "$OUT/pmc_sq1.log" 2>&1
-echo "[profile] sweep SQ counters done"
-timeout -k 10 300 python3 tools/kbench.py 20 > "$OUT/kbench.log" 2>&1
-timeout -k 10 300 python3 tools/kstamps.py > "$OUT/kstamps.log" 2>&1 || true
-for d in 0 1 2 4 6 7; do OMR_RUNS_DBG=$d timeout -k 10 120 python3 tools/kdbg.py 6 2>/dev/null | grep sweep >> "$OUT/kdbg.log" || true; done
-echo "[profile] sweep kernel timings done"
-# 4. stage kernels, FFT, Hough (un-profiled numbers + kernel stats + split counter passes for the Hough stage)
-timeout -k 10 300 python3 tools/bench_stages.py 30 > "$OUT/stages.log" 2>&1 || true
-timeout -k 10 300 python3 tools/bench_fft.py 64 4 > "$OUT/fft.log" 2>&1 || true
-timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/fft_stats" -- python3 tools/bench_fft.py > "$OUT/fft_stats.log" 2>&1 || true
-timeout -k 10 600 python3 tools/bench_hough.py 256 8 2 > "$OUT/hough.log" 2>&1 || true
-timeout -k 10 300 python3 tools/hough_run.py 1 1 5 > "$OUT/hough_single.log" 2>&1 || true
-timeout -k 10 300 python3 tools/hstamps.py > "$OUT/hstamps_a4.log" 2>&1 || true
-timeout -k 10 300 python3 tools/hstamps.py 1754 1240 > "$OUT/hstamps_half.log" 2>&1 || true
-timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/hough_stats" -- python3 tools/hough_run.py 64 4 1 > "$OUT/hough_stats.log" 2>&1 || true
-timeout -k 10 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/hough_fetch" -- python3 tools/hough_run.py 64 4 1 > "$OUT/hough_fetch.log" 2>&1 || true
-timeout -k 10 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/hough_write" -- python3 tools/hough_run.py 64 4 1 > "$OUT/hough_write.log" 2>&1 || true
-timeout -k 10 600 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAVE_CYCLES SQ_BUSY_CYCLES --kernel-trace --output-format csv -d "$OUT/hough_sq" -- python3 tools/hough_run.py 64 4 1 > "$OUT/hough_sq.log" 2>&1 || true
-echo "[profile] stages / fft / hough done"
-timeout -k 10 300 python3 tools/bench_calls.py > "$OUT/calls.log" 2>&1 || true
-timeout -k 10 600 python3 tools/core_protocol.py > "$OUT/core_protocol.log" 2>&1 || true
-timeout -k 10 300 python3 tools/bench_host.py > "$OUT/host.log" 2>&1 || true
-# 5. micro-benchmarks behind DESIGN.md's issue-cost / LDS statements
-for t in valu_issue valu_ops lds_unaligned lds_bytes mem_latency; do
-  hipcc -O2 --offload-arch=gfx950 tools/$t.hip -o /tmp/$t > "$OUT/$t.build.log" 2>&1 && timeout -k 10 200 /tmp/$t > "$OUT/$t.log" 2>&1 || true
-done
-echo "[profile] all done"
+prof() { # prof <outdir> <counters or --stats> -- program...
+  local d=$1; shift
+  if [ "$1" = "--stats" ]; then shift; timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/$d" "$@" > "$OUT/$d.log" 2>&1 || true
+  else local c=$1; shift; timeout -k 10 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$OUT/$d" "$@" > "$OUT/$d.log" 2>&1 || true; fi
+}
+SQ1="SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CU_CYCLES"
+SQ2="SQ_WAIT_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAVES"
+if [ "$PART" = "a" ]; then
+  # 1. the bench line exactly as the driver runs it (its own FETCH_SIZE / WRITE_SIZE / SQ child passes included)
+  timeout -k 10 900 python3 bench.py > "$OUT/bench_line.json" 2> "$OUT/bench_line.err"
+  rm -rf "$OUT/bench_pmc" && cp -r gpurun_out/bench_pmc "$OUT/bench_pmc" 2>/dev/null || true
+  echo "[profile] bench line done"
+  # 2. kernel stats of the same command (no counters in this run)
+  prof stats --stats -- python3 bench.py --no-cpu-baseline --no-pmc
+  echo "[profile] kernel stats done"
+  # 3. the sweep kernel in batch mode (8 scans per launch): two SQ passes, timings, phase clocks of the debug build
+  prof pmc_sq1 "$SQ1" -- python3 tools/kbatch.py 4 8
+  prof pmc_sq2 "$SQ2" -- python3 tools/kbatch.py 4 8
+  timeout -k 10 300 python3 tools/kbatch.py 16 8 > "$OUT/kbatch.log" 2>&1 || true
+  timeout -k 10 300 python3 tools/kbench.py 20 > "$OUT/kbench.log" 2>&1 || true
+  timeout -k 10 300 python3 tools/kstamps.py > "$OUT/kstamps.log" 2>&1 || true
+  echo "[profile] sweep kernel done"
+  # 4. the batch warp on its own (sweep and warp never share the chip: the context is synchronised per call)
+  timeout -k 10 300 python3 tools/bench_deskew.py 10 > "$OUT/deskew.log" 2>&1 || true
+  prof deskew_stats --stats -- python3 tools/bench_deskew.py 10
+  prof deskew_fetch FETCH_SIZE -- python3 tools/bench_deskew.py 4
+  prof deskew_write WRITE_SIZE -- python3 tools/bench_deskew.py 4
+  echo "[profile] batch warp done"
+  timeout -k 10 300 python3 tools/bench_calls.py > "$OUT/calls.log" 2>&1 || true
+  timeout -k 10 300 python3 tools/bench_host.py > "$OUT/host.log" 2>&1 || true
+  timeout -k 10 300 python3 tools/bench_threads.py > "$OUT/threads.log" 2>&1 || true
+else
+  # 5. stage kernels, FFT, Hough: un-profiled numbers, kernel stats, FETCH_SIZE / WRITE_SIZE each alone
+  timeout -k 10 300 python3 tools/bench_stages.py 30 > "$OUT/stages.log" 2>&1 || true
+  prof stages_stats --stats -- python3 tools/bench_stages.py 10
+  prof stages_fetch FETCH_SIZE -- python3 tools/bench_stages.py 5
+  prof stages_write WRITE_SIZE -- python3 tools/bench_stages.py 5
+  echo "[profile] stages done"
+  timeout -k 10 300 python3 tools/bench_fft.py 64 4 > "$OUT/fft.log" 2>&1 || true
+  prof fft_stats --stats -- python3 tools/bench_fft.py 32 3
+  for w in c5 a4; do
+    prof fft_fetch_$w FETCH_SIZE -- python3 tools/bench_fft.py 16 2 $w
+    prof fft_write_$w WRITE_SIZE -- python3 tools/bench_fft.py 16 2 $w
+    prof fft_sq_$w "$SQ1" -- python3 tools/bench_fft.py 16 2 $w
+  done
+  echo "[profile] fft done"
+  timeout -k 10 600 python3 tools/bench_hough.py 256 8 2 > "$OUT/hough.log" 2>&1 || true
+  timeout -k 10 300 python3 tools/hough_run.py 1 1 5 > "$OUT/hough_single.log" 2>&1 || true
+  timeout -k 10 300 python3 tools/hstamps.py > "$OUT/hstamps_a4.log" 2>&1 || true
+  prof hough_stats --stats -- python3 tools/hough_run.py 64 4 1
+  prof hough_fetch FETCH_SIZE -- python3 tools/hough_run.py 64 4 1
+  prof hough_write WRITE_SIZE -- python3 tools/hough_run.py 64 4 1
+  prof hough_sq "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAVE_CYCLES SQ_BUSY_CYCLES" -- python3 tools/hough_run.py 64 4 1
+  echo "[profile] hough done"
+  timeout -k 10 600 python3 tools/core_protocol.py > "$OUT/core_protocol.log" 2>&1 || true
+  # 6. micro-benchmarks behind DESIGN.md's statements
+  for t in lds_dma_window; do
+    hipcc -O2 --offload-arch=gfx950 tools/$t.hip -o /tmp/$t > "$OUT/$t.build.log" 2>&1 && timeout -k 10 200 /tmp/$t > "$OUT/$t.log" 2>&1 || true
+  done
+fi
+echo "[profile] part $PART done"
