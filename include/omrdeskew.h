@@ -326,6 +326,13 @@ int omr_edges_detection_batch_device(const uint8_t *d_scans, int32_t n, int64_t 
                                      double min_line_length, double max_line_gap, double *angles,
                                      int32_t *status, int32_t *n_lines, void *stream);
 
+/* Tuning knob of the batch above, process-wide: how many scans the sequential Hough stage works on at once
+ * (= workgroups of its kernel; each finished workgroup takes the next scan of the batch).  Every scan in
+ * flight keeps an accumulator (2.8 MB at A4) and a point mask (1.1 MB) hot, so the count trades cache
+ * footprint against occupied compute units.  0 = the library's default (profiles/r03_hough.md).  Returns
+ * the previous setting.  No counterpart in the reference (its OpenCV call is one scan per thread). */
+int32_t omr_hough_set_scans_in_flight(int32_t scans);
+
 /* The decision of correct_default (omr.rs:351-399): which angle to rotate by and whether the sheet
  * needs a manual check, from the projection result and the edges result. */
 void omr_correct_default_decision(double proj_angle, int32_t proj_status, const double *proj_candidates,

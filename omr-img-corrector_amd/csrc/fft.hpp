@@ -56,10 +56,27 @@ struct FftPass {
     int64_t src_u8_scan_stride;                  // bytes
     int64_t c_scan_stride;                       // elements of src_c / dst
     int64_t mag_scan_stride, part_scan_stride;   // floats
+    int32_t sub;            // fft_mixed.hip's Bluestein on sub-lines: their number (0: every other kind of pass)
 };
 #define OMR_FFT_MAX_M 16384    // transforms of 16384 points run in place (one 128 KiB LDS buffer, radix 2)
 #define OMR_FFT_MAX_PINGPONG 8192
 hipError_t launch_fft_pass(const FftPass &p, hipStream_t s);
+
+// fft_mixed.hip: the same pass for the line lengths that have a mixed-radix kernel (an A4 scan's short side: 1240,
+// 2480, 4960 = 2^a * 5 * 31): in-place Stockham stages in LDS instead of Bluestein's two 8192-point transforms.
+// fft_mixed_radices(): the stages of length n, first stage first (returns their number, 0 = not a mixed-radix length);
+// p.W must hold fft_mixed_table_size(n) twiddles laid out as fft_mixed.hip describes, p.m = p.n, p.chirp = NULL.
+int fft_mixed_radices(int n, int radices[4]);
+int fft_mixed_table_size(int n);
+// ... and for lines of n = SUB * P points, 2048 < n <= 8192, whose plain chirp-z would run 8192 or 16384 points:
+// Bluestein on the SUB interleaved sub-lines (m = 2048 each) and one radix-SUB stage.  fft_bluesub_lines(): SUB (0: not
+// taken); p.sub = SUB, p.m = 2048, p.chirp / p.Bf = the chirp tables of P = n / SUB points, p.W = the twiddles of the
+// stages fft_bluesub_stages() names (laid out like a mixed-radix plan of 2048 points, fft_bluesub_stage_table_size()
+// entries) followed by G[r][k] = chirp[k] exp(-2 pi i r k / n) / 2048, r < SUB, k < P.
+int fft_bluesub_lines(int n);
+int fft_bluesub_stage_table_size();
+void fft_bluesub_stages(int radices[3]);
+hipError_t launch_fft_mixed(const FftPass &p, hipStream_t s);
 
 // d_minmax: 4 ordered-uint words {min |F|, max |F|, min log, max log}; d_part: scratch for per-block
 // extrema, spec_part_floats(rows, cols) floats

@@ -420,8 +420,31 @@ __device__ __forceinline__ void ppht_draw(const PphtArgs &a, PphtShared &sh, int
 // costs a wave 70-230 cycles to issue whatever its lanes do, and a segment needs 180 x ceil(points / 64) of them, so
 // the angles are split between wave 0 and the helper waves (an accepted segment is rare -- 4 % of the served
 // points -- but its un-votes were a fifth of a scan's time on one wave).
-__device__ __forceinline__ void unvote_points(PphtShared &sh, int32_t *accum, int npts, int n0, int n1, int lane)
+//
+// The accumulator comes in two widths.  U16: a bin is an unsigned short holding count + 0x8080 (the buffer is filled with
+// the byte 0x80).  A bin's count stays within +-(pixels of one rho strip) <= the image diagonal -- every pixel votes at
+// most once and is un-voted at most once, and OpenCV's un-votes can run ahead of the votes (negative counts) -- so the
+// host may pick U16 whenever rows + cols <= OMR_PPHT_U16_MAX_EXTENT: half the footprint in L2 / Infinity Cache, twice the
+// bins per line -- and measurably SLOWER than int32 bins (hough.hpp), so the shipped library never does.
+// An un-vote is a 32-bit atomic subtract of 1 or 1 << 16 on the word that holds the bin (no borrow can cross: the
+// biased count never reaches 0).  Arg-max compares the biased values (same order) and removes the bias once.
+#define OMR_PPHT_U16_BIAS 0x8080
+template <bool U16>
+__device__ __forceinline__ int acc_load(char *accum, uint32_t off)
 {
+    if (U16) return (int)__hip_atomic_load((uint16_t *)(accum + off), __ATOMIC_RELAXED, PP_WG);
+    return __hip_atomic_load((int32_t *)(accum + off), __ATOMIC_RELAXED, PP_WG);
+}
+template <bool U16>
+__device__ __forceinline__ void acc_store(char *accum, uint32_t off, int v)
+{
+    if (U16) __hip_atomic_store((uint16_t *)(accum + off), (uint16_t)v, __ATOMIC_RELAXED, PP_WG);
+    else __hip_atomic_store((int32_t *)(accum + off), v, __ATOMIC_RELAXED, PP_WG);
+}
+template <bool U16>
+__device__ __forceinline__ void unvote_points(PphtShared &sh, char *accum, int npts, int n0, int n1, int lane)
+{
+    constexpr uint32_t BIN = U16 ? 2u : 4u;
     for (int g = 0; g < npts; g += 64) {
         if (g + lane < npts) {
             const uint32_t q = sh.pts[g + lane];
@@ -429,8 +452,9 @@ __device__ __forceinline__ void unvote_points(PphtShared &sh, int32_t *accum, in
 #pragma unroll 4
             for (int n = n0; n < n1; n++) {
                 const float4 t = sh.ang[n];  // (cos, sin, byte offset of the row's bin 0, -): LDS broadcast
-                const uint32_t o = __float_as_uint(t.z) + 4u * (uint32_t)__float2int_rn(__fadd_rn(__fmul_rn(fj, t.x), __fmul_rn(fi, t.y)));
-                __hip_atomic_fetch_sub((int32_t *)((char *)accum + o), 1, __ATOMIC_RELAXED, PP_WG);
+                const uint32_t o = __float_as_uint(t.z) + BIN * (uint32_t)__float2int_rn(__fadd_rn(__fmul_rn(fj, t.x), __fmul_rn(fi, t.y)));
+                if (U16) __hip_atomic_fetch_sub((uint32_t *)(accum + (o & ~3u)), 1u << ((o & 2u) << 3), __ATOMIC_RELAXED, PP_WG);
+                else __hip_atomic_fetch_sub((int32_t *)(accum + o), 1, __ATOMIC_RELAXED, PP_WG);
             }
         }
     }
@@ -442,9 +466,10 @@ __device__ __forceinline__ void angle_share(int numangle, int part, int &n0, int
     n0 = min(numangle, part * per);
     n1 = min(numangle, n0 + per);
 }
+template <bool U16>
 __device__ __forceinline__ void ppht_help(const PphtArgs &a, PphtShared &sh, int scan, int lane, int part)
 {
-    int32_t *accum = a.accum + (int64_t)scan * a.accum_stride;
+    char *accum = (char *)a.accum + (int64_t)scan * a.accum_stride * (U16 ? 2 : 4);
     int n0, n1;
     angle_share(a.numangle, part, n0, n1);
     for (int seen = 0;;) {
@@ -452,7 +477,7 @@ __device__ __forceinline__ void ppht_help(const PphtArgs &a, PphtShared &sh, int
         while ((seq = __hip_atomic_load(&sh.job_seq, __ATOMIC_ACQUIRE, PP_WG)) == seen) __builtin_amdgcn_s_sleep(2);
         if (seq < 0) break;  // the scan is finished
         seen = seq;
-        unvote_points(sh, accum, sh.job_npts, n0, n1, lane);
+        unvote_points<U16>(sh, accum, sh.job_npts, n0, n1, lane);
         // release: the decrements are performed before wave 0 reads the accumulator again
         if (lane == 0) __hip_atomic_fetch_add(&sh.job_done, 1, __ATOMIC_RELEASE, PP_WG);
     }
@@ -559,14 +584,15 @@ __device__ __forceinline__ void gap_rule_short(unsigned long long n0, unsigned l
 }
 
 #define OMR_PPHT_PTS 1024  // LDS list of a segment's points waiting for their un-votes
-template <int NPL, bool SHORT_GAP>  // accumulator angles per lane; lineGap < 64 (the loop-free rule with one shift)
+template <int NPL, bool SHORT_GAP, bool U16>  // accumulator angles per lane; lineGap < 64 (the loop-free rule with one shift); bin width
 __device__ __forceinline__ void ppht_serve(const PphtArgs &a, PphtShared &sh, int scan, int lane)
 {
     const int W = a.width, H = a.height;
     unsigned long long *mask = (unsigned long long *)a.mask + (int64_t)scan * (ppht_mask_bytes(H, W) / 8);
     const int TX = ppht_tiles_x(W);
     const uint32_t *order = a.order + a.scan_off[scan];
-    int32_t *accum = a.accum + (int64_t)scan * a.accum_stride;
+    constexpr uint32_t BIN = U16 ? 2u : 4u;
+    char *accum = (char *)a.accum + (int64_t)scan * a.accum_stride * (int64_t)BIN;
     int32_t *lines = a.lines + (int64_t)scan * a.cap * 4;
     const int N = a.count[scan];
     // Lanes without an angle (numangle is 180: lanes 52-63 of the third set) vote for a scratch bin of their own
@@ -580,12 +606,11 @@ __device__ __forceinline__ void ppht_serve(const PphtArgs &a, PphtShared &sh, in
         voter[v] = n < a.numangle;
         tc[v] = voter[v] ? a.ttab[2 * n] : 0.f;
         ts[v] = voter[v] ? a.ttab[2 * n + 1] : 0.f;
-        rowb[v] = 4u * (uint32_t)(voter[v] ? (int64_t)a.row_base[n] : a.accum_stride - 64 + lane);
+        rowb[v] = BIN * (uint32_t)(voter[v] ? (int64_t)a.row_base[n] : a.accum_stride - 64 + lane);
     }
     auto bin_off = [&](int v, float fj, float fi) -> uint32_t {
-        return rowb[v] + 4u * (uint32_t)__float2int_rn(__fadd_rn(__fmul_rn(fj, tc[v]), __fmul_rn(fi, ts[v])));
+        return rowb[v] + BIN * (uint32_t)__float2int_rn(__fadd_rn(__fmul_rn(fj, tc[v]), __fmul_rn(fi, ts[v])));
     };
-    auto bin_ptr = [&](uint32_t off) -> int32_t * { return (int32_t *)((char *)accum + off); };
     int k0 = 0, nl = 0, jobs = 0;
     PP_DECL
     uint32_t pt = 0;              // this lane's drawn point of the current round
@@ -639,14 +664,14 @@ __device__ __forceinline__ void ppht_serve(const PphtArgs &a, PphtShared &sh, in
 #pragma unroll
             for (int v = 0; v < NPL; v++) {
                 off[v] = bin_off(v, fj, fi);
-                val[v] = __hip_atomic_load(bin_ptr(off[v]), __ATOMIC_RELAXED, PP_WG);
+                val[v] = acc_load<U16>(accum, off[v]);
             }
         }
         int key = (int)0x80000000;
 #pragma unroll
         for (int v = 0; v < NPL; v++) {
             val[v] += 1;
-            __hip_atomic_store(bin_ptr(off[v]), val[v], __ATOMIC_RELAXED, PP_WG);
+            acc_store<U16>(accum, off[v], val[v]);
             const int k = (int)(((uint32_t)val[v] << 8) | (uint32_t)(255 - (lane + 64 * v)));
             key = voter[v] ? max(key, k) : key;
         }
@@ -659,11 +684,11 @@ __device__ __forceinline__ void ppht_serve(const PphtArgs &a, PphtShared &sh, in
 #pragma unroll
             for (int v = 0; v < NPL; v++) {
                 aoff[v] = bin_off(v, fj, fi);
-                aval[v] = __hip_atomic_load(bin_ptr(aoff[v]), __ATOMIC_RELAXED, PP_WG);
+                aval[v] = acc_load<U16>(accum, aoff[v]);
             }
         }
         key = wave_max_i32(key);
-        const int max_val = key >> 8, max_n = 255 - (key & 255);
+        const int max_val = (key >> 8) - (U16 ? OMR_PPHT_U16_BIAS : 0), max_n = 255 - (key & 255);
         PP_CLK(c2)
         PP_ADD(1, c1, c2)
         if (max_val < a.threshold) continue;  // with threshold 0 only when un-votes drove the bins negative
@@ -737,7 +762,7 @@ __device__ __forceinline__ void ppht_serve(const PphtArgs &a, PphtShared &sh, in
             angle_share(a.numangle, 0, n0, n1);
             sh.job_npts = npts;
             __hip_atomic_store(&sh.job_seq, ++jobs, __ATOMIC_RELEASE, PP_WG);  // the points are in LDS before the helpers start
-            unvote_points(sh, accum, npts, n0, n1, lane);
+            unvote_points<U16>(sh, accum, npts, n0, n1, lane);
             while (__hip_atomic_load(&sh.job_done, __ATOMIC_ACQUIRE, PP_WG) != OMR_PPHT_HELPERS * jobs) __builtin_amdgcn_s_sleep(1);
             PP_CLK(u1)
             PP_ADD(10, u0, u1)
@@ -817,38 +842,56 @@ __device__ __forceinline__ void ppht_serve(const PphtArgs &a, PphtShared &sh, in
 
 // (NPL, SHORT_GAP) are template parameters of the KERNEL: each launch then runs a body that holds one vote width and one
 // gap rule only (the reference's parameters: 180 angles, lineGap 15 .. 75).
-template <int NPL, bool SHORT_GAP>
+template <int NPL, bool SHORT_GAP, bool U16>
 __global__ __launch_bounds__(OMR_PPHT_THREADS) void ppht_kernel(const PphtArgs a)
 {
     __shared__ PphtShared sh;
-    const int scan = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    __shared__ int next_scan;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int k = tid; k < a.numangle; k += OMR_PPHT_THREADS) {
         sh.walk[k] = a.walk[k];
-        sh.ang[k] = make_float4(a.ttab[2 * k], a.ttab[2 * k + 1], __uint_as_float(4u * (uint32_t)a.row_base[k]), 0.f);
+        sh.ang[k] = make_float4(a.ttab[2 * k], a.ttab[2 * k + 1], __uint_as_float((U16 ? 2u : 4u) * (uint32_t)a.row_base[k]), 0.f);
     }
-    if (tid == 0) {
-        sh.produced = 0;
-        sh.job_seq = 0;
-        sh.job_done = 0;
+    // The grid holds as many workgroups as scans are meant to be in flight (launch_ppht); a workgroup that has finished
+    // its scan takes the next one from the queue, so the number of accumulators and masks being worked on -- the
+    // footprint in L2 and Infinity Cache -- is the grid size whatever the batch size.  Every wave leaves its role when
+    // the scan is finished and the queue runs dry for all workgroups: the loop ends.
+    for (int scan = blockIdx.x; scan < a.n_scans;) {
+        if (tid == 0) {
+            sh.produced = 0;
+            sh.job_seq = 0;
+            sh.job_done = 0;
+        }
+        __syncthreads();  // from here on the waves run on their own until the scan is finished
+        if (wave == 1) ppht_draw(a, sh, scan, lane);
+        else if (wave >= 2) ppht_help<U16>(a, sh, scan, lane, wave - 1);
+        else ppht_serve<NPL, SHORT_GAP, U16>(a, sh, scan, lane);
+        if (tid == 0) next_scan = (int)gridDim.x + atomicAdd(a.queue, 1);
+        __syncthreads();
+        scan = next_scan;
     }
-    __syncthreads();  // the only workgroup barrier: from here on the waves run on their own
-    const int wave = tid >> 6;
-    if (wave == 1) ppht_draw(a, sh, scan, lane);
-    else if (wave >= 2) ppht_help(a, sh, scan, lane, wave - 1);
-    else ppht_serve<NPL, SHORT_GAP>(a, sh, scan, lane);
 }
 
-hipError_t launch_ppht(const PphtArgs &a, int n, hipStream_t s)
+template <int NPL, bool SHORT_GAP>
+static void launch_ppht_width(const PphtArgs &a, int n, hipStream_t s)  // n = workgroups = scans in flight
 {
+    if (a.acc_u16) hipLaunchKernelGGL((ppht_kernel<NPL, SHORT_GAP, true>), dim3(n), dim3(OMR_PPHT_THREADS), 0, s, a);
+    else hipLaunchKernelGGL((ppht_kernel<NPL, SHORT_GAP, false>), dim3(n), dim3(OMR_PPHT_THREADS), 0, s, a);
+}
+hipError_t launch_ppht(const PphtArgs &a, int in_flight, hipStream_t s)
+{
+    const int n = in_flight > 0 ? (in_flight < a.n_scans ? in_flight : a.n_scans) : a.n_scans;
     if (n <= 0) return hipSuccess;
+    if (!a.queue) return hipErrorInvalidValue;
     if (a.numangle > OMR_PPHT_MAX_ANGLES) return hipErrorInvalidValue;
+    if (a.acc_u16 && (a.accum_stride & 1)) return hipErrorInvalidValue;  // a scan's bins start on a 32-bit word
     const bool short_gap = (uint32_t)a.line_gap < 64u;
     if (a.numangle <= 192) {
-        if (short_gap) hipLaunchKernelGGL((ppht_kernel<3, true>), dim3(n), dim3(OMR_PPHT_THREADS), 0, s, a);
-        else hipLaunchKernelGGL((ppht_kernel<3, false>), dim3(n), dim3(OMR_PPHT_THREADS), 0, s, a);
+        if (short_gap) launch_ppht_width<3, true>(a, n, s);
+        else launch_ppht_width<3, false>(a, n, s);
     } else {
-        if (short_gap) hipLaunchKernelGGL((ppht_kernel<4, true>), dim3(n), dim3(OMR_PPHT_THREADS), 0, s, a);
-        else hipLaunchKernelGGL((ppht_kernel<4, false>), dim3(n), dim3(OMR_PPHT_THREADS), 0, s, a);
+        if (short_gap) launch_ppht_width<4, true>(a, n, s);
+        else launch_ppht_width<4, false>(a, n, s);
     }
     return hipGetLastError();
 }

@@ -40,8 +40,11 @@ struct PphtArgs {
     uint32_t *order;          // same size and offsets as nz: the points in the order they are drawn (written by the kernel)
     const int64_t *scan_off;  // [n] offset of a scan's list in nz / order
     const int32_t *count;     // [n] points per scan
-    int32_t *accum;           // n x accum_stride, zeroed; row k of a scan starts at row_base[k] - (its lowest rho)
+    void *accum;              // n x accum_stride bins; row k of a scan starts at row_base[k] - (its lowest rho).
+                              // acc_u16 = 0: int32 bins, zeroed.  acc_u16 = 1: uint16 bins holding count + 0x8080 (fill
+                              // the buffer with the byte 0x80), accum_stride even; for rows + cols <= OMR_PPHT_U16_MAX_EXTENT
     int64_t accum_stride;
+    int32_t acc_u16;
     const int32_t *row_base;  // numangle: offset of the bin rho = 0 of row k (rows hold only the reachable rho range)
     int32_t numangle;
     const float *ttab;        // numangle x (cos / rho, sin / rho) as float
@@ -50,10 +53,21 @@ struct PphtArgs {
     int32_t *lines;           // n x cap x 4
     int32_t cap;
     int32_t *n_lines;         // [n]
+    int32_t n_scans;
+    int32_t *queue;           // one zeroed counter: scans handed out beyond the first grid-full
 };
 #define OMR_PPHT_THREADS 320      // wave 0 serves the points, wave 1 draws them, waves 2-4 help with the un-votes
 #define OMR_PPHT_MAX_ANGLES 256   // up to four accumulator angles per lane
-hipError_t launch_ppht(const PphtArgs &a, int n, hipStream_t s);
+// rows + cols up to which the accumulator is kept in 16-bit bins (hough.hip).  0 = never: measured side by side on one
+// GPU (profiles/r03_hough.md) the 16-bit accumulator LOST to int32 bins, 587 against 650 scans/s at 256 A4 scans -- the
+// batch is bound by the latency of each scan's dependent chain, not by the footprint, and 16-bit stores are partial
+// writes of a 32-bit word.  -DOMR_PPHT_U16_MAX_EXTENT=16000 rebuilds the 16-bit library of that comparison (a bin's
+// count stays within +-(image diagonal), far inside the 16-bit range for rows + cols <= 16000).
+#ifndef OMR_PPHT_U16_MAX_EXTENT
+#define OMR_PPHT_U16_MAX_EXTENT 0
+#endif
+// in_flight: workgroups launched = scans worked on at once (<= 0 or >= n_scans: one workgroup per scan)
+hipError_t launch_ppht(const PphtArgs &a, int in_flight, hipStream_t s);
 #ifdef OMR_RUNS_DEBUG
 hipError_t debug_ppht_stamps(unsigned long long out[12], bool reset);
 #endif

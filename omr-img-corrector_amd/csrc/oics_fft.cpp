@@ -60,11 +60,98 @@ void fft_host(std::vector<cd> &a)  // iterative radix-2, in place, forward
 // device tables of one axis length
 struct AxisTables {
     int n = 0, m = 0, log2m = 0;
-    bool blue = false;
+    bool blue = false, mixed = false;  // mixed: one of fft_mixed.hip's kernels takes this length
+    int sub = 0;                       // ... as Bluestein on this many sub-lines
     DevBuf W, Wfull, chirp, Bf;
+    hipError_t launch(const FftPass &p, hipStream_t s) const { return mixed ? launch_fft_mixed(p, s) : launch_fft_pass(p, s); }
+    // fft_mixed.hip's stage tables: per stage (radix R after Ns points) R == 16 -> w^k, else [q - 1][k] = w^(q k), w =
+    // exp(-2 pi i / (R Ns)); nothing for the first stage
+    static int stage_twiddles(const int *r, int ns, std::vector<cfloat> *w)
+    {
+        int Ns = 1;
+        for (int i = 0; i < ns; i++) {
+            if (Ns > 1) {
+                const double step = -2.0 * kPi / ((double)r[i] * (double)Ns);
+                for (int q = 1; q < (r[i] == 16 ? 2 : r[i]); q++)
+                    for (int k = 0; k < Ns; k++) {
+                        const double ang = step * (double)(((long long)q * k) % ((long long)r[i] * Ns));
+                        w->push_back(cfloat{(float)cos(ang), (float)sin(ang)});
+                    }
+            }
+            Ns *= r[i];
+        }
+        return Ns;
+    }
+    int build_mixed(hipStream_t s)
+    {
+        int r[4];
+        const int ns = fft_mixed_radices(n, r);
+        std::vector<cfloat> w;
+        const int Ns = stage_twiddles(r, ns, &w);
+        if ((int)w.size() != fft_mixed_table_size(n) || Ns != n) return fail(OMR_ERR_ASSERT, "mixed-radix plan of length %d", n);
+        mixed = true;
+        blue = false;
+        m = n;
+        log2m = 0;
+        OMR_HIP(W.alloc(sizeof(cfloat) * w.size()));
+        OMR_HIP(hipMemcpyAsync(W.p, w.data(), sizeof(cfloat) * w.size(), hipMemcpyHostToDevice, s));
+        OMR_HIP(hipStreamSynchronize(s));  // the host vector goes out of scope
+        return OMR_OK;
+    }
+    // chirp of P points and the spectrum of its padded conjugate (Bluestein with transforms of mm points)
+    static void chirp_tables(int P, int mm, std::vector<cd> *c, std::vector<cd> *b)
+    {
+        c->resize((size_t)P);
+        for (int k = 0; k < P; k++) {
+            const long long k2 = ((long long)k * k) % (2LL * P);  // exp(-i pi k^2 / P) has period 2 P in k^2
+            const double ang = -kPi * (double)k2 / (double)P;
+            (*c)[k] = cd(cos(ang), sin(ang));
+        }
+        b->assign((size_t)mm, cd(0, 0));
+        (*b)[0] = std::conj((*c)[0]);
+        for (int k = 1; k < P; k++) (*b)[k] = (*b)[mm - k] = std::conj((*c)[k]);
+        fft_host(*b);
+    }
+    int build_sub(hipStream_t s)  // fft_mixed.hip: Bluestein on `sub` interleaved sub-lines of P = n / sub points, m = 2048
+    {
+        const int P = n / sub;
+        mixed = true;
+        blue = true;
+        m = 2048;
+        log2m = 11;
+        int r[3];
+        fft_bluesub_stages(r);
+        std::vector<cfloat> w;
+        if (stage_twiddles(r, 3, &w) != m || (int)w.size() != fft_bluesub_stage_table_size())
+            return fail(OMR_ERR_ASSERT, "sub-line plan of length %d", n);
+        std::vector<cd> c, b;
+        chirp_tables(P, m, &c, &b);
+        for (int q = 0; q < sub; q++)
+            for (int k = 0; k < P; k++) {
+                const double ang = -2.0 * kPi * (double)(((long long)q * k) % n) / (double)n;
+                const cd g = c[k] * cd(cos(ang), sin(ang)) / (double)m;
+                w.push_back(cfloat{(float)g.real(), (float)g.imag()});
+            }
+        std::vector<cfloat> cf((size_t)P), bf((size_t)m);
+        for (int k = 0; k < P; k++) cf[k] = cfloat{(float)c[k].real(), (float)c[k].imag()};
+        for (int k = 0; k < m; k++) bf[k] = cfloat{(float)b[k].real(), (float)b[k].imag()};
+        OMR_HIP(W.alloc(sizeof(cfloat) * w.size()));
+        OMR_HIP(chirp.alloc(sizeof(cfloat) * cf.size()));
+        OMR_HIP(Bf.alloc(sizeof(cfloat) * bf.size()));
+        OMR_HIP(hipMemcpyAsync(W.p, w.data(), sizeof(cfloat) * w.size(), hipMemcpyHostToDevice, s));
+        OMR_HIP(hipMemcpyAsync(chirp.p, cf.data(), sizeof(cfloat) * cf.size(), hipMemcpyHostToDevice, s));
+        OMR_HIP(hipMemcpyAsync(Bf.p, bf.data(), sizeof(cfloat) * bf.size(), hipMemcpyHostToDevice, s));
+        OMR_HIP(hipStreamSynchronize(s));  // the host vectors go out of scope
+        return OMR_OK;
+    }
     int build(int len, hipStream_t s)
     {
         n = len;
+        {
+            int r[4];
+            if (fft_mixed_radices(n, r) > 0) return build_mixed(s);
+            if ((sub = fft_bluesub_lines(n)) > 0) return build_sub(s);
+        }
         blue = (n & (n - 1)) != 0;
         const int need = blue ? 2 * n - 1 : n;
         m = 1;
@@ -104,16 +191,8 @@ struct AxisTables {
         OMR_HIP(W.alloc(sizeof(cfloat) * w.size()));
         OMR_HIP(hipMemcpyAsync(W.p, w.data(), sizeof(cfloat) * w.size(), hipMemcpyHostToDevice, s));
         if (blue) {
-            std::vector<cd> c((size_t)n);
-            for (int k = 0; k < n; k++) {
-                const long long k2 = ((long long)k * k) % (2LL * n);  // exp(-i pi k^2 / n) has period 2n in k^2
-                const double ang = -kPi * (double)k2 / (double)n;
-                c[k] = cd(cos(ang), sin(ang));
-            }
-            std::vector<cd> b((size_t)m, cd(0, 0));
-            b[0] = std::conj(c[0]);
-            for (int k = 1; k < n; k++) b[k] = b[m - k] = std::conj(c[k]);
-            fft_host(b);
+            std::vector<cd> c, b;
+            chirp_tables(n, m, &c, &b);
             std::vector<cfloat> cf((size_t)n), bf((size_t)m);
             for (int k = 0; k < n; k++) cf[k] = cfloat{(float)c[k].real(), (float)c[k].imag()};
             for (int k = 0; k < m; k++) bf[k] = cfloat{(float)b[k].real(), (float)b[k].imag()};
@@ -201,6 +280,7 @@ struct FftWork {
         p.Wfull = axc->Wfull.as<cfloat>();
         p.chirp = axc->blue ? axc->chirp.as<cfloat>() : nullptr;
         p.Bf = axc->blue ? axc->Bf.as<cfloat>() : nullptr;
+        p.sub = axc->sub;
         p.out_scale = 1.0f;
         p.line_stride = pitch;  // (unused: the input is the 8-bit scan)
         p.elem_stride = 1;
@@ -209,7 +289,7 @@ struct FftWork {
         p.xcd_blocked = 1;      // neighbouring rows' 16-byte pieces of a line meet in one XCD's L2
         p.real_pairs = 1;  // two real rows per workgroup, columns 0 .. cols / 2 written
         p.src_rows = rows;
-        OMR_HIP(launch_fft_pass(p, s));
+        OMR_HIP(axc->launch(p, s));
         // along columns = along the lines of the transposed array, with DFT_SCALE
         FftPass q{};
         q.scans = scans;
@@ -234,8 +314,9 @@ struct FftWork {
         q.Wfull = axr->Wfull.as<cfloat>();
         q.chirp = axr->blue ? axr->chirp.as<cfloat>() : nullptr;
         q.Bf = axr->blue ? axr->Bf.as<cfloat>() : nullptr;
+        q.sub = axr->sub;
         q.out_scale = (float)(1.0 / ((double)rows * (double)cols));
-        OMR_HIP(launch_fft_pass(q, s));
+        OMR_HIP(axr->launch(q, s));
         OMR_HIP(launch_minmax_final(part.as<float>(), cols / 2 + 1, mm.as<uint32_t>(), s, scans, 2 * (int64_t)cols));
         OMR_HIP(launch_spec_pictures(mag.as<float>(), rows, cols, mag_pitch, mm.as<uint32_t>(), d_mag_u8, d_log_u8, s, scans,
                                      (int64_t)(cols / 2 + 1) * mag_pitch));

@@ -15,6 +15,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
 #include <thread>
 #include <vector>
 
@@ -61,6 +62,9 @@ int check_img(const omr_image *im)
     if (im->step_bytes < (int64_t)im->cols * im->channels) return fail(OMR_ERR_BADARG, "step_bytes too small");
     return OMR_OK;
 }
+
+// omr_hough_set_scans_in_flight(): 0 = the default (see ppht_device)
+std::atomic<int> g_scans_in_flight{0};
 
 inline int cv_round(double v) { return (int)lrint(v); }
 inline int cv_round(float v) { return (int)lrintf(v); }
@@ -125,7 +129,10 @@ int ppht_device(uint8_t *d_edges, int32_t *d_rowcnt, int rows, int cols, int n, 
         accum_stride += rmax - rmin + 1;
     }
     accum_stride += 64;  // scratch bins of the lanes that hold no angle
-    DevBuf rowoff, total, scanoff, nz, order, d_ttab, d_walk, d_rowbase, accum, lines, nlines, tiled;
+    accum_stride += accum_stride & 1;
+    const bool acc_u16 = rows + cols <= OMR_PPHT_U16_MAX_EXTENT;  // hough.hip: a bin's count is bounded by the diagonal
+    const size_t bin_bytes = acc_u16 ? sizeof(uint16_t) : sizeof(int32_t);
+    DevBuf rowoff, total, scanoff, nz, order, d_ttab, d_walk, d_rowbase, accum, lines, nlines, tiled, queue;
     OMR_HIP(rowoff.alloc(sizeof(int32_t) * (size_t)n * rows));
     OMR_HIP(total.alloc(sizeof(int32_t) * (size_t)n));
     OMR_HIP(launch_edges_rowscan(d_rowcnt, rows, n, rowoff.as<int32_t>(), total.as<int32_t>(), s));
@@ -155,8 +162,8 @@ int ppht_device(uint8_t *d_edges, int32_t *d_rowcnt, int rows, int cols, int n, 
     OMR_HIP(hipMemcpyAsync(d_walk.p, walk.data(), sizeof(PphtWalk) * walk.size(), hipMemcpyHostToDevice, s));
     OMR_HIP(d_rowbase.alloc(sizeof(int32_t) * row_base.size()));
     OMR_HIP(hipMemcpyAsync(d_rowbase.p, row_base.data(), sizeof(int32_t) * row_base.size(), hipMemcpyHostToDevice, s));
-    OMR_HIP(accum.alloc(sizeof(int32_t) * (size_t)n * (size_t)accum_stride));
-    OMR_HIP(hipMemsetAsync(accum.p, 0, accum.bytes, s));
+    OMR_HIP(accum.alloc(bin_bytes * (size_t)n * (size_t)accum_stride));
+    OMR_HIP(hipMemsetAsync(accum.p, acc_u16 ? 0x80 : 0, accum.bytes, s));
     OMR_HIP(lines.alloc(sizeof(int32_t) * 4 * (size_t)n * cap));
     OMR_HIP(nlines.alloc(sizeof(int32_t) * (size_t)n));
     PphtArgs a{};
@@ -167,8 +174,9 @@ int ppht_device(uint8_t *d_edges, int32_t *d_rowcnt, int rows, int cols, int n, 
     a.order = order.as<uint32_t>();
     a.scan_off = scanoff.as<int64_t>();
     a.count = total.as<int32_t>();
-    a.accum = accum.as<int32_t>();
+    a.accum = accum.p;
     a.accum_stride = accum_stride;
+    a.acc_u16 = acc_u16 ? 1 : 0;
     a.row_base = d_rowbase.as<int32_t>();
     a.numangle = numangle;
     a.ttab = d_ttab.as<float>();
@@ -179,7 +187,11 @@ int ppht_device(uint8_t *d_edges, int32_t *d_rowcnt, int rows, int cols, int n, 
     a.lines = lines.as<int32_t>();
     a.cap = cap;
     a.n_lines = nlines.as<int32_t>();
-    OMR_HIP(launch_ppht(a, n, s));
+    OMR_HIP(queue.alloc(sizeof(int32_t)));
+    OMR_HIP(hipMemsetAsync(queue.p, 0, sizeof(int32_t), s));
+    a.n_scans = n;
+    a.queue = queue.as<int32_t>();
+    OMR_HIP(launch_ppht(a, g_scans_in_flight.load(std::memory_order_relaxed), s));
     std::vector<int32_t> nl((size_t)n);
     OMR_HIP(hipMemcpyAsync(nl.data(), nlines.p, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, s));
     OMR_HIP(hipStreamSynchronize(s));
@@ -304,6 +316,11 @@ int edges_lines_device(const uint8_t *d_src, int64_t scan_stride, int64_t step, 
 }  // namespace omr
 
 extern "C" {
+
+int32_t omr_hough_set_scans_in_flight(int32_t scans)
+{
+    return (int32_t)omr::hh::g_scans_in_flight.exchange(scans < 0 ? 0 : scans);
+}
 
 int omr_canny(const omr_image *src, double low_thresh, double high_thresh, omr_image_owned *edges)
 {

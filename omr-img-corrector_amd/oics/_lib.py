@@ -107,6 +107,7 @@ SYMBOLS = {
                                                       C.c_int32, i32p]),
     "omr_edges_detection_batch_device": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.c_int32,
                                                    C.c_int64, C.c_double, C.c_double, f64p, i32p, i32p, C.c_void_p]),
+    "omr_hough_set_scans_in_flight": (C.c_int32, [C.c_int32]),
     "omr_correct_default_decision": (None, [C.c_double, C.c_int32, f64p, C.c_int32, C.c_double, f64p, i32p]),
     "omr_correct_default": (C.c_int, [C.POINTER(OmrImage), C.c_uint16, C.c_double, C.c_int32, C.c_int32, C.c_double,
                                       C.c_double, f64p, i32p, C.POINTER(OmrImageOwned)]),

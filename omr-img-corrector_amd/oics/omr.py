@@ -75,6 +75,12 @@ def edges_detection_batch_device(d_scans_ptr, n, scan_stride, rows, cols, channe
     return angles, status, nl
 
 
+def hough_set_scans_in_flight(scans):
+    """Tuning knob of edges_detection_batch_device (include/omrdeskew.h): scans the sequential Hough stage works on at
+    once; 0 = the library's default.  Returns the previous setting."""
+    return int(lib().omr_hough_set_scans_in_flight(int(scans)))
+
+
 def correct_default_decision(projection_result, edges_angle):
     """omr.rs:351-399 -> (rotate_angle, need_check)"""
     c = np.ascontiguousarray(projection_result.candidates, np.float64)

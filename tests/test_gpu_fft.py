@@ -34,6 +34,36 @@ def test_fft_pictures_match_oracle(rows, cols, seed):
     assert dmax <= PICTURE_TOL and same >= PICTURE_EQUAL_MIN, ("magnitude picture", dmax, same)
 
 
+@pytest.mark.parametrize("rows,cols,seed", [(101, 1240, 11), (1240, 70, 12), (57, 2480, 13), (2480, 93, 14), (33, 4960, 15),
+                                           (4960, 40, 16), (1240, 1240, 17)])
+def test_mixed_radix_lengths(rows, cols, seed):
+    """An A4 scan's short side (150 k dpi: 1240 k = 2^a * 5 * 31 pixels) has a mixed-radix kernel of its own (fft_mixed.hip) --
+    as the row pass (two 8-bit rows per complex line, an odd last row, a last partial group of lines) and, for a scan
+    lying on its side, as the column pass.  Same tolerance as every other length."""
+    g, _ = synth.make_card(rows, cols, seed)
+    m, lg = fft.get_fft_image(g)
+    em, elg = offt.get_fft_image(g)
+    dmax, same = close(lg, elg)
+    assert dmax <= PICTURE_TOL and same >= PICTURE_EQUAL_MIN, ("log picture", dmax, same)
+    dmax, same = close(m, em)
+    assert dmax <= PICTURE_TOL and same >= PICTURE_EQUAL_MIN, ("magnitude picture", dmax, same)
+
+
+@pytest.mark.parametrize("rows,cols,seed", [(3508, 36, 21), (37, 3508, 22), (3000, 50, 23), (26, 2052, 24), (7016, 24, 25),
+                                           (19, 5000, 26), (4104, 30, 27)])
+def test_sub_line_chirp_lengths(rows, cols, seed):
+    """An A4 scan's long side (150 k dpi: 1754 k = 2^a * 877 pixels, 877 prime) and every other length 4 P (2048 < n <=
+    4096) or 8 P (4096 < n <= 8192) is transformed as chirp-z on 4 / 8 interleaved sub-lines plus one radix-4 / radix-8
+    stage (fft_mixed.hip), as the column pass and as the row pass (odd row counts: the last row goes alone)."""
+    g, _ = synth.make_card(rows, cols, seed)
+    m, lg = fft.get_fft_image(g)
+    em, elg = offt.get_fft_image(g)
+    dmax, same = close(lg, elg)
+    assert dmax <= PICTURE_TOL and same >= PICTURE_EQUAL_MIN, ("log picture", dmax, same)
+    dmax, same = close(m, em)
+    assert dmax <= PICTURE_TOL and same >= PICTURE_EQUAL_MIN, ("magnitude picture", dmax, same)
+
+
 def test_fft_picture_properties():
     # a pure horizontal cosine: the spectrum has its DC peak and two symmetric peaks on the centre row
     rows, cols = 128, 128
@@ -61,8 +91,9 @@ def test_fft_size_limits():
 
 
 def test_long_lines_run_in_place():
-    """Lengths 4097 .. 8192 need a 16384-point chirp transform: one 128 KiB LDS buffer, radix 2 in place (round-1
-    verdict, missing item 6: the reference transforms any size, fft.rs:42-65).  Includes the 600-dpi A4 shape."""
+    """Lengths 4097 .. 8192 that are not multiples of 8 need a 16384-point chirp transform: one 128 KiB LDS buffer, radix 2
+    in place (round-1 verdict, missing item 6: the reference transforms any size, fft.rs:42-65); multiples of 8 go in
+    eight sub-lines (5000, 7016) or have a mixed-radix kernel (4960).  Includes the 600-dpi A4 shape."""
     for rows, cols, seed in ((24, 5000, 3), (4100, 40, 4), (7016, 4960, 5), (16384, 8, 6)):
         g, _ = synth.make_card(rows, cols, seed)
         m, lg = fft.get_fft_image(g)
@@ -117,7 +148,8 @@ def test_golden_picture(golden_dir):
 
 
 def test_headline_size_pictures():
-    """BASELINE config 5's scan size (4096x4096, powers of two) and the A4 scan (Bluestein on both axes)."""
+    """BASELINE config 5's scan size (4096x4096, powers of two) and the A4 scan (mixed radix along the rows, chirp-z on four
+    sub-lines along the columns: 3508 = 4 * 877)."""
     for rows, cols, seed in ((4096, 4096, 3), (3508, 2480, 2)):
         g, _ = synth.make_card(rows, cols, seed)
         _, lg = fft.get_fft_image(g)
