@@ -200,8 +200,9 @@ with open(os.path.join(dst, tag + "_fft.md"), "w") as f:
     stats_table("fft_stats", f, 8)
     for w, nm in (("c5", "4096 x 4096"), ("a4", "2480 x 3508")):
         f.write("\nMeasured HBM-side traffic, %s, 16 scans per call (FETCH_SIZE and WRITE_SIZE each in a pass of its own):\n\n" % nm)
-        hbm_table("fft_fetch_" + w, "fft_write_" + w, f, needles=("fft_pass_kernel", "spec_pictures_kernel"))
-        counter_table("fft_sq_" + w, "fft_pass_kernel", f)
+        hbm_table("fft_fetch_" + w, "fft_write_" + w, f, needles=("fft_pass_kernel", "fft_mixed_kernel", "fft_bluesub_kernel", "spec_pictures_kernel"))
+        for needle in ("fft_pass_kernel", "fft_mixed_kernel", "fft_bluesub_kernel"):
+            counter_table("fft_sq_" + w, needle, f)
 with open(os.path.join(dst, tag + "_hough.md"), "w") as f:
     f.write("# %s -- Hough-line path (BASELINE config 4)\n\n" % tag + STAMP)
     j = last_json(read("hough.log"))
@@ -229,6 +230,12 @@ with open(os.path.join(dst, tag + "_hough.md"), "w") as f:
                 "= %.0f GB/s = %.3f of 8 TB/s.\n" % (b / 1e9, fe[1] / 1e3, b / (fe[1] * 1e-6) / 1e9, b / (fe[1] * 1e-6) / 1e9 / 8000))
     except Exception as e:  # noqa: BLE001
         f.write("\n(HBM traffic not computed: %r)\n" % (e,))
+    ab = "\n".join(l for l in read("hough_ab.log").splitlines() if "amdgpu.ids" not in l and not l.startswith("{"))
+    if ab.strip():
+        f.write("\n## Accumulator width and scans in flight (`bash tools/hough_ab.sh`, ONE box, both libraries built from this commit)\n\n"
+                "`omr_hough_set_scans_in_flight(k)`: k workgroups, each takes the next scan of the batch when it has finished one "
+                "(k = batch: one workgroup per scan, the default).  Rates are whole calls of `omr_edges_detection_batch_device` "
+                "(Canny, hysteresis, point lists, HoughLinesP, votes), mean over the repetitions.\n\n```\n%s\n```\n" % ab)
 with open(os.path.join(dst, tag + "_calls.md"), "w") as f:
     f.write("# %s -- per-call latency of the host-image drivers and the host-memory batch\n\n" % tag + STAMP)
     f.write("`python3 tools/bench_calls.py`:\n\n```\n%s```\n\n`python3 tools/bench_host.py`:\n\n```\n%s```\n\n`python3 tools/bench_threads.py`:\n\n```\n%s```\n" % (

@@ -6,6 +6,7 @@
 # the program itself (python3 <script>) directly after `--`; nothing under the profiler spawns a build or a child.
 #   usage: bash tools/profile_round.sh r03 a     (bench line, sweep kernel, batch warp)
 #          bash tools/profile_round.sh r03 b     (stage kernels, FFT, Hough, per-call latencies, micro-benchmarks)
+#          bash tools/profile_round.sh r03 c     (Hough batch: int32 against 16-bit accumulator, scans in flight)
 set -eo pipefail
 TAG=${1:-r03}
 PART=${2:-a}
@@ -19,7 +20,10 @@ prof() { # prof <outdir> <counters or --stats> -- program...
 }
 SQ1="SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CU_CYCLES"
 SQ2="SQ_WAIT_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAVES"
-if [ "$PART" = "a" ]; then
+if [ "$PART" = "c" ]; then
+  # 7. Hough batch: accumulator width and scans in flight, side by side on this box (builds the 16-bit variant here)
+  bash tools/hough_ab.sh "$TAG"
+elif [ "$PART" = "a" ]; then
   # 1. the bench line exactly as the driver runs it (its own FETCH_SIZE / WRITE_SIZE / SQ child passes included)
   timeout -k 10 900 python3 bench.py > "$OUT/bench_line.json" 2> "$OUT/bench_line.err"
   rm -rf "$OUT/bench_pmc" && cp -r gpurun_out/bench_pmc "$OUT/bench_pmc" 2>/dev/null || true

@@ -7,7 +7,7 @@ cd "$(dirname "$0")/.."
 test -z "$(git status --porcelain)" || { echo "commit first: the profiles name the commit they measured"; exit 1; }
 head=$(git rev-parse HEAD)
 mkdir -p "gpurun_out/$tag"
-for part in a b; do
+for part in a b c; do
   /usr/local/graft/bin/gpurun --timeout 1200 -- "bash tools/profile_round.sh $tag $part > gpurun_out/profile_round_$part.log 2>&1; tail -3 gpurun_out/profile_round_$part.log"
 done
 echo "$head" > "gpurun_out/$tag/COMMIT"
