@@ -17,6 +17,7 @@ namespace omr {
 #define DW_TH (LINEAR ? 32 : 64)
 #define DW_LDS 16384
 
+__device__ __forceinline__ int dw_mad24(int a, int b, int c) { return __mul24(a, b) + c; }  // v_mad_i32_i24
 __device__ __forceinline__ uint8_t dw_sat_u8(int v) { return (uint8_t)(v < 0 ? 0 : v > 255 ? 255 : v); }
 
 template <bool LINEAR>
@@ -48,6 +49,8 @@ __device__ __forceinline__ int dw_tap_global(const uint8_t *__restrict__ src, in
 // memory round trips (winner -> canvas size -> table entries of the corners -> box -> taps), so everything that
 // does not depend on the box -- the thread's own column and row table entries -- is requested before the box is.
 template <bool LINEAR>
+// (forcing more waves per SIMD was measured and lost: __launch_bounds__(256, 6) spills, 127 / 126 us per 8 A4 scans
+// against 62 / 104 at the compiler's own 100 / 92 VGPRs)
 __global__ __launch_bounds__(256) void deskew_warp_kernel(const DeskewPass p)
 {
     __shared__ __attribute__((aligned(16))) uint8_t box[DW_LDS];
@@ -72,9 +75,11 @@ __global__ __launch_bounds__(256) void deskew_warp_kernel(const DeskewPass p)
     const int lx = (threadIdx.x & 31) * 4, x0 = tx0 + lx, yq = ty0 + (threadIdx.x >> 5);
     const int xl = min(x0, p.DC - 4);  // DC is a multiple of 4 and the tables are 16-byte aligned
     const int4 ad = *(const int4 *)(AD + xl), bd = *(const int4 *)(BD + xl);
+    // (rows past the tile's last one repeat it and columns past its last one repeat that column below: every sample a
+    // thread computes then lies inside the tile's box, stored or not, and a tap needs no bounds test)
     int2_t rows[DW_TH / 8];
 #pragma unroll
-    for (int k = 0; k < DW_TH / 8; k++) rows[k] = XY[min(yq + 8 * k, p.DR - 1)];
+    for (int k = 0; k < DW_TH / 8; k++) rows[k] = XY[min(yq + 8 * k, ty1)];
     // ---- the box: fixed-point source coordinates of the tile's corner samples (wave-uniform).  X0(y) and
     // adelta(x) are both monotone, so the four corners bound every sample of the tile.
     const int cx[4] = {(r0.x + rd + a0) >> 10, (r0.x + rd + a1) >> 10, (r1.x + rd + a0) >> 10, (r1.x + rd + a1) >> 10};
@@ -85,81 +90,70 @@ __global__ __launch_bounds__(256) void deskew_warp_kernel(const DeskewPass p)
     const int by1 = max(max(cy[0], cy[1]), max(cy[2], cy[3])) + 1 + (LINEAR ? 1 : 0);
     const int bb0 = bx0 & ~3, bb1 = (bx1 + 4) & ~3;  // the box in bytes of a source row, widened to whole dwords: [bb0, bb1)
     const int bwb = bb1 - bb0, bh = by1 - by0 + 1;
-    const bool staged = bwb > 0 && bh > 0 && (int64_t)bwb * bh <= DW_LDS && bx0 > -30000 && bx1 < 30000 && by0 > -30000 &&
-                        by1 < 30000;
+    // (a scan whose rows are not whole aligned dwords -- width, pitch or address not a multiple of 4 -- takes the
+    // unstaged path below: the staging loop then has no partial dwords and no branches)
+    const bool dwords = ((p.sstep | p.scan_stride | (int64_t)(uintptr_t)p.src | (int64_t)p.scols) & 3) == 0;
+    const bool staged = dwords && bwb > 0 && bh > 0 && (int64_t)bwb * bh <= DW_LDS && bx0 > -30000 && bx1 < 30000 &&
+                        by0 > -30000 && by1 < 30000;
     const uint32_t border4 = (uint32_t)p.border * 0x01010101u;
     if (staged) {
-        // the box as dwords, thread t takes dwords t, t + 256, ..: ALL loads are issued before the first LDS write
-        // (a load -> wait -> write loop pays a memory round trip per dword).  (row, dword in row) of a thread's next
-        // piece follows from the previous one without a division.
+        // the box as dwords, thread t takes dwords t, t + 256, ..: ALL loads are issued before the first LDS write, and
+        // every one of them unconditionally (a dword outside the image reads the scan's first dword and is replaced by
+        // the border value afterwards) -- a load inside a divergent branch is waited for before the next is issued, a
+        // memory round trip per dword.  (row, dword in row) of a thread's next piece follows from the previous one
+        // without a division.
         constexpr int NP = DW_LDS / 4 / 256;  // 16 pieces per thread at most
         const int bq = bwb >> 2, total = bq * bh;
-        const bool aligned = ((p.sstep | p.scan_stride | (int64_t)(uintptr_t)p.src) & 3) == 0;
         const int dq = 256 / bq, dr = 256 - dq * bq;  // 256 = dq * bq + dr
         int ly = (int)threadIdx.x / bq, lq = (int)threadIdx.x - ly * bq;
         uint32_t v[NP];
+        bool in[NP];
 #pragma unroll
         for (int n = 0; n < NP; n++) {
-            v[n] = border4;
-            if ((int)threadIdx.x + n * 256 < total) {
-                const int gy = by0 + ly, gb = bb0 + lq * 4;
-                if (aligned && (unsigned)gy < (unsigned)p.srows && gb >= 0 && gb + 4 <= p.scols) {
-                    v[n] = *(const uint32_t *)(src + (int64_t)gy * p.sstep + gb);
-                } else if ((unsigned)gy < (unsigned)p.srows && gb + 4 > 0 && gb < p.scols) {
-                    uint32_t t = 0;
-                    for (int j = 0; j < 4; j++) {
-                        const int b = gb + j;
-                        const uint32_t px = (b >= 0 && b < p.scols) ? src[(int64_t)gy * p.sstep + b] : (uint32_t)p.border;
-                        t |= px << (8 * j);
-                    }
-                    v[n] = t;
-                }
-            }
+            const int gy = by0 + ly, gb = bb0 + lq * 4;
+            in[n] = (int)threadIdx.x + n * 256 < total && (unsigned)gy < (unsigned)p.srows && (unsigned)gb < (unsigned)p.scols;
+            v[n] = *(const uint32_t *)(src + (in[n] ? (int64_t)gy * p.sstep + gb : 0));
             ly += dq, lq += dr;
             if (lq >= bq) lq -= bq, ly++;
         }
 #pragma unroll
         for (int n = 0; n < NP; n++)
-            if ((int)threadIdx.x + n * 256 < total) *(uint32_t *)&box[((int)threadIdx.x + n * 256) * 4] = v[n];
+            if ((int)threadIdx.x + n * 256 < total) *(uint32_t *)&box[((int)threadIdx.x + n * 256) * 4] = in[n] ? v[n] : border4;
     }
     __syncthreads();
     if (x0 >= dcols) return;
-    const int adv[4] = {ad.x, ad.y, ad.z, ad.w}, bdv[4] = {bd.x, bd.y, bd.z, bd.w};
-    const int org = -by0 * bwb - bb0;  // box[(sy - by0) * bwb + sx - bb0] = box[sy * bwb + sx + org]
-    auto store4 = [&](const int y, const uint32_t out) {
-        uint8_t *D = dst + (int64_t)y * p.dstep + x0;
-        if (x0 + 4 <= dcols && ((uintptr_t)D & 3) == 0) {
-            *(uint32_t *)D = out;
-        } else {
-            for (int j = 0; j < 4 && x0 + j < dcols; j++) D[j] = (uint8_t)(out >> (8 * j));
-        }
-    };
-    if (!staged) {  // workgroup-uniform: a box too large for LDS (strong shear); taps from global memory
+    int adv[4] = {ad.x, ad.y, ad.z, ad.w}, bdv[4] = {bd.x, bd.y, bd.z, bd.w};
+#pragma unroll
+    for (int j = 0; j < 4; j++) {  // (xl == x0 unless the thread starts past the tables' last four columns, and then past tx1 too)
+        const bool past = x0 + j > tx1;
+        adv[j] = past ? a1 : adv[j];
+        bdv[j] = past ? b1 : bdv[j];
+    }
+    if (!staged) {  // workgroup-uniform: a box too large for LDS (strong shear) or rows that are not whole dwords; taps from global memory
         for (int k = 0; k < DW_TH / 8; k++) {
             const int y = yq + 8 * k;
             if (y >= drows) break;
-            uint32_t out = 0;
-            for (int j = 0; j < 4; j++)
-                out |= (uint32_t)dw_tap_global<LINEAR>(src, p.sstep, p.srows, p.scols, rows[k].x + rd + adv[j],
-                                                       rows[k].y + rd + bdv[j], p.border)
-                       << (8 * j);
-            store4(y, out);
+            uint8_t *D = dst + (int64_t)y * p.dstep + x0;
+            for (int j = 0; j < 4 && x0 + j < dcols; j++)
+                D[j] = (uint8_t)dw_tap_global<LINEAR>(src, p.sstep, p.srows, p.scols, rows[k].x + rd + adv[j], rows[k].y + rd + bdv[j],
+                                                      p.border);
         }
         return;
     }
-    // straight-line: the 16 pixels' taps are all requested before the first is blended
+    // box[(sy - by0) * bwb + (sx - bb0)]: the box's origin rides on the row's X0 / Y0 (multiples of 1024: the fraction
+    // bits stay; |coordinates| < 30000 pixels, so nothing overflows).  Straight-line: the 16 / 32 pixels' taps are all requested before the first is blended,
+    // and nothing below is conditional except the last tile column's byte stores -- a row past the tile's last one
+    // recomputes that row's pixels (its table entry was clamped) and stores them there again, the same bytes.
+    const int orgx = rd - (bb0 << 10), orgy = rd - (by0 << 10);
     uint32_t outs[DW_TH / 8];
 #pragma unroll
     for (int k = 0; k < DW_TH / 8; k++) {
-        const int X0 = rows[k].x + rd, Y0 = rows[k].y + rd;
+        const int X0 = rows[k].x + orgx, Y0 = rows[k].y + orgy;
         uint32_t out = 0;
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             const int Xf = X0 + adv[j], Yf = Y0 + bdv[j];
-            // rows past the end of the canvas (clamped table entries) stay inside the box or are clamped into it:
-            // their results are never stored
-            int idx = (Yf >> 10) * bwb + (Xf >> 10) + org;
-            idx = min(max(idx, 0), DW_LDS - 2 * 1 - (LINEAR ? bwb : 0) - 1);
+            const int idx = dw_mad24(Yf >> 10, bwb, Xf >> 10);
             int v;
             if (!LINEAR) {
                 v = box[idx];
@@ -168,16 +162,24 @@ __global__ __launch_bounds__(256) void deskew_warp_kernel(const DeskewPass p)
                 // blends and a vertical one: the same integer, and <= 255 without a clamp
                 const int fx = (Xf >> 5) & 31, fy = (Yf >> 5) & 31;
                 const uint8_t *B = &box[idx];
-                const int top = B[0] * (32 - fx) + B[1] * fx, bot = B[bwb] * (32 - fx) + B[bwb + 1] * fx;
-                v = (top * (32 - fy) + bot * fy + 512) >> 10;
+                const int b0 = B[0], b1 = B[1], b2 = B[bwb], b3 = B[bwb + 1];
+                const int top = dw_mad24(fx, b1 - b0, b0 << 5), bot = dw_mad24(fx, b3 - b2, b2 << 5);
+                v = dw_mad24(fy, bot - top, (top << 5) + 512) >> 10;
             }
             out |= (uint32_t)v << (8 * j);
         }
         outs[k] = out;
     }
+    const bool whole = x0 + 4 <= dcols && ((p.dstep | p.out_stride | (int64_t)(uintptr_t)p.dst) & 3) == 0;
 #pragma unroll
-    for (int k = 0; k < DW_TH / 8; k++)
-        if (yq + 8 * k < drows) store4(yq + 8 * k, outs[k]);
+    for (int k = 0; k < DW_TH / 8; k++) {
+        uint8_t *D = dst + (int64_t)min(yq + 8 * k, ty1) * p.dstep + x0;
+        if (whole) {
+            *(uint32_t *)D = outs[k];
+        } else {
+            for (int j = 0; j < 4 && x0 + j < dcols; j++) D[j] = (uint8_t)(outs[k] >> (8 * j));
+        }
+    }
 }
 
 hipError_t launch_deskew_warp(const DeskewPass &p, int scans, int interp, hipStream_t s)
