@@ -179,7 +179,10 @@ void return_call_slot(CallSlot *c)
 
 void call_slot_stats(int dev, int *live, int *idle, size_t *idle_pinned)
 {
-    if (dev < 0 || dev >= kMaxDevices) dev = 0;
+    if (live) *live = 0;
+    if (idle) *idle = 0;
+    if (idle_pinned) *idle_pinned = 0;
+    if (dev < 0 || dev >= kMaxDevices) return;  // no pool exists for such a device (lease_call_slot refuses it)
     SlotPool &pool = slots_of(dev);
     std::lock_guard<std::mutex> lk(pool.mu);
     if (live) *live = pool.live;

@@ -215,7 +215,10 @@ const AxisTables *axis_tables(int len, hipStream_t s, int *rc)
     static std::mutex mu;
     static std::map<std::pair<int, int>, AxisTables *> *cache = new std::map<std::pair<int, int>, AxisTables *>();
     int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    if (hipError_t e = hipGetDevice(&dev); e != hipSuccess) {  // (never another device's tables)
+        *rc = fail(OMR_ERR_GPU, "hipGetDevice: %s", hipGetErrorString(e));
+        return nullptr;
+    }
     std::lock_guard<std::mutex> lock(mu);
     auto it = cache->find({dev, len});
     if (it != cache->end()) {

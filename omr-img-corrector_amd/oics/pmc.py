@@ -28,7 +28,7 @@ def rocprof():
 
 
 def short(name):
-    n = name.split("(")[0].strip()
+    n = name.replace("(anonymous namespace)::", "").split("(")[0].strip()
     return n[5:] if n.startswith("void ") else n
 
 

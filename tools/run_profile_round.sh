@@ -6,6 +6,7 @@ tag=${1:-r03}
 cd "$(dirname "$0")/.."
 test -z "$(git status --porcelain)" || { echo "commit first: the profiles name the commit they measured"; exit 1; }
 head=$(git rev-parse HEAD)
+make -C omr-img-corrector_amd/csrc all debug > /dev/null   # (tools/kstamps.py and hstamps.py load the debug library)
 mkdir -p "gpurun_out/$tag"
 for part in a b c; do
   /usr/local/graft/bin/gpurun --timeout 1200 -- "bash tools/profile_round.sh $tag $part > gpurun_out/profile_round_$part.log 2>&1; tail -3 gpurun_out/profile_round_$part.log"
