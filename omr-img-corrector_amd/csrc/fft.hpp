@@ -69,13 +69,14 @@ hipError_t launch_fft_pass(const FftPass &p, hipStream_t s);
 int fft_mixed_radices(int n, int radices[4]);
 int fft_mixed_table_size(int n);
 // ... and for lines of n = SUB * P points, 2048 < n <= 8192, whose plain chirp-z would run 8192 or 16384 points:
-// Bluestein on the SUB interleaved sub-lines (m = 2048 each) and one radix-SUB stage.  fft_bluesub_lines(): SUB (0: not
-// taken); p.sub = SUB, p.m = 2048, p.chirp / p.Bf = the chirp tables of P = n / SUB points, p.W = the twiddles of the
-// stages fft_bluesub_stages() names (laid out like a mixed-radix plan of 2048 points, fft_bluesub_stage_table_size()
-// entries) followed by G[r][k] = chirp[k] exp(-2 pi i r k / n) / 2048, r < SUB, k < P.
+// Bluestein on the SUB interleaved sub-lines (M = 1792 or 2048 points each) and one radix-SUB stage.
+// fft_bluesub_lines(): SUB (0: not taken); fft_bluesub_plan(): M and the stages of an M-point transform; p.sub = SUB,
+// p.m = M, p.chirp / p.Bf = the chirp tables of P = n / SUB points for M-point transforms, p.W = the stages' twiddles
+// (laid out like a mixed-radix plan of M points, fft_bluesub_stage_table_size(n) entries) followed by
+// G[r][k] = chirp[k] exp(-2 pi i r k / n) / M, r < SUB, k < P.
 int fft_bluesub_lines(int n);
-int fft_bluesub_stage_table_size();
-void fft_bluesub_stages(int radices[3]);
+int fft_bluesub_plan(int n, int *m, int radices[3]);
+int fft_bluesub_stage_table_size(int n);
 hipError_t launch_fft_mixed(const FftPass &p, hipStream_t s);
 
 // d_minmax: 4 ordered-uint words {min |F|, max |F|, min log, max log}; d_part: scratch for per-block

@@ -140,10 +140,15 @@ __host__ __device__ constexpr int mixed_tw_size(int R, int Ns) { return Ns == 1 
 // One Stockham stage on LINES lines of N points in place.  first_in(l, i): point i of line l of the transform's input
 // (only the first stage reads it; SYNC0: that input lives in the LDS lines themselves, so the first stage needs the
 // two barriers of every other stage).
-template <int NT, int LINES, int N, int R, int Ns, bool FIRST, bool SYNC0, class F>
+// PAD: a line is skewed by one element every 32 (index i lives at i + i / 32, lines N + N / 32 apart).  Power-of-two
+// stages need it: radix 16 with Ns = 1 stores to addresses 16 j + q -- a 128-byte lane stride, 32 lanes on one pair
+// of banks; with the skew the 64 lanes cover every bank twice.  (An odd first radix spreads its stores by itself.)
+template <bool PAD>
+__host__ __device__ __forceinline__ constexpr int lpad(int i) { return PAD ? i + (i >> 5) : i; }
+template <int NT, int LINES, int N, int R, int Ns, bool FIRST, bool SYNC0, bool PAD, class F>
 __device__ __forceinline__ void mixed_stage(cfloat *lds, const cfloat *__restrict__ tw, const int tid, F first_in)
 {
-    constexpr int NB = N / R, B = LINES * NB, BPT = (B + NT - 1) / NT;
+    constexpr int NB = N / R, B = LINES * NB, BPT = (B + NT - 1) / NT, PITCH = lpad<PAD>(N);
     constexpr bool SYNC = !FIRST || SYNC0;
     cfloat u[BPT][R];
     if (SYNC) __syncthreads();  // the previous stage's outputs are in place
@@ -153,7 +158,7 @@ __device__ __forceinline__ void mixed_stage(cfloat *lds, const cfloat *__restric
         if (B % NT == 0 || idx < B) {
             const int l = idx / NB, j = idx - l * NB;
 #pragma unroll
-            for (int q = 0; q < R; q++) u[b][q] = FIRST ? first_in(l, j + q * NB) : lds[l * N + j + q * NB];
+            for (int q = 0; q < R; q++) u[b][q] = FIRST ? first_in(l, j + q * NB) : lds[l * PITCH + lpad<PAD>(j + q * NB)];
         }
     }
     if (SYNC) __syncthreads();  // every input of this stage is in registers
@@ -178,20 +183,21 @@ __device__ __forceinline__ void mixed_stage(cfloat *lds, const cfloat *__restric
                 }
             }
             dft<R>(u[b]);
-            cfloat *o = lds + l * N + (j - k) * R + k;
+            cfloat *o = lds + l * PITCH;
+            const int o0 = (j - k) * R + k;
 #pragma unroll
-            for (int q = 0; q < R; q++) o[q * Ns] = u[b][q];
+            for (int q = 0; q < R; q++) o[lpad<PAD>(o0 + q * Ns)] = u[b][q];
         }
     }
 }
-template <int NT, int LINES, int N, int Ns, bool FIRST, bool SYNC0, int R, int... REST>
+template <int NT, int LINES, int N, int Ns, bool FIRST, bool SYNC0, bool PAD, int R, int... REST>
 struct MixedStages {
     template <class F>
     static __device__ __forceinline__ void run(cfloat *lds, const cfloat *__restrict__ tw, const int tid, F first_in)
     {
-        mixed_stage<NT, LINES, N, R, Ns, FIRST, SYNC0>(lds, tw, tid, first_in);
+        mixed_stage<NT, LINES, N, R, Ns, FIRST, SYNC0, PAD>(lds, tw, tid, first_in);
         if constexpr (sizeof...(REST) > 0)
-            MixedStages<NT, LINES, N, Ns * R, false, false, REST...>::run(lds, tw + mixed_tw_size(R, Ns), tid, first_in);
+            MixedStages<NT, LINES, N, Ns * R, false, false, PAD, REST...>::run(lds, tw + mixed_tw_size(R, Ns), tid, first_in);
     }
 };
 template <int... RS>
@@ -242,7 +248,7 @@ __device__ __forceinline__ cfloat pass_source(const FftPass &p, const int line, 
 // emit_pair; lane order: the LINES pairs of one column index are neighbours -- with the transposed output their 16-byte
 // pieces are too), else the column pass (|F(k, line)| at its own place -- the picture kernel shifts and mirrors -- and
 // the workgroup's extrema, written once per line slot: minmax_final_kernel reads one pair per line).
-template <int NT, int LINES, bool PAIRS>
+template <int NT, int LINES, bool PAIRS, bool PAD = false>
 __device__ __forceinline__ void pass_emit(const FftPass &p, const cfloat *lds, const int n, const int pitch, const int line0,
                                           const int total, const int tid, float *red)
 {
@@ -256,7 +262,7 @@ __device__ __forceinline__ void pass_emit(const FftPass &p, const cfloat *lds, c
             if (line >= total) continue;
             const int64_t r = 2 * (int64_t)line;
             const bool second = r + 1 < p.src_rows;
-            const cfloat zk = lds[l * pitch + k], zn = lds[l * pitch + (k == 0 ? 0 : n - k)];
+            const cfloat zk = lds[l * pitch + lpad<PAD>(k)], zn = lds[l * pitch + lpad<PAD>(k == 0 ? 0 : n - k)];
             const cfloat a = cfloat{(0.5f * (zk.x + zn.x)) * p.out_scale, (0.5f * (zk.y - zn.y)) * p.out_scale};
             const cfloat b = cfloat{(0.5f * (zk.y + zn.y)) * p.out_scale, (-0.5f * (zk.x - zn.x)) * p.out_scale};
             cfloat *d0 = p.dst + r * dls + (int64_t)k * des;
@@ -273,7 +279,7 @@ __device__ __forceinline__ void pass_emit(const FftPass &p, const cfloat *lds, c
             const int l = idx / n, k = idx - l * n;
             const int line = line0 + l;
             if (line >= total) continue;
-            const cfloat z = lds[l * pitch + k];
+            const cfloat z = lds[l * pitch + lpad<PAD>(k)];
             const cfloat v = cfloat{z.x * p.out_scale, z.y * p.out_scale};
             if (p.mag_dst) {
                 const float mg = sqrtf(v.x * v.x + v.y * v.y);
@@ -343,12 +349,12 @@ __global__ __launch_bounds__(NT) void fft_mixed_kernel(FftPass p)
             }
             *(uint2 *)(rows8 + (size_t)row * N + 8 * piece) = v;
         }
-        MixedStages<NT, LINES, N, 1, true, true, RS...>::run(lds, p.W, tid, [&](int l, int i) {
+        MixedStages<NT, LINES, N, 1, true, true, false, RS...>::run(lds, p.W, tid, [&](int l, int i) {
             const uint8_t *b = rows8 + (size_t)l * 2 * N + i;
             return cfloat{(float)b[0] * p.in_scale + 0.0f, (float)b[N] * p.in_scale + 0.0f};
         });
     } else {
-        MixedStages<NT, LINES, N, 1, true, false, RS...>::run(lds, p.W, tid,
+        MixedStages<NT, LINES, N, 1, true, false, false, RS...>::run(lds, p.W, tid,
                                                                [&](int l, int i) { return pass_source<PAIRS>(p, line0 + l, total, i); });
     }
     __syncthreads();
@@ -358,17 +364,29 @@ __global__ __launch_bounds__(NT) void fft_mixed_kernel(FftPass p)
 // ---- Bluestein on SUB interleaved sub-lines.  A line of n = SUB * P points whose P has no small factors (the LONG side
 // of an A4 scan: 150 k dpi gives 1754 k pixels, 1754 = 2 * 877 and 877 is prime) used to pay two transforms of
 // m >= 2 n - 1 points (8192 for n = 3508).  Decimated in time by SUB first, x_r[j] = x[SUB j + r], it pays SUB chirp-z
-// transforms of P points with m = 2048 >= 2 P - 1 -- the same number of points, but 2048 = 16 * 16 * 8 is three
-// stages instead of four, the SUB sub-lines are the LINES of the in-place stages above (64 KB of LDS for SUB = 4: two
-// workgroups per CU where the 8192-point ping-pong pair held the CU alone), and one radix-SUB stage with the twiddles
-// W_n^(r k) puts the line together: X[k + P q] = sum_r W_SUB^(r q) W_n^(r k) X_r[k].
-// Tables: p.chirp = exp(-i pi k^2 / P) (P), p.Bf = FFT_2048 of the padded conjugate chirp, p.W = the twiddles of the
-// (16, 16, 8) stages, then G[r][k] = chirp[k] W_n^(r k) / 2048 (SUB x P: the last chirp product, the inverse
-// transform's 1 / m and the combining twiddle in one factor).
-template <int NT, int SUB, bool PAIRS>
+// transforms of P points with M >= 2 P - 1 points each -- M = 1792 = 7 * 16 * 16 when that holds (P <= 896: one eighth
+// fewer points than 2048, and the odd first radix spreads its stores over the LDS banks by itself), else M = 2048 =
+// 16 * 16 * 8.  Either way three stages instead of the four of 8192 points, the SUB sub-lines are
+// the LINES of the in-place stages above (57 KB of LDS for SUB = 4, M = 1792: two workgroups per CU where the
+// 8192-point ping-pong pair held the CU alone), and one radix-SUB stage with the twiddles W_n^(r k) puts the line
+// together: X[k + P q] = sum_r W_SUB^(r q) W_n^(r k) X_r[k].
+// Tables: p.chirp = exp(-i pi k^2 / P) (P), p.Bf = FFT_M of the padded conjugate chirp, p.W = the twiddles of the
+// stages, then G[r][k] = chirp[k] W_n^(r k) / M (SUB x P: the last chirp product, the inverse transform's 1 / m and
+// the combining twiddle in one factor).
+template <int... RS>
+struct StageTable;  // twiddle entries of a plan's stages
+template <int R, int... REST>
+struct StageTable<R, REST...> {
+    static constexpr int size(int Ns = 1) { return mixed_tw_size(R, Ns) + StageTable<REST...>::size(Ns * R); }
+};
+template <>
+struct StageTable<> {
+    static constexpr int size(int = 1) { return 0; }
+};
+template <int NT, int SUB, bool PAIRS, bool PAD, int... RS>
 __global__ __launch_bounds__(NT) void fft_bluesub_kernel(FftPass p)
 {
-    constexpr int M = 2048;
+    constexpr int M = Product<RS...>::value, MP = lpad<PAD>(M);  // sub-line r at lds + r * MP
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
     cfloat *lds = (cfloat *)lds_raw;
     pass_scan_offsets(p);
@@ -378,18 +396,18 @@ __global__ __launch_bounds__(NT) void fft_bluesub_kernel(FftPass p)
     const cfloat *__restrict__ chirp = p.chirp;
     const cfloat *__restrict__ Bf = p.Bf;
     // A_r = FFT_M(x_r * chirp, zero beyond P)
-    MixedStages<NT, SUB, M, 1, true, false, 16, 16, 8>::run(lds, p.W, tid, [&](int r, int i) {
+    MixedStages<NT, SUB, M, 1, true, false, PAD, RS...>::run(lds, p.W, tid, [&](int r, int i) {
         cfloat v{0.f, 0.f};
         if (i < P) v = cmul(pass_source<PAIRS>(p, line, total, SUB * i + r), chirp[i]);
         return v;
     });
     // conj(IFFT_M(A_r Bf)) * M = FFT_M(conj(A_r Bf)): the product rides on the first stage's loads
-    MixedStages<NT, SUB, M, 1, true, true, 16, 16, 8>::run(lds, p.W, tid, [&](int r, int i) {
-        const cfloat c = cmul(lds[r * M + i], Bf[i]);
+    MixedStages<NT, SUB, M, 1, true, true, PAD, RS...>::run(lds, p.W, tid, [&](int r, int i) {
+        const cfloat c = cmul(lds[r * MP + lpad<PAD>(i)], Bf[i]);
         return cfloat{c.x, -c.y};
     });
     // X_r[k] W_n^(r k) = conj(.) G[r][k], then the radix-SUB stage; the line ends up in natural order at lds[0 .. n)
-    const cfloat *__restrict__ G = p.W + (mixed_tw_size(16, 1) + mixed_tw_size(16, 16) + mixed_tw_size(8, 256));
+    const cfloat *__restrict__ G = p.W + StageTable<RS...>::size();
     constexpr int KPT = (1024 + NT - 1) / NT;  // P <= 1024
     cfloat y[KPT][SUB];
     __syncthreads();
@@ -399,7 +417,7 @@ __global__ __launch_bounds__(NT) void fft_bluesub_kernel(FftPass p)
         if (k < P) {
 #pragma unroll
             for (int r = 0; r < SUB; r++) {
-                const cfloat v = lds[r * M + k];
+                const cfloat v = lds[r * MP + lpad<PAD>(k)];
                 y[b][r] = cmul(cfloat{v.x, -v.y}, G[r * P + k]);
             }
         }
@@ -411,11 +429,11 @@ __global__ __launch_bounds__(NT) void fft_bluesub_kernel(FftPass p)
         if (k < P) {
             dft<SUB>(y[b]);
 #pragma unroll
-            for (int q = 0; q < SUB; q++) lds[k + P * q] = y[b][q];
+            for (int q = 0; q < SUB; q++) lds[lpad<PAD>(k + P * q)] = y[b][q];
         }
     }
     __syncthreads();
-    pass_emit<NT, 1, PAIRS>(p, lds, n, n, line, total, tid, (float *)lds_raw);
+    pass_emit<NT, 1, PAIRS, PAD>(p, lds, n, 0, line, total, tid, (float *)lds_raw);
 }
 
 template <int NT, int LINES, bool PAIRS, int... RS>
@@ -432,13 +450,13 @@ hipError_t launch_one(const FftPass &p, hipStream_t s)
     return hipGetLastError();
 }
 
-template <int NT, int SUB, bool PAIRS>
+template <int NT, int SUB, bool PAIRS, bool PAD, int... RS>
 hipError_t launch_sub(const FftPass &p, hipStream_t s)
 {
-    const size_t lds = sizeof(cfloat) * (size_t)SUB * 2048;
+    const size_t lds = sizeof(cfloat) * (size_t)SUB * lpad<PAD>(Product<RS...>::value);
     const int total = PAIRS ? (p.src_rows + 1) / 2 : p.lines;
     const dim3 grid(total, p.scans > 0 ? p.scans : 1);
-    auto kern = fft_bluesub_kernel<NT, SUB, PAIRS>;
+    auto kern = fft_bluesub_kernel<NT, SUB, PAIRS, PAD, RS...>;
     hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, grid, dim3(NT), lds, s, p);
@@ -484,8 +502,24 @@ int fft_bluesub_lines(int n)
     if (n > 4096 && n <= 8192 && n % 8 == 0) return 8;
     return 0;
 }
-int fft_bluesub_stage_table_size() { return mixed_tw_size(16, 1) + mixed_tw_size(16, 16) + mixed_tw_size(8, 256); }
-void fft_bluesub_stages(int radices[3]) { radices[0] = 16, radices[1] = 16, radices[2] = 8; }
+// points per sub-line transform and its stages, first stage first (returns their number)
+int fft_bluesub_plan(int n, int *m, int radices[3])
+{
+    const int sub = fft_bluesub_lines(n);
+    if (!sub) return 0;
+    if (2 * (n / sub) - 1 <= 1792) {
+        *m = 1792, radices[0] = 7, radices[1] = 16, radices[2] = 16;
+    } else {
+        *m = 2048, radices[0] = 16, radices[1] = 16, radices[2] = 8;
+    }
+    return 3;
+}
+int fft_bluesub_stage_table_size(int n)
+{
+    int m, r[3];
+    if (!fft_bluesub_plan(n, &m, r)) return 0;
+    return m == 1792 ? StageTable<7, 16, 16>::size() : StageTable<16, 16, 8>::size();
+}
 
 hipError_t launch_fft_mixed(const FftPass &p, hipStream_t s)
 {
@@ -494,9 +528,18 @@ hipError_t launch_fft_mixed(const FftPass &p, hipStream_t s)
     const bool colpass = p.real_pairs == 0 && p.src_c != nullptr && (p.mag_dst != nullptr || p.dst != nullptr);
     if (!rowpass && !colpass) return hipErrorInvalidValue;
     if (p.sub) {
-        if (p.sub != fft_bluesub_lines(p.n) || !p.chirp || !p.Bf || !p.W || p.m != 2048) return hipErrorInvalidValue;
-        if (p.sub == 4) return rowpass ? launch_sub<512, 4, true>(p, s) : launch_sub<512, 4, false>(p, s);
-        return rowpass ? launch_sub<1024, 8, true>(p, s) : launch_sub<1024, 8, false>(p, s);
+        int m, r[3];
+        if (p.sub != fft_bluesub_lines(p.n) || !fft_bluesub_plan(p.n, &m, r) || !p.chirp || !p.Bf || !p.W || p.m != m)
+            return hipErrorInvalidValue;
+        if (m == 1792) {
+            if (p.sub == 4) return rowpass ? launch_sub<512, 4, true, false, 7, 16, 16>(p, s) : launch_sub<512, 4, false, false, 7, 16, 16>(p, s);
+            return rowpass ? launch_sub<1024, 8, true, false, 7, 16, 16>(p, s) : launch_sub<1024, 8, false, false, 7, 16, 16>(p, s);
+        }
+        // (2048 points, measured on 3508-point lines: with skewed lines the bank conflicts go from 2.0e8 to 1.1e7 cycles per
+        // launch, but the index arithmetic costs 50 VGPRs -- one workgroup per CU instead of two, the 1024-thread form
+        // spills -- and the pass takes the same 0.57 ms per 8 scans: unskewed)
+        if (p.sub == 4) return rowpass ? launch_sub<512, 4, true, false, 16, 16, 8>(p, s) : launch_sub<512, 4, false, false, 16, 16, 8>(p, s);
+        return rowpass ? launch_sub<1024, 8, true, false, 16, 16, 8>(p, s) : launch_sub<1024, 8, false, false, 16, 16, 8>(p, s);
     }
     if (p.chirp || !p.W) return hipErrorInvalidValue;
     switch (p.n) {

@@ -57,6 +57,28 @@ void fft_host(std::vector<cd> &a)  // iterative radix-2, in place, forward
     }
 }
 
+void dft_host(std::vector<cd> &a)  // forward DFT of any length: radix 2 for powers of two, else the definition (once per axis length)
+{
+    const size_t n = a.size();
+    if ((n & (n - 1)) == 0) return fft_host(a);
+    std::vector<cd> w(n), out(n);
+    for (size_t t = 0; t < n; t++) {
+        const double ang = -2.0 * kPi * (double)t / (double)n;
+        w[t] = cd(cos(ang), sin(ang));
+    }
+    for (size_t k = 0; k < n; k++) {
+        cd acc(0, 0);
+        size_t idx = 0;
+        for (size_t j = 0; j < n; j++) {
+            acc += a[j] * w[idx];
+            idx += k;
+            if (idx >= n) idx -= n;
+        }
+        out[k] = acc;
+    }
+    a.swap(out);
+}
+
 // device tables of one axis length
 struct AxisTables {
     int n = 0, m = 0, log2m = 0;
@@ -110,19 +132,18 @@ struct AxisTables {
         b->assign((size_t)mm, cd(0, 0));
         (*b)[0] = std::conj((*c)[0]);
         for (int k = 1; k < P; k++) (*b)[k] = (*b)[mm - k] = std::conj((*c)[k]);
-        fft_host(*b);
+        dft_host(*b);
     }
-    int build_sub(hipStream_t s)  // fft_mixed.hip: Bluestein on `sub` interleaved sub-lines of P = n / sub points, m = 2048
+    int build_sub(hipStream_t s)  // fft_mixed.hip: Bluestein on `sub` interleaved sub-lines of P = n / sub points, m = 1792 or 2048
     {
         const int P = n / sub;
         mixed = true;
         blue = true;
-        m = 2048;
-        log2m = 11;
+        log2m = 0;
         int r[3];
-        fft_bluesub_stages(r);
+        const int ns = fft_bluesub_plan(n, &m, r);
         std::vector<cfloat> w;
-        if (stage_twiddles(r, 3, &w) != m || (int)w.size() != fft_bluesub_stage_table_size())
+        if (!ns || stage_twiddles(r, ns, &w) != m || (int)w.size() != fft_bluesub_stage_table_size(n) || m < 2 * P - 1)
             return fail(OMR_ERR_ASSERT, "sub-line plan of length %d", n);
         std::vector<cd> c, b;
         chirp_tables(P, m, &c, &b);

@@ -50,11 +50,14 @@ def test_mixed_radix_lengths(rows, cols, seed):
 
 
 @pytest.mark.parametrize("rows,cols,seed", [(3508, 36, 21), (37, 3508, 22), (3000, 50, 23), (26, 2052, 24), (7016, 24, 25),
-                                           (19, 5000, 26), (4104, 30, 27)])
+                                           (19, 5000, 26), (4104, 30, 27),
+                                           # P = n / 4 (8) > 896: the sub-lines take 2048-point transforms instead of 1792
+                                           (4000, 30, 28), (21, 4000, 29), (8160, 16, 30)])
 def test_sub_line_chirp_lengths(rows, cols, seed):
     """An A4 scan's long side (150 k dpi: 1754 k = 2^a * 877 pixels, 877 prime) and every other length 4 P (2048 < n <=
-    4096) or 8 P (4096 < n <= 8192) is transformed as chirp-z on 4 / 8 interleaved sub-lines plus one radix-4 / radix-8
-    stage (fft_mixed.hip), as the column pass and as the row pass (odd row counts: the last row goes alone)."""
+    4096) or 8 P (4096 < n <= 8192) is transformed as chirp-z on 4 / 8 interleaved sub-lines (1792 = 7 * 16 * 16 points each
+    when 2 P - 1 fits, else 2048) plus one radix-4 / radix-8 stage (fft_mixed.hip), as the column pass and as the row pass
+    (odd row counts: the last row goes alone)."""
     g, _ = synth.make_card(rows, cols, seed)
     m, lg = fft.get_fft_image(g)
     em, elg = offt.get_fft_image(g)
