@@ -1,21 +1,28 @@
-// fft_mixed.hip -- mixed-radix line transforms of the FFT deskew path (packages/lib/src/fft.rs:42-65: the reference
-// transforms the scan at its own size) for the lengths an A4 scan's SHORT side takes: 150 k dpi gives 1240 k pixels,
-// 1240 = 2^3 * 5 * 31.  fft.hip's general answer for a length that is not a power of two is Bluestein's chirp-z -- two
-// 8192-point transforms for a 2480-point line, 86 butterfly-levels per point; here the same line is three in-place
-// Stockham stages of radix 31, 5 and 16 (about 13), the line never leaving LDS.
+// fft_mixed.hip -- line transforms of the FFT deskew path (packages/lib/src/fft.rs:42-65: the reference transforms the
+// scan at its own size) as IN-PLACE Stockham stages in LDS, for the lengths that matter most: an A4 scan's sides and
+// BASELINE config 5's 4096.
+//   * mixed radix (31, 5, 2^a) for the SHORT side of an A4 scan: 150 k dpi gives 1240 k pixels, 1240 = 2^3 * 5 * 31.
+//     fft.hip's general answer for a length that is not a power of two is Bluestein's chirp-z -- two 8192-point
+//     transforms for a 2480-point line, 86 butterfly-levels per point; here the same line is three stages of radix 31,
+//     5 and 16 (about 13), the line never leaving LDS;
+//   * chirp-z on interleaved sub-lines for the LONG side (1754 k = 2^b * 877, 877 prime) and every other 4 P / 8 P
+//     (fft_bluesub_kernel below);
+//   * 4096 points as three radix-16 stages.
 //
-// Its own translation unit and its own kernel on purpose: the code generated for fft.hip's fft_pass_kernel is
+// Its own translation unit and its own kernels on purpose: the code generated for fft.hip's fft_pass_kernel is
 // sensitive to what else is compiled into it (an odd-radix stage that was merely present slowed every power-of-two
-// transform by 15-25 %, fft.hip).  launch_fft_pass() hands a pass over to launch_fft_mixed() when fft_mixed_radices()
-// knows the length; every other length keeps the Bluestein path.
+// transform by 15-25 %, fft.hip).  oics_fft.cpp hands a pass to launch_fft_mixed() when fft_mixed_radices() or
+// fft_bluesub_lines() knows the length; every other length keeps fft.hip's paths.
 //
 // One workgroup transforms LINES lines at once so that every stage has at least one butterfly per thread (radix 31
 // has only n / 31 per line).  A stage works IN PLACE: every thread reads the inputs of its butterflies into registers,
-// the workgroup meets, the outputs go back to the Stockham positions -- half the LDS of a ping-pong pair, so four
-// workgroups share a CU.  The first stage reads the pass's input (two 8-bit rows as the real and the imaginary part,
-// copied into LDS in whole rows first, or a complex line straight from global memory) and the radix-31 stage comes
-// first (Ns = 1: no twiddles on the most expensive butterfly).  An odd butterfly uses the real symmetry of its matrix (x[k] +- x[R - k]): R = 31 costs
-// 900 fused multiply-adds, its cosines and sines are instruction literals (fft_dft_tables.hpp).
+// the workgroup meets, the outputs go back to the Stockham positions -- half the LDS of a ping-pong pair, so two to
+// four workgroups share a CU, and that occupancy is what these latency-bound passes are short of (the same 4096-point
+// line: 0.135 ms per picture as four ping-pong radix-8 stages, 0.102 here).  The first stage reads the pass's input
+// (two 8-bit rows as the real and the imaginary part, copied into LDS in whole rows first, or a complex line straight
+// from global memory); an odd radix comes first (Ns = 1: no twiddles on the most expensive butterfly).  An odd
+// butterfly uses the real symmetry of its matrix (x[k] +- x[R - k]): R = 31 costs 900 fused multiply-adds, its cosines
+// and sines are instruction literals (fft_dft_tables.hpp).
 //
 // float32 throughout like fft.hip; this file contracts (fmaf) -- the pictures' tolerance test covers it
 // (tests/test_gpu_fft.py).
@@ -472,6 +479,7 @@ int fft_mixed_radices(int n, int radices[4])
     case 1240: radices[0] = 31, radices[1] = 5, radices[2] = 8; return 3;
     case 2480: radices[0] = 31, radices[1] = 5, radices[2] = 16; return 3;
     case 4960: radices[0] = 31, radices[1] = 5, radices[2] = 4, radices[3] = 8; return 4;
+    case 4096: radices[0] = 16, radices[1] = 16, radices[2] = 16; return 3;
     default: return 0;
     }
 }
@@ -548,6 +556,10 @@ hipError_t launch_fft_mixed(const FftPass &p, hipStream_t s)
     // (128, 1) 0.1250, (96, 1) 0.1274 ms per A4 scan -- 160 radix-31 butterflies on three waves, four workgroups per CU
     case 2480: return rowpass ? launch_one<192, 2, true, 31, 5, 16>(p, s) : launch_one<192, 2, false, 31, 5, 16>(p, s);
     case 4960: return rowpass ? launch_one<192, 1, true, 31, 5, 4, 8>(p, s) : launch_one<192, 1, false, 31, 5, 4, 8>(p, s);
+    // 4096 points (BASELINE config 5's side) as three in-place radix-16 stages, two lines per 512-thread workgroup, two
+    // workgroups per CU: 0.102 ms per 4096 x 4096 picture against 0.135 for fft.hip's four ping-pong radix-8 stages
+    // ((256 threads, 1 line): 0.106), measured side by side
+    case 4096: return rowpass ? launch_one<512, 2, true, 16, 16, 16>(p, s) : launch_one<512, 2, false, 16, 16, 16>(p, s);
     default: return hipErrorInvalidValue;
     }
 }
