@@ -511,21 +511,42 @@ __global__ __launch_bounds__(256) void spec_pictures_kernel(const float *__restr
     // picture pixel (r, c) <- fft_shift (fft.rs:67-86: the quadrants swap, an odd last row / column keeps its place) <-
     // spectrum point (k, sc); points of the right half come from their mirror images (R - k, C - sc)
     const int cxh = cols / 2, cyh = rows / 2;
+    // Nearly every tile lies inside ONE quadrant and on one side of the mirror: the map (r, c) -> (k, sc) is then the
+    // same affine one for all its pixels (workgroup-uniform, decided from the tile's corners) and the loads carry no
+    // selects -- a v_cndmask costs this chip 17 cycles (profiles/r02_valu_issue.md) and the general form below has
+    // nine per pixel.  The tiles on a quadrant border, in the first column tile (c = 0 is its own mirror), on the row
+    // k = 0 of the mirrored half and on an odd last row / column take the general form.
+    const int c_hi = min(c0 + 63, cols - 1), r_hi = min(r0 + 63, rows - 1);
+    const bool mirrored = c0 >= 1 && c_hi < cxh, direct = c0 >= cxh && c_hi < 2 * cxh;
+    const bool upper = r_hi < cyh, lower = r0 > cyh && r_hi < 2 * cyh;
+    if ((mirrored || direct) && (upper || lower)) {
+        const int r = min(r0 + tx, r_hi);  // (lanes past the picture repeat its last row / column: never stored)
+        const int kq = upper ? r + cyh : r - cyh;
+        const int k = mirrored ? rows - kq : kq;                 // (kq > 0 here)
+        const int sc0 = mirrored ? cols - cxh : -cxh, scs = mirrored ? -1 : 1;  // sc = sc0 + scs * c
+        const float *base = magT + k;
 #pragma unroll
-    for (int i = 0; i < 16; i++) {
-        const int c = c0 + ty + 4 * i, r = r0 + tx;
-        float v = 0.f;
-        if (c < cols && r < rows) {
-            const bool inq = c < 2 * cxh && r < 2 * cyh;
-            int k = inq ? (r < cyh ? r + cyh : r - cyh) : r;
-            int sc = inq ? (c < cxh ? c + cxh : c - cxh) : c;
-            if (sc > cxh) {
-                sc = cols - sc;
-                k = k == 0 ? 0 : rows - k;
-            }
-            v = magT[(int64_t)sc * mag_pitch + k];
+        for (int i = 0; i < 16; i++) {
+            const int c = min(c0 + ty + 4 * i, c_hi);
+            tile[ty + 4 * i][tx] = base[(int64_t)(sc0 + scs * c) * mag_pitch];
         }
-        tile[ty + 4 * i][tx] = v;
+    } else {
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            const int c = c0 + ty + 4 * i, r = r0 + tx;
+            float v = 0.f;
+            if (c < cols && r < rows) {
+                const bool inq = c < 2 * cxh && r < 2 * cyh;
+                int k = inq ? (r < cyh ? r + cyh : r - cyh) : r;
+                int sc = inq ? (c < cxh ? c + cxh : c - cxh) : c;
+                if (sc > cxh) {
+                    sc = cols - sc;
+                    k = k == 0 ? 0 : rows - k;
+                }
+                v = magT[(int64_t)sc * mag_pitch + k];
+            }
+            tile[ty + 4 * i][tx] = v;
+        }
     }
     __syncthreads();
 #pragma unroll
