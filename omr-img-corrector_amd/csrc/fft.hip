@@ -488,6 +488,7 @@ __device__ __forceinline__ float spec_m3(float mg, float beta, float alpha)
     const float c2 = c1 * alpha + 0.0f;
     return c2 * 255.0f + 0.0f;  // fft_magnitude
 }
+// (the hardware's v_log_f32 times ln 2 in place of logf passes the pictures' tolerance too but measured no faster)
 __device__ __forceinline__ float spec_log(float m3) { return logf(m3 * 1.0f + (float)(1.0 / 255.0)); }
 
 // magT: |F| of the half spectrum, transposed (cols / 2 + 1 lines of mag_pitch floats, line = spectrum column).  A workgroup turns a tile of 64 columns x 64 rows through LDS
