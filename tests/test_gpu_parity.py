@@ -243,7 +243,11 @@ def test_headline_size_against_oracle(oracle):
     # size-independent properties
     total = (b == 0).sum()
     assert (got[0].sum(axis=1) == got[1].sum(axis=1)).all()  # both projections count the same pixels
-    assert (got[0].sum(axis=1) <= total).all()  # a rotation moves black pixels out of the canvas, never in (the border is white)
+    # (NOT an invariant, so not asserted: "a rotation never adds black pixels".  Nearest-neighbour sampling repeats a
+    # source column every 1 / (1 - cos t) pixels and a source row every 1 / |sin t|, so a candidate's count can exceed the
+    # scan's by a fraction of a per cent; what must hold is the equality of the two projections' totals above, the exact
+    # sums at angle 0 below, and bit-equality with the oracle.)
+    assert (np.abs(got[0].sum(axis=1).astype(np.int64) - int(total)) <= 0.08 * int(total)).all()  # within the canvas loss at 10 degrees
     assert (got[0][200] == (b == 0).sum(axis=0)).all() and (got[1][200] == (b == 0).sum(axis=1)).all()  # angle 0
     exp = oracle.sweep(b, 10, 0.05, threads=os.cpu_count() or 4, fast=True)
     assert_sweep_equal(got, exp, "headline size")
