@@ -506,8 +506,8 @@ struct RunWordK {
     int ca0, cb0;
 };
 template <int NLEV, int SMAX, int K>
-__device__ __forceinline__ uint32_t pair_words(const int rx, const int ry, const uint32_t tabv, const RunWordK (&wk)[RUN_K],
-                                               uint32_t (&c0)[RUN_K], uint32_t (&c1)[RUN_K], uint32_t (&c2)[RUN_K])
+__device__ __forceinline__ void pair_words(const int rx, const int ry, const uint32_t tabv, const RunWordK (&wk)[RUN_K],
+                                           uint32_t (&D)[RUN_K])
 {
     constexpr int k = K;
     constexpr uint32_t ta = k * RUN_TAB_BYTES, tb = ta + RUN_TAB_BYTES;
@@ -546,53 +546,60 @@ __device__ __forceinline__ uint32_t pair_words(const int rx, const int ry, const
     }
     Da = merge_word<NLEV, SMAX>(wa, (uint32_t)A0a >> 10, sa03, sa47, sxa);
     Db = merge_word<NLEV, SMAX>(wb, (uint32_t)A0b >> 10, sb03, sb47, sxb);
-    count_columns(c0[k], c1[k], c2[k], Da);
-    count_columns(c0[k + 1], c1[k + 1], c2[k + 1], Db);
-    return __popc(Da) + __popc(Db);
+    D[k] = Da;
+    D[k + 1] = Db;
 }
 
 // A pair's column lag bound (0, 1 or 2; wave-uniform) picks its specialisation: most words of a
 // candidate need no lag handling even when some word of the group does.
 template <int NLEV, int K>
-__device__ __forceinline__ uint32_t pair_dispatch(const int rx, const int ry, const uint32_t tabv, const RunWordK (&wk)[RUN_K],
-                                                  uint32_t (&c0)[RUN_K], uint32_t (&c1)[RUN_K], uint32_t (&c2)[RUN_K],
-                                                  const int lagbits)
+__device__ __forceinline__ void pair_dispatch(const int rx, const int ry, const uint32_t tabv, const RunWordK (&wk)[RUN_K],
+                                              uint32_t (&D)[RUN_K], const int lagbits)
 {
     // keep the pairs apart: without this fence the scheduler hoists both pairs' loads
     __builtin_amdgcn_sched_barrier(0);
     const int lag = (lagbits >> K) & 3;
-    if (lag == 0) return pair_words<NLEV, 0, K>(rx, ry, tabv, wk, c0, c1, c2);
-    if (lag == 1) return pair_words<NLEV, 1, K>(rx, ry, tabv, wk, c0, c1, c2);
-    return pair_words<NLEV, 2, K>(rx, ry, tabv, wk, c0, c1, c2);
+    if (lag == 0) return pair_words<NLEV, 0, K>(rx, ry, tabv, wk, D);
+    if (lag == 1) return pair_words<NLEV, 1, K>(rx, ry, tabv, wk, D);
+    return pair_words<NLEV, 2, K>(rx, ry, tabv, wk, D);
 }
 
 // The RUN_K words of one band for one wave.  NLEV is uniform for the whole group (maximum over its
 // words; unused levels have empty masks), so the wave dispatches once per band to a straight-line
 // specialisation.
 template <int NLEV>
-__device__ __forceinline__ uint32_t band_words(const int rx, const int ry, const uint32_t tabv, const RunWordK (&wk)[RUN_K],
-                                               uint32_t (&c0)[RUN_K], uint32_t (&c1)[RUN_K], uint32_t (&c2)[RUN_K],
-                                               const int lagbits)
+__device__ __forceinline__ void band_words(const int rx, const int ry, const uint32_t tabv, const RunWordK (&wk)[RUN_K],
+                                           uint32_t (&D)[RUN_K], const int lagbits)
 {
-    uint32_t cnt = pair_dispatch<NLEV, 0>(rx, ry, tabv, wk, c0, c1, c2, lagbits);
-    cnt += pair_dispatch<NLEV, 2>(rx, ry, tabv, wk, c0, c1, c2, lagbits);
-    return cnt;
+    pair_dispatch<NLEV, 0>(rx, ry, tabv, wk, D, lagbits);
+    pair_dispatch<NLEV, 2>(rx, ry, tabv, wk, D, lagbits);
 }
 
+// The specialisations only BUILD the band's four destination words; the column counters and the row count are
+// updated once, after the branches have met: with the counters inside them every join of the dispatch copied the
+// twelve counter registers around (ten v_mov_b64 per band).
 __device__ __forceinline__ uint32_t band_words_s(const int rx, const int ry, const uint32_t tabv, const RunWordK (&wk)[RUN_K],
                                                  uint32_t (&c0)[RUN_K], uint32_t (&c1)[RUN_K], uint32_t (&c2)[RUN_K],
                                                  const int nlev, const int lagbits)
 {
+    uint32_t D[RUN_K];
     switch (nlev) {
-    case 1: return band_words<1>(rx, ry, tabv, wk, c0, c1, c2, lagbits);
-    case 2: return band_words<2>(rx, ry, tabv, wk, c0, c1, c2, lagbits);
-    case 3: return band_words<3>(rx, ry, tabv, wk, c0, c1, c2, lagbits);
-    case 4: return band_words<4>(rx, ry, tabv, wk, c0, c1, c2, lagbits);
-    case 5: return band_words<5>(rx, ry, tabv, wk, c0, c1, c2, lagbits);
-    case 6: return band_words<6>(rx, ry, tabv, wk, c0, c1, c2, lagbits);
-    case 7: return band_words<7>(rx, ry, tabv, wk, c0, c1, c2, lagbits);
-    default: return band_words<8>(rx, ry, tabv, wk, c0, c1, c2, lagbits);
+    case 1: band_words<1>(rx, ry, tabv, wk, D, lagbits); break;
+    case 2: band_words<2>(rx, ry, tabv, wk, D, lagbits); break;
+    case 3: band_words<3>(rx, ry, tabv, wk, D, lagbits); break;
+    case 4: band_words<4>(rx, ry, tabv, wk, D, lagbits); break;
+    case 5: band_words<5>(rx, ry, tabv, wk, D, lagbits); break;
+    case 6: band_words<6>(rx, ry, tabv, wk, D, lagbits); break;
+    case 7: band_words<7>(rx, ry, tabv, wk, D, lagbits); break;
+    default: band_words<8>(rx, ry, tabv, wk, D, lagbits); break;
     }
+    uint32_t cnt = 0;
+#pragma unroll
+    for (int k = 0; k < RUN_K; k++) {
+        count_columns(c0[k], c1[k], c2[k], D[k]);
+        cnt += __popc(D[k]);
+    }
+    return cnt;
 }
 
 // bit-sliced a += b for two NP-plane numbers; a grows to NP + 1 planes
