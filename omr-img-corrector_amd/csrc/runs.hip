@@ -779,8 +779,12 @@ __global__ __launch_bounds__(RUN_BAND, 4) void runs_kernel(const RunPass p, cons
     // (an s_load spelled out: the compiler will not use the scalar unit for a pointer out of the argument struct,
     // and a vector load costs a dozen VALU operations of address arithmetic and a vmcnt wait.  The result is valid
     // after the caller's next `s_waitcnt lgkmcnt(0)`.)
-    auto geometry_issue = [&](const int gl, const int band) -> unsigned long long {
-        const uint32_t off = (uint32_t)__builtin_amdgcn_readfirstlane((((gl * NBt) + band0 + band) * RUN_WAVES + wave) * 8);
+    // The table is walked in order -- (group, band) -> the next band, or band 0 of the next group -- so its byte offset
+    // is a running SCALAR: computed from the loop counters it was a 32-bit vector multiply, a select and a
+    // v_readfirstlane per band (the compiler keeps the group counter in a VGPR).
+    uint32_t goff = (uint32_t)__builtin_amdgcn_readfirstlane((band0 * RUN_WAVES + wave) * 8);
+    const uint32_t goff_band = RUN_WAVES * 8, goff_group = (uint32_t)__builtin_amdgcn_readfirstlane((NBt - NB + 1) * RUN_WAVES * 8);
+    auto geometry_issue = [&](const uint32_t off) -> unsigned long long {
         unsigned long long q;
         asm volatile("s_load_dwordx2 %0, %1, %2" : "=&s"(q) : "s"(wgeo_a), "s"(off) : "memory");
         return q;
@@ -823,7 +827,7 @@ __global__ __launch_bounds__(RUN_BAND, 4) void runs_kernel(const RunPass p, cons
     __syncthreads();  // word-group constants are in LDS
     fetch_tables(0, 0);
     int2_t rt = load_rt(0);  // this band's rows (the next band's are loaded while this one is swept)
-    unsigned long long gq = geometry_issue(0, 0);
+    unsigned long long gq = geometry_issue(goff);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     RunGeom cur = geometry_take(gq);
     if (cur.fits) fetch_window(cur);
@@ -865,7 +869,8 @@ __global__ __launch_bounds__(RUN_BAND, 4) void runs_kernel(const RunPass p, cons
             int2_t rt_n = rt;
             if (more) {
                 const int band_n = last_band ? 0 : band + 1;
-                gq = geometry_issue(last_band ? gl + 1 : gl, band_n);
+                goff = (uint32_t)__builtin_amdgcn_readfirstlane(goff + (last_band ? goff_group : goff_band));
+                gq = geometry_issue(goff);
                 rt_n = load_rt(band_n);
             }
             const int r = band * RUN_BAND + tid;  // row within the chunk
