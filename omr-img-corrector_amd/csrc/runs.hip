@@ -488,11 +488,15 @@ __device__ __forceinline__ uint32_t merge_word(const uint2 (&d)[NLEV], const uin
 // bit-sliced add of a 1-bit value per column into a 3-plane counter: five 2-cycle ops
 __device__ __forceinline__ void count_columns(uint32_t &c0, uint32_t &c1, uint32_t &c2, const uint32_t D)
 {
-    const uint32_t t = c0 & D;
-    c0 ^= D;
-    const uint32_t u = c1 & t;
-    c1 ^= t;
-    c2 |= u;
+    // t = c0 & D; c0 ^= D; c2 |= c1 & t; c1 ^= t -- spelled out so that the counters stay IN PLACE: the compiler's form
+    // renames them and copies them back at the loop edge (four v_mov_b64 per band)
+    uint32_t t;
+    asm("v_and_b32 %3, %0, %4\n\t"
+        "v_xor_b32 %0, %0, %4\n\t"
+        "v_and_or_b32 %2, %1, %3, %2\n\t"
+        "v_xor_b32 %1, %1, %3"
+        : "+v"(c0), "+v"(c1), "+v"(c2), "=&v"(t)
+        : "v"(D));
 }
 
 // One pair of words of one band for one wave.  Both words are in flight together: both fraction
