@@ -509,16 +509,24 @@ __device__ __forceinline__ void count_columns(uint32_t &c0, uint32_t &c1, uint32
 struct RunWordK {
     int ca0, cb0;
 };
+// the row-fraction look-ups of a pair (the head of its chain of dependent LDS reads: look-up -> level masks -> merge)
+template <int K>
+__device__ __forceinline__ uint2 pair_lookup_y(const int ry, const uint32_t tabv, const RunWordK (&wk)[RUN_K])
+{
+    constexpr uint32_t ta = K * RUN_TAB_BYTES, tb = ta + RUN_TAB_BYTES;
+    const int B0a = ry + wk[K].cb0, B0b = ry + wk[K + 1].cb0;
+    return make_uint2(ldsr_u8((((uint32_t)B0a & 1023u) | tabv) + (ta + RUN_IDXY_OFS)),
+                      ldsr_u8((((uint32_t)B0b & 1023u) | tabv) + (tb + RUN_IDXY_OFS)));
+}
 template <int NLEV, int SMAX, int K>
 __device__ __forceinline__ void pair_words(const int rx, const int ry, const uint32_t tabv, const RunWordK (&wk)[RUN_K],
-                                           uint32_t (&D)[RUN_K])
+                                           uint32_t (&D)[RUN_K], const uint2 idy)
 {
     constexpr int k = K;
     constexpr uint32_t ta = k * RUN_TAB_BYTES, tb = ta + RUN_TAB_BYTES;
     const int A0a = rx + wk[k].ca0, B0a = ry + wk[k].cb0, A0b = rx + wk[k + 1].ca0, B0b = ry + wk[k + 1].cb0;
     uint32_t Da, Db;
-    const uint32_t idya = ldsr_u8((((uint32_t)B0a & 1023u) | tabv) + (ta + RUN_IDXY_OFS));
-    const uint32_t idyb = ldsr_u8((((uint32_t)B0b & 1023u) | tabv) + (tb + RUN_IDXY_OFS));
+    const uint32_t idya = idy.x, idyb = idy.y;
     uint32_t idxa = 0, idxb = 0;
     if (SMAX > 0) {
         idxa = ldsr_u8((((uint32_t)A0a & 1023u) | tabv) + (ta + RUN_IDXX_OFS));
@@ -558,14 +566,14 @@ __device__ __forceinline__ void pair_words(const int rx, const int ry, const uin
 // candidate need no lag handling even when some word of the group does.
 template <int NLEV, int K>
 __device__ __forceinline__ void pair_dispatch(const int rx, const int ry, const uint32_t tabv, const RunWordK (&wk)[RUN_K],
-                                              uint32_t (&D)[RUN_K], const int lagbits)
+                                              uint32_t (&D)[RUN_K], const int lagbits, const uint2 idy)
 {
     // keep the pairs apart: without this fence the scheduler hoists both pairs' loads
     __builtin_amdgcn_sched_barrier(0);
     const int lag = (lagbits >> K) & 3;
-    if (lag == 0) return pair_words<NLEV, 0, K>(rx, ry, tabv, wk, D);
-    if (lag == 1) return pair_words<NLEV, 1, K>(rx, ry, tabv, wk, D);
-    return pair_words<NLEV, 2, K>(rx, ry, tabv, wk, D);
+    if (lag == 0) return pair_words<NLEV, 0, K>(rx, ry, tabv, wk, D, idy);
+    if (lag == 1) return pair_words<NLEV, 1, K>(rx, ry, tabv, wk, D, idy);
+    return pair_words<NLEV, 2, K>(rx, ry, tabv, wk, D, idy);
 }
 
 // The RUN_K words of one band for one wave.  NLEV is uniform for the whole group (maximum over its
@@ -575,8 +583,11 @@ template <int NLEV>
 __device__ __forceinline__ void band_words(const int rx, const int ry, const uint32_t tabv, const RunWordK (&wk)[RUN_K],
                                            uint32_t (&D)[RUN_K], const int lagbits)
 {
-    pair_dispatch<NLEV, 0>(rx, ry, tabv, wk, D, lagbits);
-    pair_dispatch<NLEV, 2>(rx, ry, tabv, wk, D, lagbits);
+    // the second pair's look-ups travel while the first pair is merged (two registers held across it): its chain of
+    // dependent LDS reads is then one round trip shorter
+    const uint2 idy0 = pair_lookup_y<0>(ry, tabv, wk), idy2 = pair_lookup_y<2>(ry, tabv, wk);
+    pair_dispatch<NLEV, 0>(rx, ry, tabv, wk, D, lagbits, idy0);
+    pair_dispatch<NLEV, 2>(rx, ry, tabv, wk, D, lagbits, idy2);
 }
 
 // The specialisations only BUILD the band's four destination words; the column counters and the row count are
