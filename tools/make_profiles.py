@@ -153,6 +153,9 @@ with open(os.path.join(dst, tag + "_pmc_sweep.md"), "w") as f:
                 % (cyc, us, cyc / us / 1e3, nv, nv / 1024, nv / 1024 * 3.86 / cyc, nv / 1024 * 2 / cyc))
     f.write("\n## Un-profiled kernel timings\n\n`python3 tools/kbatch.py 16 8` (8 scans per launch, HIP events around the sweep stage):\n\n```\n%s```\n"
             % read("kbatch.log").replace("/opt/amdgpu/share/libdrm/amdgpu.ids: No such file or directory\n", ""))
+    if read("kbatch_groups.log"):
+        f.write("\nLarger launch groups (`python3 tools/kbatch.py 8 16` / `8 32`; the bench's default is 32 scans per launch: the "
+                "partial last wave of workgroups of a launch is amortised over more work):\n\n```\n%s```\n" % read("kbatch_groups.log"))
     f.write("\n`python3 tools/kbench.py 20` (one scan per launch, the three sweep kernels):\n\n```\n%s```\n"
             % read("kbench.log").replace("/opt/amdgpu/share/libdrm/amdgpu.ids: No such file or directory\n", ""))
     f.write("\n## Phase clocks of wave 0 (debug library, tools/kstamps.py)\n\n```\n%s```\n" % read("kstamps.log").replace("/opt/amdgpu/share/libdrm/amdgpu.ids: No such file or directory\n", ""))

@@ -35,6 +35,7 @@ elif [ "$PART" = "a" ]; then
   prof pmc_sq1 "$SQ1" -- python3 tools/kbatch.py 4 8
   prof pmc_sq2 "$SQ2" -- python3 tools/kbatch.py 4 8
   timeout -k 10 300 python3 tools/kbatch.py 16 8 > "$OUT/kbatch.log" 2>&1 || true
+  for g in 16 32; do timeout -k 10 300 python3 tools/kbatch.py 8 $g 2>&1 | grep "pass 2" >> "$OUT/kbatch_groups.log" || true; done
   timeout -k 10 300 python3 tools/kbench.py 20 > "$OUT/kbench.log" 2>&1 || true
   timeout -k 10 300 python3 tools/kstamps.py > "$OUT/kstamps.log" 2>&1 || true
   echo "[profile] sweep kernel done"
