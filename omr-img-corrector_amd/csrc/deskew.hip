@@ -45,7 +45,10 @@ __device__ __forceinline__ int dw_tap_global(const uint8_t *__restrict__ src, in
 // grid = (tiles across the largest canvas, tiles down it, scans of the launch); a tile outside its scan's canvas
 // leaves at once.  (Scans fastest instead -- XCD x warps only scan x, so overlapping boxes meet in one L2 -- halves the
 // HBM fetch, 71.8 -> 34.3 MB per 8 scans = the scans' own bytes, but is no faster: 65 / 114 us against 66 / 105.  The
-// kernel is not waiting for HBM.)  The source bounding box of a tile (four corner samples; one pixel of slack for the rounding of
+// kernel is not waiting for HBM.  Nor for its chain of round trips alone: a software-pipelined form -- a vertical strip of
+// four 128 x 32 tiles per workgroup, tile i sampled from one LDS box while the box of tile i + 1 is in flight and the
+// table entries of tile i + 2 are requested -- was built, bit-exact, and slower: 103 / 138 us at 112 / 168 VGPRs and
+// 32 KB of LDS per workgroup.)  The source bounding box of a tile (four corner samples; one pixel of slack for the rounding of
 // the fixed-point tables, one more for the bilinear taps) is staged in LDS with row-contiguous dword loads, border
 // value outside the image, so a tap is one LDS byte read with no bounds test.  The kernel is a chain of dependent
 // memory round trips (winner -> canvas size -> table entries of the corners -> box -> taps), so everything that
