@@ -196,9 +196,22 @@ int omr_batch_deskew_device(omr_batch_ctx *ctx, const uint8_t *d_scans, int64_t 
  * slots that exist, slots idle in the pool, pinned bytes held by idle slots.  Pointers may be NULL. */
 int omr_call_pool_stats(int32_t device, int32_t *live_slots, int32_t *idle_slots, int64_t *idle_pinned_bytes);
 
+/* ---- scan-lane sweep (batches) ------------------------------------ */
+/* The batch path sweeps 64 scans per wavefront (lane = scan): the geometry of a candidate -- which source row,
+ * word column, shift and destination bits make up every destination word (projection.rs:47-65 ->
+ * transfer.rs:459-486) -- is one wave-uniform PROGRAM per (candidate, strip of two word columns), enumerated
+ * from warpAffine's integer tables.  This entry point builds one strip's program on the HOST (no GPU needed):
+ * n_records rows (pre_rows virtual ones first) of seg_dwords_per_row dwords in the segment stream and of 4 dwords
+ * in the fetch stream (layout: csrc/slane.hpp).  NULL output pointers query the sizes.
+ * OMR_ERR_NOTIMPL when the strip does not fit the scheme (such candidates stay with the run-merging kernel). */
+int omr_slane_strip_program(int32_t rows, int32_t cols, const double *fwd_M, int32_t strip, uint32_t *seg_out,
+                            uint32_t *fetch_out, int32_t *seg_dwords_per_row, int32_t *n_records, int32_t *pre_rows,
+                            int32_t *most_segments);
+
 /* Host-buffer batch over the visible devices (SURVEY.md 8b `omr_sweep_batch`): scans[i] goes
  * to device i % n_devices (pinned staging ring, copy / sweep overlapped, four scans per launch);
- * the only "collective" is the host-side gather of the results.
+ * the only "collective" is the host-side gather of the results.  n_devices <= 0 = every visible device;
+ * n_devices > omr_device_count() is OMR_ERR_BADARG (never a silent clamp).
  * best_angle[i] = (best_idx[i] - N) * step (projection.rs:189-190). */
 int omr_sweep_batch(const omr_image *scans, int32_t n, uint16_t max_angle, double step,
                     int32_t n_devices, int32_t *best_idx, double *best_angle, double *v_sd_opt,

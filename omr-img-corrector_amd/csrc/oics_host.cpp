@@ -795,7 +795,10 @@ int omr_sweep_batch(const omr_image *scans, int32_t n, uint16_t max_angle, doubl
     if (n == 0) return OMR_OK;
     int ndev = omr_device_count();
     if (ndev <= 0) return fail(OMR_ERR_GPU, "no usable HIP device (there is no CPU fallback)");
-    if (n_devices <= 0 || n_devices > ndev) n_devices = ndev;
+    // 0 (or less) = every visible device; more than are visible is an error, not a silent clamp: a caller that
+    // asked for 8 devices must not believe it ran on 8
+    if (n_devices > ndev) return fail(OMR_ERR_BADARG, "n_devices exceeds omr_device_count()");
+    if (n_devices <= 0) n_devices = ndev;
     int N, A = candidate_count(max_angle, step, &N);
     if (A <= 0) return fail(OMR_ERR_BADARG, "empty candidate range");
     const int rows = scans[0].rows, cols = scans[0].cols;

@@ -1,0 +1,62 @@
+/* slane_interp.c -- TEST INFRASTRUCTURE ONLY (see oracle.h): a CPU interpreter of the scan-lane sweep's programs
+ * (omr-img-corrector_amd/csrc/slane.hpp).  It executes one strip's program exactly as a wave does -- the 65-register
+ * ring, fetches committed one row late, (mask, pk) segments over register pairs -- for `lanes` scans held in the
+ * interleaved bit image, and returns the strip's contribution to both projections.  tests/ compare that with the
+ * oracle's own sweep (oracle.c, projection.rs:47-65): it pins the PROGRAM FORMAT and the generator on the CPU,
+ * before any GPU is involved.  Nothing here is shipped or measured. */
+#include <stdint.h>
+#include <string.h>
+
+#define SL_FETCH 4
+#define SL_RING 65
+
+/* seg: n_records rows of seg_dwords dwords (K words x S x (mask, pk)); fet: n_records rows of 4 fetch dwords
+ * (E << 8 | ring register); bits: entries[E][lanes] dwords (entry 0 all zero);
+ * hrow[r * lanes + lane] += black pixels of row r in this strip (r = record - pre_rows, 0 <= r < rows);
+ * vcol[(k * 32 + bit) * lanes + lane] += black pixels of column bit of the strip's word k.
+ * Returns 0, or -1 when a fetch / register index is out of range or a virtual row carries bits. */
+int orc_slane_run_strip(const uint32_t *seg, int seg_dwords, const uint32_t *fet, int n_records, int pre_rows, int rows,
+                        int K, const uint32_t *bits, int64_t n_entries, int lanes, uint32_t *hrow, uint32_t *vcol)
+{
+    const int S = seg_dwords / (2 * K);
+    uint32_t ring[SL_RING][64], T[SL_FETCH][64];
+    uint32_t pend[SL_FETCH];
+    if (lanes > 64) return -1;
+    memset(ring, 0, sizeof ring);
+    memset(T, 0, sizeof T);
+    for (int f = 0; f < SL_FETCH; f++) pend[f] = 64u;
+    for (int q = 0; q < n_records; q++) {
+        const uint32_t *rec = fet + (int64_t)q * SL_FETCH;
+        /* commit what the previous record fetched, then issue this record's fetches */
+        for (int f = 0; f < SL_FETCH; f++) {
+            const uint32_t reg = pend[f] & 255u;
+            if (reg >= SL_RING) return -1;
+            memcpy(ring[reg], T[f], sizeof(uint32_t) * (size_t)lanes);
+        }
+        for (int f = 0; f < SL_FETCH; f++) {
+            const int64_t e = rec[f] >> 8;
+            if (e >= n_entries) return -1;
+            memcpy(T[f], bits + e * lanes, sizeof(uint32_t) * (size_t)lanes);
+            pend[f] = rec[f];
+        }
+        for (int k = 0; k < K; k++) {
+            const uint32_t *w = seg + (int64_t)q * seg_dwords + k * 2 * S;
+            const int n = (int)((w[1] >> 16) & 31u);
+            if (n > S) return -1;
+            for (int lane = 0; lane < lanes; lane++) {
+                uint32_t D = 0;
+                for (int j = 0; j < n; j++) {
+                    const uint32_t mask = w[2 * j], pk = w[2 * j + 1];
+                    const uint32_t idx = pk & 255u, sh = (pk >> 8) & 31u;
+                    if (idx + 1 >= SL_RING) return -1;
+                    const uint64_t pair = ((uint64_t)ring[idx + 1][lane] << 32) | ring[idx][lane];
+                    D |= (uint32_t)(pair >> sh) & mask;
+                }
+                if (q >= pre_rows && q - pre_rows < rows) hrow[(int64_t)(q - pre_rows) * lanes + lane] += (uint32_t)__builtin_popcount(D);
+                else if (D) return -1; /* virtual rows carry no bits */
+                for (int b = 0; b < 32; b++) vcol[(int64_t)(k * 32 + b) * lanes + lane] += (D >> b) & 1u;
+            }
+        }
+    }
+    return 0;
+}

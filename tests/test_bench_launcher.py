@@ -31,6 +31,22 @@ def test_gpus2_spawns_two_ranks_and_gathers():
     assert "spawned 2 rank processes" in rec["launcher"]
 
 
+def test_gpus8_dry_run_gathers_4096_results_in_order():
+    """BASELINE config 3 (4096 scans over 8 GPUs) as a launch rehearsal: 8 gloo ranks of 512 scans each, results
+    gathered in scan order (the dry run itself raises when the order is wrong on any rank).  Round-3 verdict item 7:
+    the only form of the 8-GPU launch that can be shown without the hardware."""
+    p = subprocess.run([sys.executable, BENCH, "--gpus", "8", "--dry-run", "--scans", "512"],
+                       env=_env(), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    lines = [ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 8 and rec["dry_run"] is True
+    assert rec["shard_sizes"] == [512] * 8 and rec["gathered_results"] == 4096
+    assert rec["config"]["global_batch"] == 4096 and rec["scaling"] == "weak"
+    assert "spawned 8 rank processes" in rec["launcher"]
+
+
 def test_world_size_mismatch_is_an_error():
     # a torchrun-like environment that disagrees with --gpus: must exit non-zero, not run single-rank
     p = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--dry-run"], env=_env(WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"),

@@ -323,6 +323,26 @@ def test_device_argmax_tie_policy(oracle):
         assert int(out.item()) == lowest, (trial, n)
 
 
+def test_c2_as_baseline_words_it_401_inclusive_candidates(oracle):
+    """BASELINE.json config 2 says "401 candidate angles" (-10 .. +10 inclusive); the reference's range is half-open
+    (projection.rs:36-38: 400).  The inclusive set goes through omr_sweep_plan_create (arbitrary matrices): all 401 are
+    run-merged and equal the oracle bit for bit; the first 400 are the half-open sweep's matrices (round-3 verdict
+    item 7 / weak 9)."""
+    b, theta = synth.make_binary_card(3508, 2480, 5)
+    M400 = oracle.rotation_matrices(3508, 2480, 10, 0.05)
+    last = oracle.get_rotation_matrix_2d(float(np.float32(2480) / np.float32(2.0)), float(np.float32(3508) / np.float32(2.0)), 10.0, 1.0)
+    Ms = np.concatenate([M400, np.asarray(last, np.float64).reshape(1, 6)])
+    assert Ms.shape == (401, 6)
+    plan = projection.SweepPlan(3508, 2480, matrices=Ms)
+    assert plan.info() == (401, 0)
+    got = plan.run(b)
+    plan.close()
+    exp = oracle.sweep_matrices(b, Ms, threads=os.cpu_count() or 4, fast=True)
+    assert_sweep_equal(got, exp, "401 inclusive candidates")
+    assert got[4] == oracle.argmax_path1(exp[2], exp[3])[0]
+    assert abs((got[4] - 200) * 0.05 - theta) < 0.5
+
+
 def test_run_merging_kernel_covers_the_headline_sweep():
     # every candidate of +-10 deg @ 0.05 deg on an A4 scan must qualify for the run-merging kernel
     plan = projection.SweepPlan(3508, 2480, 10, 0.05)
