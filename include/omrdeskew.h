@@ -208,6 +208,17 @@ int omr_slane_strip_program(int32_t rows, int32_t cols, const double *fwd_M, int
                             uint32_t *fetch_out, int32_t *seg_dwords_per_row, int32_t *n_records, int32_t *pre_rows,
                             int32_t *most_segments);
 
+/* Switch a batch context to the scan-lane sweep: every launch then carries up to max_scans_per_launch scans (whole
+ * groups of 64, at most 4096), 64 scans per wavefront; results are bit-identical to the run-merging path.  The
+ * programs of all (candidate, strip) pairs are generated on the host's cores and uploaded once (about 7 GB of HBM for
+ * 2480x3508 with 400 candidates).  0 switches back.  OMR_ERR_NOTIMPL, context unchanged, when a candidate does not
+ * fit the scheme (beyond about +-10 degrees at unit scale, or more than 4078 rows). */
+int omr_batch_set_lanes(omr_batch_ctx *ctx, int32_t max_scans_per_launch);
+/* The integer projections one scan / candidate of the last scan-lane launch left in scratch set `set` (0 for the
+ * first launch of a stream): vproj = cols counts, hproj = rows counts; either may be NULL.  Synchronises. */
+int omr_batch_lanes_projections(omr_batch_ctx *ctx, int32_t set, int32_t scan, int32_t a, uint32_t *vproj,
+                                uint32_t *hproj);
+
 /* Host-buffer batch over the visible devices (SURVEY.md 8b `omr_sweep_batch`): scans[i] goes
  * to device i % n_devices (pinned staging ring, copy / sweep overlapped, four scans per launch);
  * the only "collective" is the host-side gather of the results.  n_devices <= 0 = every visible device;

@@ -1043,8 +1043,9 @@ int batch_run(omr_batch_ctx *ctx, const uint8_t *d_scans, int64_t scan_stride, i
 {
     const int S = (int)ctx->streams.size();
     const int A = ctx->tables.dims.A;
+    const bool lanes = ctx->lanes > 0;  // scan-lane sweep: 64 scans per wavefront, up to ctx->lanes scans per launch
     for (int i = 0, launch = 0; i < n; launch++) {
-        const int z = std::min(ctx->group, n - i);  // scans of this launch
+        const int z = std::min(lanes ? ctx->lanes : ctx->group, n - i);  // scans of this launch
         const int k = launch % S;
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (ctx->timing) {
@@ -1063,8 +1064,16 @@ int batch_run(omr_batch_ctx *ctx, const uint8_t *d_scans, int64_t scan_stride, i
         // this scratch set's previous std-dev / arg-max (/ warp) must have read its projections (/ best indices)
         if (ctx->post_pending[set]) OMR_HIP(hipStreamWaitEvent(ctx->streams[k], ctx->ev_post[set], 0));
         // the warp reads the winners on the device: the caller's array, or the scratch set's
-        int32_t *best = d_best_idx ? d_best_idx + i : (dk ? ctx->scratch[set]->best.as<int32_t>() : nullptr);
-        int rc = enqueue_sweep(ctx->tables, *ctx->scratch[set], KERNEL_AUTO, d_scans + (size_t)i * scan_stride,
+        int32_t *best = d_best_idx ? d_best_idx + i
+                                   : (dk ? (lanes ? ctx->slane_scratch[set]->best.as<int32_t>() : ctx->scratch[set]->best.as<int32_t>())
+                                         : nullptr);
+        int rc;
+        if (lanes)
+            rc = slane_enqueue(ctx->slane, *ctx->slane_scratch[set], d_scans + (size_t)i * scan_stride, scan_stride, step_bytes, z,
+                               black_max, ctx->streams[k], ctx->post_streams[k], ctx->ev_mid[set],
+                               d_v_sd ? d_v_sd + (size_t)i * A : nullptr, d_h_sd ? d_h_sd + (size_t)i * A : nullptr, best, e0, e1);
+        else
+            rc = enqueue_sweep(ctx->tables, *ctx->scratch[set], KERNEL_AUTO, d_scans + (size_t)i * scan_stride,
                                step_bytes, black_max, ctx->streams[k], nullptr, nullptr,
                                d_v_sd ? d_v_sd + (size_t)i * A : nullptr, d_h_sd ? d_h_sd + (size_t)i * A : nullptr, best, e0,
                                e1, false, ctx->post_streams[k], ctx->ev_mid[set], z, scan_stride);
@@ -1164,6 +1173,61 @@ int omr_batch_set_group(omr_batch_ctx *ctx, int32_t scans_per_launch)
         sc = std::move(fresh);
     }
     ctx->group = scans_per_launch;
+    return OMR_OK;
+}
+
+// Scan-lane sweep for this context: up to max_scans_per_launch scans per launch (rounded up to whole groups of 64),
+// 64 scans per wavefront.  Builds every strip's program on the host's cores and uploads them (once); 0 switches back
+// to the run-merging path.  OMR_ERR_NOTIMPL (and the context unchanged) when a candidate does not fit the scheme.
+int omr_batch_set_lanes(omr_batch_ctx *ctx, int32_t max_scans_per_launch)
+{
+    NoPoolScope plan_owned;
+    if (!ctx || max_scans_per_launch < 0 || max_scans_per_launch > 64 * 64) return fail(OMR_ERR_BADARG, "scans per launch must be 0..4096");
+    int rc = omr_batch_sync(ctx);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    OMR_HIP(hipSetDevice(ctx->tables.device));
+    if (max_scans_per_launch == 0) {
+        ctx->lanes = 0;
+        ctx->slane_scratch.clear();
+        return OMR_OK;
+    }
+    if (!ctx->slane.built && (rc = ctx->slane.build(ctx->tables))) return rc;
+    const int groups = (max_scans_per_launch + SL_LANES - 1) / SL_LANES;
+    ctx->slane_scratch.clear();
+    for (size_t i = 0; i < ctx->scratch.size(); i++) {
+        std::unique_ptr<SlaneScratch> sc(new SlaneScratch);
+        if ((rc = sc->create(ctx->slane, groups))) {
+            ctx->slane_scratch.clear();
+            ctx->lanes = 0;
+            return rc;
+        }
+        ctx->slane_scratch.push_back(std::move(sc));
+    }
+    ctx->lanes = groups * SL_LANES;
+    return OMR_OK;
+}
+
+// Integer projections of one scan and candidate as the LAST scan-lane launch of scratch set `set` left them (for
+// tests and inspection): vproj cols u32, hproj rows u32.  Synchronises the context.
+int omr_batch_lanes_projections(omr_batch_ctx *ctx, int32_t set, int32_t scan, int32_t a, uint32_t *vproj, uint32_t *hproj)
+{
+    if (!ctx || ctx->lanes <= 0) return fail(OMR_ERR_BADARG, "the context is not in scan-lane mode");
+    int rc = omr_batch_sync(ctx);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    OMR_HIP(hipSetDevice(ctx->tables.device));
+    if (set < 0 || set >= (int)ctx->slane_scratch.size() || scan < 0 || scan >= ctx->lanes || a < 0 || a >= ctx->slane.A)
+        return fail(OMR_ERR_BADARG, "set / scan / candidate out of range");
+    const SlaneScratch &s = *ctx->slane_scratch[(size_t)set];
+    const SlanePlan &p = ctx->slane;
+    const size_t nscp = (size_t)s.nsg * SL_LANES;
+    if (vproj)
+        OMR_HIP(hipMemcpy2D(vproj, 4, s.vproj.as<uint32_t>() + (size_t)a * p.g.cols * nscp + scan, nscp * 4, 4, (size_t)p.g.cols,
+                            hipMemcpyDeviceToHost));
+    if (hproj)
+        OMR_HIP(hipMemcpy2D(hproj, 4, s.hrows.as<uint32_t>() + ((size_t)a * p.nrec + SL_PRE) * nscp + scan, nscp * 4, 4,
+                            (size_t)p.g.rows, hipMemcpyDeviceToHost));
     return OMR_OK;
 }
 

@@ -9,6 +9,7 @@
 #include <vector>
 
 #include "kernels.hpp"
+#include "slane.hpp"
 
 namespace omr {
 
@@ -144,6 +145,26 @@ int enqueue_sweep(const SweepTables &t, SweepScratch &s, int kernel_sel, const u
                   double *d_h_sd, int32_t *d_best, hipEvent_t ev0, hipEvent_t ev1, bool want_proj = false,
                   hipStream_t post_stream = nullptr, hipEvent_t ev_mid = nullptr, int scans = 1, int64_t img_stride = 0);
 
+// ---- scan-lane sweep (slane.hpp): lane = scan, for batches of same-shape scans
+struct SlanePlan {
+    SlaneGeom g;
+    int A = 0, nrec = 0;
+    bool built = false;
+    int64_t prog_dwords = 0;
+    DevBuf prog, d_tasks;
+    std::vector<SlaneStrip> strips;  // [A][NS]
+    std::vector<int32_t> tasks;      // candidate * NS + strip, in launch order
+    int build(const SweepTables &t);  // OMR_ERR_NOTIMPL when a candidate does not fit the scheme
+};
+struct SlaneScratch {
+    int nsg = 0;  // scan groups of 64 scans a launch may carry
+    DevBuf bits, hrows, vproj, planes, descs, vsd, hsd, best;
+    int create(const SlanePlan &p, int groups);
+};
+int slane_enqueue(const SlanePlan &p, SlaneScratch &s, const uint8_t *d_img, int64_t scan_stride, int64_t step, int nscans,
+                  int black_max, hipStream_t stream, hipStream_t post_stream, hipEvent_t ev_mid, double *d_v_sd, double *d_h_sd,
+                  int32_t *d_best, hipEvent_t ev0, hipEvent_t ev1);
+
 }  // namespace omr
 
 struct omr_sweep_plan {
@@ -173,6 +194,10 @@ struct omr_batch_ctx {
     size_t events_used = 0;
     bool timing = false;
     int group = 1;  // scans per kernel launch (omr_batch_set_group)
+    // scan-lane sweep (omr_batch_set_lanes): 64 scans per wavefront, up to `lanes` scans per launch
+    int lanes = 0;
+    omr::SlanePlan slane;
+    std::vector<std::unique_ptr<omr::SlaneScratch>> slane_scratch;  // [2 * n_streams]
     // final deskew (omr_batch_deskew_device): per candidate the CONTAIN canvas and warpAffine's fixed-point tables
     bool dk_built = false;
     int dk_rows = 0, dk_cols = 0;  // largest canvas (cols rounded up to 4)

@@ -79,4 +79,29 @@ int slane_strip_segments(const SlaneGeom &g, const int32_t *ad, const int32_t *b
 bool slane_strip_program(const SlaneGeom &g, const int32_t *ad, const int32_t *bd, const int32_t *x0, const int32_t *y0,
                          int strip, int cls, uint32_t *seg, uint32_t *fet);
 
+// What a wave of slane_kernel starts from (64 bytes, read by scalar loads; tools/gen_slane_asm.py fixes the layout)
+struct SlaneTask {
+    uint64_t seg, fet;   // the strip's segment / fetch stream
+    uint64_t hrow;       // row counts of (candidate, scan group): u32 [record][scan], record 0 = first virtual row
+    uint64_t planes;     // counter dump of (task, scan group): [word][18][64]
+    uint32_t rsrc[4];    // buffer descriptor of the scan group's interleaved bit image
+    uint32_t nrec;       // records (even)
+    uint32_t hpitch;     // bytes between rows of hrow
+    int32_t cls;         // 0 / 1 / 2 = 2 / 4 / 8 slots per word
+    int32_t pad;
+};
+static_assert(sizeof(SlaneTask) == 64, "SlaneTask layout (slane_asm.inc loads it by offset)");
+
+}  // namespace omr
+
+#include <hip/hip_runtime_api.h>
+namespace omr {
+hipError_t launch_slane_pack(const uint8_t *d_img, int64_t scan_stride, int64_t step, const SlaneGeom &g, int nscans,
+                             int black_max, uint32_t *d_bits, hipStream_t s);
+// nsg_used = scan groups that carry scans in this launch, nsg = scan groups the scratch (and its descriptors) is laid out for
+hipError_t launch_slane(const SlaneTask *d_descs, int nsg_used, int nsg, int ntasks, hipStream_t s);
+hipError_t launch_slane_vproj(const uint32_t *d_planes, const int32_t *d_tasks, int ntasks, int nsg_used, int nsg, int NS,
+                              int cols, int nrec, uint32_t *d_vproj, hipStream_t s);
+hipError_t launch_slane_stddev(const uint32_t *d_vproj, const uint32_t *d_hproj, int A, int cols, int rows, int hrows_per_cand,
+                               int hrow0, int nsg_used, int nsg, int nscans, double *d_v_sd, double *d_h_sd, hipStream_t s);
 }  // namespace omr

@@ -1,0 +1,155 @@
+// slane_engine.cpp -- host side of the scan-lane sweep: the plan (every strip's program, generated on the host's
+// cores and uploaded once), the per-launch scratch and the enqueue (slane.hpp).
+#include <algorithm>
+#include <atomic>
+#include <thread>
+
+#include "../../include/omrdeskew.h"
+#include "engine.hpp"
+#include "slane.hpp"
+
+namespace omr {
+
+static int host_threads()
+{
+    const unsigned hw = std::thread::hardware_concurrency();
+    return (int)std::max(1u, std::min(hw ? hw : 4u, 16u));
+}
+
+int SlanePlan::build(const SweepTables &t)
+{
+    const SweepDims &d = t.dims;
+    if (d.rows + SL_PRE + 1 >= 4096) return fail(OMR_ERR_NOTIMPL, "scan-lane sweep: more than 4078 rows (12 counter planes)");
+    g.set(d.rows, d.cols);
+    A = d.A;
+    nrec = slane_records(d.rows);
+    const int NS = g.NS, T = host_threads();
+    strips.assign((size_t)A * NS, SlaneStrip{0, 0, -1, 0});
+    // ---- pass 1: the class of every strip (most segments per word), candidates dealt to the host's threads
+    std::atomic<int> next{0};
+    std::atomic<int> bad{0};
+    auto pass = [&](bool emit, uint32_t *host_prog) {
+        next = 0;
+        std::vector<std::thread> pool;
+        for (int th = 0; th < T; th++)
+            pool.emplace_back([&, emit, host_prog]() {
+                std::vector<int32_t> ad, bd, x0, y0;
+                for (;;) {
+                    const int a = next.fetch_add(1);
+                    if (a >= A || bad.load()) return;
+                    slane_host_tables(&t.host_minv[6 * (size_t)a], d.rows, d.cols, ad, bd, x0, y0);
+                    for (int st = 0; st < NS; st++) {
+                        SlaneStrip &S = strips[(size_t)a * NS + st];
+                        if (!emit) {
+                            S.nseg = slane_strip_segments(g, ad.data(), bd.data(), x0.data(), y0.data(), st);
+                            S.cls = S.nseg < 0 ? -1 : slane_class(S.nseg);
+                            if (S.cls < 0) bad = 1;
+                        } else if (!slane_strip_program(g, ad.data(), bd.data(), x0.data(), y0.data(), st, S.cls,
+                                                        host_prog + S.seg_offset, host_prog + S.fet_offset)) {
+                            bad = 1;
+                        }
+                    }
+                }
+            });
+        for (auto &th : pool) th.join();
+    };
+    pass(false, nullptr);
+    if (bad.load()) return fail(OMR_ERR_NOTIMPL, "a candidate does not fit the scan-lane scheme (more than 8 segments per word or 4 word columns per source row)");
+    int64_t off = 0;
+    for (auto &S : strips) {
+        S.seg_offset = off;
+        off += ((int64_t)nrec * slane_seg_dwords(S.cls) + 63) & ~63ll;
+        S.fet_offset = off;
+        off += ((int64_t)nrec * SL_FETCH + 63) & ~63ll;
+    }
+    prog_dwords = off + 256;  // the kernel reads up to two records past a strip's last one
+    std::vector<uint32_t> host((size_t)prog_dwords, 0u);
+    pass(true, host.data());
+    if (bad.load()) return fail(OMR_ERR_NOTIMPL, "a strip's ring schedule does not fit (16 source rows x 4 word columns)");
+    OMR_HIP(prog.alloc(sizeof(uint32_t) * (size_t)prog_dwords));
+    OMR_HIP(hipMemcpy(prog.p, host.data(), sizeof(uint32_t) * (size_t)prog_dwords, hipMemcpyHostToDevice));
+    // ---- tasks: heaviest class first, then strip-major with the candidate fastest (a workgroup's four waves sweep
+    // adjacent candidates of one strip: the same source window)
+    tasks.clear();
+    for (int c = 2; c >= 0; c--)
+        for (int st = 0; st < NS; st++)
+            for (int a = 0; a < A; a++)
+                if (strips[(size_t)a * NS + st].cls == c) tasks.push_back(a * NS + st);
+    OMR_HIP(d_tasks.alloc(sizeof(int32_t) * tasks.size()));
+    OMR_HIP(hipMemcpy(d_tasks.p, tasks.data(), sizeof(int32_t) * tasks.size(), hipMemcpyHostToDevice));
+    built = true;
+    return OMR_OK;
+}
+
+int SlaneScratch::create(const SlanePlan &p, int groups)
+{
+    if (groups < 1 || groups > 64) return fail(OMR_ERR_BADARG, "1..64 scan groups per launch");
+    nsg = groups;
+    const SlaneGeom &g = p.g;
+    const size_t nscp = (size_t)nsg * SL_LANES, ntasks = p.tasks.size();
+    const size_t bits_b = sizeof(uint32_t) * (size_t)nsg * g.entries * SL_LANES;
+    OMR_HIP(bits.alloc(bits_b));
+    OMR_HIP(hipMemset(bits.p, 0, bits_b));  // entry 0 and the guard columns stay zero for good
+    OMR_HIP(hrows.alloc(sizeof(uint32_t) * (size_t)p.A * p.nrec * nscp));
+    OMR_HIP(vproj.alloc(sizeof(uint32_t) * (size_t)p.A * g.cols * nscp));
+    OMR_HIP(planes.alloc(sizeof(uint32_t) * ntasks * nsg * SL_K * 18 * SL_LANES));
+    OMR_HIP(vsd.alloc(sizeof(double) * nscp * p.A));
+    OMR_HIP(hsd.alloc(sizeof(double) * nscp * p.A));
+    OMR_HIP(best.alloc(sizeof(int32_t) * nscp));
+    // ---- one 64-byte descriptor per (task, scan group)
+    std::vector<SlaneTask> h(ntasks * (size_t)nsg);
+    const uint64_t prog0 = (uint64_t)p.prog.p;
+    for (size_t ti = 0; ti < ntasks; ti++) {
+        const int task = p.tasks[ti], a = task / g.NS;
+        const SlaneStrip &S = p.strips[(size_t)task];
+        for (int sg = 0; sg < nsg; sg++) {
+            SlaneTask &k = h[ti * nsg + sg];
+            k.seg = prog0 + 4ull * (uint64_t)S.seg_offset;
+            k.fet = prog0 + 4ull * (uint64_t)S.fet_offset;
+            k.hrow = (uint64_t)hrows.p + 4ull * ((uint64_t)a * p.nrec * nscp + (uint64_t)sg * SL_LANES);
+            k.planes = (uint64_t)planes.p + 4ull * ((ti * nsg + sg) * SL_K * 18 * SL_LANES);
+            const uint64_t base = (uint64_t)bits.p + 4ull * (uint64_t)sg * g.entries * SL_LANES;
+            k.rsrc[0] = (uint32_t)base;
+            k.rsrc[1] = (uint32_t)(base >> 32) & 0xffffu;
+            k.rsrc[2] = (uint32_t)(g.entries * SL_LANES * 4);
+            k.rsrc[3] = 0x00020000u;
+            k.nrec = (uint32_t)p.nrec;
+            k.hpitch = (uint32_t)(nscp * 4);
+            k.cls = S.cls;
+            k.pad = 0;
+        }
+    }
+    OMR_HIP(descs.alloc(sizeof(SlaneTask) * h.size()));
+    OMR_HIP(hipMemcpy(descs.p, h.data(), sizeof(SlaneTask) * h.size(), hipMemcpyHostToDevice));
+    return OMR_OK;
+}
+
+// pack -> sweep -> column counts -> std-dev -> arg-max for `nscans` device-resident scans (at most nsg * 64)
+int slane_enqueue(const SlanePlan &p, SlaneScratch &s, const uint8_t *d_img, int64_t scan_stride, int64_t step, int nscans,
+                  int black_max, hipStream_t stream, hipStream_t post_stream, hipEvent_t ev_mid, double *d_v_sd, double *d_h_sd,
+                  int32_t *d_best, hipEvent_t ev0, hipEvent_t ev1)
+{
+    if (!d_img || nscans < 1 || nscans > s.nsg * SL_LANES) return fail(OMR_ERR_BADARG, "scan-lane launch: %d scans, scratch holds %d", nscans, s.nsg * SL_LANES);
+    if (step < p.g.cols) return fail(OMR_ERR_BADARG, "step_bytes %lld < cols %d", (long long)step, p.g.cols);
+    const int used = (nscans + SL_LANES - 1) / SL_LANES;  // scan groups that hold scans; the descriptors are laid out for s.nsg
+    const size_t nscp = (size_t)s.nsg * SL_LANES;
+    OMR_HIP(hipMemsetAsync(s.hrows.p, 0, sizeof(uint32_t) * (size_t)p.A * p.nrec * nscp, stream));
+    OMR_HIP(launch_slane_pack(d_img, scan_stride, step, p.g, nscans, black_max, s.bits.as<uint32_t>(), stream));
+    if (ev0) OMR_HIP(hipEventRecord(ev0, stream));
+    OMR_HIP(launch_slane(s.descs.as<SlaneTask>(), used, s.nsg, (int)p.tasks.size(), stream));
+    if (ev1) OMR_HIP(hipEventRecord(ev1, stream));
+    if (post_stream && ev_mid) {
+        OMR_HIP(hipEventRecord(ev_mid, stream));
+        OMR_HIP(hipStreamWaitEvent(post_stream, ev_mid, 0));
+        stream = post_stream;
+    }
+    OMR_HIP(launch_slane_vproj(s.planes.as<uint32_t>(), p.d_tasks.as<int32_t>(), (int)p.tasks.size(), used, s.nsg, p.g.NS, p.g.cols,
+                               p.nrec, s.vproj.as<uint32_t>(), stream));
+    double *vs = d_v_sd ? d_v_sd : s.vsd.as<double>(), *hs = d_h_sd ? d_h_sd : s.hsd.as<double>();
+    OMR_HIP(launch_slane_stddev(s.vproj.as<uint32_t>(), s.hrows.as<uint32_t>(), p.A, p.g.cols, p.g.rows, p.nrec, SL_PRE, used, s.nsg,
+                                nscans, vs, hs, stream));
+    if (d_best) OMR_HIP(launch_argmax_path1(vs, hs, p.A, d_best, stream, nscans));
+    return OMR_OK;
+}
+
+}  // namespace omr

@@ -171,6 +171,17 @@ class Batch:
         """Scans carried by one launch of each kernel (amortises the launch-to-launch cost)."""
         check(lib().omr_batch_set_group(self.handle, int(scans_per_launch)))
 
+    def set_lanes(self, max_scans_per_launch):
+        """Scan-lane sweep: up to this many scans per launch, 64 scans per wavefront (0 = back to the run-merging path)."""
+        check(lib().omr_batch_set_lanes(self.handle, int(max_scans_per_launch)))
+
+    def lanes_projections(self, scan, a, rows, cols, scratch_set=0):
+        """(vproj, hproj) of one scan / candidate as the last scan-lane launch left them (tests, inspection)."""
+        vp, hp = np.zeros(cols, np.uint32), np.zeros(rows, np.uint32)
+        check(lib().omr_batch_lanes_projections(self.handle, scratch_set, scan, a, vp.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                                hp.ctypes.data_as(C.POINTER(C.c_uint32))))
+        return vp, hp
+
     def info(self):
         r, g = C.c_int32(), C.c_int32()
         check(lib().omr_batch_info(self.handle, C.byref(r), C.byref(g)))

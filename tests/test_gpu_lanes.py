@@ -1,0 +1,132 @@
+"""The scan-lane sweep on the GPU (omr_batch_set_lanes): 64 scans per wavefront, the geometry as
+wave-uniform programs.  Bar: bit-exact -- integer projections, f64 std-dev bit patterns and the arg-max index equal
+the CPU oracle's (projection.rs:47-65, calculate.rs:13-23, projection.rs:125-190) for every scan of a batch, in every
+lane position, for partial groups, and equal to the run-merging path at the headline size."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import oics
+from oics import projection, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def make_scans(rows, cols, n, seed):
+    rng = np.random.Generator(np.random.PCG64(seed))
+    out = []
+    for i in range(n):
+        kind = i % 5
+        if kind == 0:
+            img = np.where(rng.random((rows, cols)) < rng.uniform(0.02, 0.6), 0, 255).astype(np.uint8)
+        elif kind == 1:
+            img = synth.make_binary_card(rows, cols, seed * 100 + i, skew=float(rng.uniform(-4, 4)))[0]
+        elif kind == 2:
+            img = np.full((rows, cols), 255, np.uint8)
+            img[rng.integers(0, rows, 40), :] = 0  # horizontal rules
+            img[:, rng.integers(0, cols, 25)] = 0  # vertical rules
+        elif kind == 3:
+            img = rng.integers(0, 256, (rows, cols)).astype(np.uint8)  # non-binary: threshold fused in the pack
+        else:
+            img = np.zeros((rows, cols), np.uint8) if i % 2 else np.full((rows, cols), 255, np.uint8)
+        out.append(np.ascontiguousarray(img))
+    return out
+
+
+def run_lanes(scans, max_angle, step, lanes, want_proj=()):
+    rows, cols = scans[0].shape
+    n = len(scans)
+    dev = torch.device("cuda:0")
+    buf = torch.empty((n, rows, cols), dtype=torch.uint8, device=dev)
+    for i, s in enumerate(scans):
+        buf[i] = torch.from_numpy(s).to(dev)
+    _, A = projection.candidate_count(max_angle, step)
+    best = torch.zeros(n, dtype=torch.int32, device=dev)
+    vs = torch.zeros((n, A), dtype=torch.float64, device=dev)
+    hs = torch.zeros((n, A), dtype=torch.float64, device=dev)
+    b = projection.Batch(rows, cols, max_angle, step, n_streams=1)
+    b.set_lanes(lanes)
+    b.run_device(buf.data_ptr(), rows * cols, cols, n, 127, best.data_ptr(), vs.data_ptr(), hs.data_ptr())
+    b.sync()
+    proj = {}
+    if n <= lanes:  # a single launch: scratch set 0 still holds it
+        for scan, a in want_proj:
+            proj[(scan, a)] = b.lanes_projections(scan, a, rows, cols)
+    b.close()
+    return best.cpu().numpy(), vs.cpu().numpy(), hs.cpu().numpy(), proj
+
+
+@pytest.mark.parametrize("rows,cols,max_angle,step,n", [(200, 300, 5, 0.5, 70), (97, 131, 9, 1.5, 64), (333, 64, 10, 1.0, 5),
+                                                        (120, 1000, 3, 0.25, 130)])
+def test_lanes_match_the_oracle(oracle, rows, cols, max_angle, step, n):
+    scans = make_scans(rows, cols, n, rows + cols)
+    N, A = oracle.candidate_count(max_angle, step)
+    probes = [(0, 0), (n - 1, A - 1), (n // 2, A // 2), (min(n - 1, 63), 1)]
+    best, vs, hs, proj = run_lanes(scans, max_angle, step, 64 * ((n + 63) // 64), probes)
+    for i, img in enumerate(scans):
+        binimg = np.where(img <= 127, 0, 255).astype(np.uint8)
+        evp, ehp, evs, ehs = oracle.sweep(binimg, max_angle, step)
+        for (scan, a), (vp, hp) in proj.items():
+            if scan == i:
+                assert (vp == evp[a]).all(), "vproj scan %d candidate %d" % (scan, a)
+                assert (hp == ehp[a]).all(), "hproj scan %d candidate %d" % (scan, a)
+        assert (vs[i].view(np.uint64) == evs.view(np.uint64)).all(), "v_sd bits, scan %d" % i
+        assert (hs[i].view(np.uint64) == ehs.view(np.uint64)).all(), "h_sd bits, scan %d" % i
+        assert best[i] == oracle.argmax_path1(evs, ehs)[0]
+
+
+def test_lanes_in_several_launches(oracle):
+    # 200 scans through launches of 64: the scratch sets alternate, the last launch is a partial group
+    rows, cols = 150, 220
+    scans = make_scans(rows, cols, 200, 7)
+    best, vs, hs, _ = run_lanes(scans, 6, 0.5, 64)
+    for i in (0, 63, 64, 127, 128, 191, 192, 199):
+        binimg = np.where(scans[i] <= 127, 0, 255).astype(np.uint8)
+        _, _, evs, ehs = oracle.sweep(binimg, 6, 0.5)
+        assert (vs[i].view(np.uint64) == evs.view(np.uint64)).all() and (hs[i].view(np.uint64) == ehs.view(np.uint64)).all()
+        assert best[i] == oracle.argmax_path1(evs, ehs)[0]
+
+
+def test_lanes_headline_size(oracle):
+    """C2's shape and sweep, 66 scans (two scan groups, the second nearly empty): two scans against the oracle on all
+    host cores, every scan against the run-merging path."""
+    rows, cols = 3508, 2480
+    cards = [synth.make_card(rows, cols, 3 + i) for i in range(6)]
+    scans = [cards[i % 6][0] for i in range(66)]
+    best, vs, hs, proj = run_lanes(scans, 10, 0.05, 128, [(0, 0), (65, 399), (5, 137)])
+    dev = torch.device("cuda:0")
+    ref = {}
+    b = projection.Batch(rows, cols, 10, 0.05, n_streams=1)
+    buf = torch.empty((6, rows, cols), dtype=torch.uint8, device=dev)
+    for i in range(6):
+        buf[i] = torch.from_numpy(cards[i][0]).to(dev)
+    rb = torch.zeros(6, dtype=torch.int32, device=dev)
+    rv = torch.zeros((6, 400), dtype=torch.float64, device=dev)
+    rh = torch.zeros((6, 400), dtype=torch.float64, device=dev)
+    b.run_device(buf.data_ptr(), rows * cols, cols, 6, 127, rb.data_ptr(), rv.data_ptr(), rh.data_ptr())
+    b.sync()
+    b.close()
+    rb, rv, rh = rb.cpu().numpy(), rv.cpu().numpy(), rh.cpu().numpy()
+    for i in range(66):
+        assert (vs[i].view(np.uint64) == rv[i % 6].view(np.uint64)).all(), "v_sd vs run-merging, scan %d" % i
+        assert (hs[i].view(np.uint64) == rh[i % 6].view(np.uint64)).all(), "h_sd vs run-merging, scan %d" % i
+        assert best[i] == rb[i % 6]
+    for i in (0, 5):
+        binimg = np.where(scans[i] <= 127, 0, 255).astype(np.uint8)
+        evp, ehp, evs, ehs = oracle.sweep(binimg, 10, 0.05, threads=os.cpu_count() or 4, fast=True)
+        assert (vs[i].view(np.uint64) == evs.view(np.uint64)).all() and (hs[i].view(np.uint64) == ehs.view(np.uint64)).all()
+        for (scan, a), (vp, hp) in proj.items():
+            if scan == i:
+                assert (vp == evp[a]).all() and (hp == ehp[a]).all()
+        assert abs((best[i] - 200) * 0.05 - cards[i][1]) < 0.5
+
+
+def test_steep_sweep_is_refused(oracle):
+    # +-20 degrees: more than 8 segments per word -> -213, the context stays on the run-merging / gather path
+    b = projection.Batch(300, 400, 20, 1.0, n_streams=1)
+    with pytest.raises(oics.OmrError) as e:
+        b.set_lanes(64)
+    assert e.value.code == -213
+    b.close()
