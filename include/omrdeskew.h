@@ -201,7 +201,7 @@ int omr_call_pool_stats(int32_t device, int32_t *live_slots, int32_t *idle_slots
  * word column, shift and destination bits make up every destination word (projection.rs:47-65 ->
  * transfer.rs:459-486) -- is one wave-uniform PROGRAM per (candidate, strip of two word columns), enumerated
  * from warpAffine's integer tables.  This entry point builds one strip's program on the HOST (no GPU needed):
- * n_records rows (pre_rows virtual ones first) of seg_dwords_per_row dwords in the segment stream and of 4 dwords
+ * n_records rows (pre_rows virtual ones first) of seg_dwords_per_row dwords in the segment stream and of 8 dwords
  * in the fetch stream (layout: csrc/slane.hpp).  NULL output pointers query the sizes.
  * OMR_ERR_NOTIMPL when the strip does not fit the scheme (such candidates stay with the run-merging kernel). */
 int omr_slane_strip_program(int32_t rows, int32_t cols, const double *fwd_M, int32_t strip, uint32_t *seg_out,

@@ -1225,9 +1225,18 @@ int omr_batch_lanes_projections(omr_batch_ctx *ctx, int32_t set, int32_t scan, i
     if (vproj)
         OMR_HIP(hipMemcpy2D(vproj, 4, s.vproj.as<uint32_t>() + (size_t)a * p.g.cols * nscp + scan, nscp * 4, 4, (size_t)p.g.cols,
                             hipMemcpyDeviceToHost));
-    if (hproj)
-        OMR_HIP(hipMemcpy2D(hproj, 4, s.hrows.as<uint32_t>() + ((size_t)a * p.nrec + SL_PRE) * nscp + scan, nscp * 4, 4,
-                            (size_t)p.g.rows, hipMemcpyDeviceToHost));
+    if (hproj) {  // rows travel packed in pairs: record 2 i in the low half of a dword, 2 i + 1 in the high half
+        std::vector<uint32_t> pairs((size_t)p.nrec / 2);
+        OMR_HIP(hipMemcpy2D(pairs.data(), 4, s.hrows.as<uint32_t>() + (size_t)a * (p.nrec / 2) * nscp + scan, nscp * 4, 4,
+                            pairs.size(), hipMemcpyDeviceToHost));
+        for (int r = 0; r < p.g.rows; r++) {
+            const int q = r + SL_PRE;
+            hproj[r] = (pairs[(size_t)q >> 1] >> ((q & 1) * 16)) & 0xffffu;
+        }
+        int32_t g = 0;
+        OMR_HIP(hipMemcpy(&g, s.guard.p, sizeof g, hipMemcpyDeviceToHost));
+        if (g) return fail(OMR_ERR_GPU, "scan-lane kernel: its LDS accumulators are not at LDS address 0");
+    }
     return OMR_OK;
 }
 

@@ -150,7 +150,7 @@ struct SlanePlan {
     SlaneGeom g;
     int A = 0, nrec = 0;
     bool built = false;
-    int64_t prog_dwords = 0;
+    int64_t prog_dwords = 0, null_seg = 0, null_fet = 0;  // the null program: empty words, nothing to fetch
     DevBuf prog, d_tasks;
     std::vector<SlaneStrip> strips;  // [A][NS]
     std::vector<int32_t> tasks;      // candidate * NS + strip, in launch order
@@ -158,7 +158,7 @@ struct SlanePlan {
 };
 struct SlaneScratch {
     int nsg = 0;  // scan groups of 64 scans a launch may carry
-    DevBuf bits, hrows, vproj, planes, descs, vsd, hsd, best;
+    DevBuf bits, hrows, vproj, planes, descs, vsd, hsd, best, guard;
     int create(const SlanePlan &p, int groups);
 };
 int slane_enqueue(const SlanePlan &p, SlaneScratch &s, const uint8_t *d_img, int64_t scan_stride, int64_t step, int nscans,

@@ -14,14 +14,17 @@
 //   ring       : the wave keeps the source entries it needs in 64 VGPRs: register (s & 15) * 4 + (c - cb(s));
 //                every source row s has its own column base cb(s), chosen by the generator
 //   records    : one per destination row, plus SL_PRE virtual rows ahead of row 0 that only fill the ring and a
-//                virtual row at the end when that makes the count even (the kernel sweeps two rows per turn).
+//                virtual rows at the end up to a multiple of 16 (four rows per turn, row counts flushed every 16).
 //                Two streams per strip:
-//                  fetch stream, 4 dwords per row: E << 8 | ring register (64 = dummy, E = 0): the entries to
-//                                   load while this row is swept; they are committed to the ring before the
-//                                   NEXT row (byte offset of the entry = the dword with its low byte cleared)
+//                  fetch stream, 8 dwords per row: 4 x (E << 8) = the byte offsets of the entries whose loads are
+//                                   ISSUED while this row is swept (0 = the all-zero entry: a dummy), then 4 x
+//                                   (ring register | 0x8000) to COMMIT before this row: where the loads issued
+//                                   SL_AHEAD rows earlier belong (register 64 = dummy; 0x8000 = M0's DST_REL bit)
 //                  segment stream, SL_K words x S x (mask, pk) per row: destination bits `mask` = bits (sh + i) of
-//                                   the register pair (ring[idx + 1] : ring[idx]); pk = idx | sh << 8, the
-//                                   first pk of a word also carries its segment count n << 16
+//                                   the register pair (ring[idx + 1] : ring[idx]); pk = sh | idx << 5 | 0x60000
+//                                   (pk >> 5 is M0 for the indexed v_alignbit: index + SRC0_REL | SRC1_REL; pk
+//                                   itself is its shift operand), the first pk of a word also carries its
+//                                   segment count n << 24
 //                S = 2 / 4 / 8 slots per word (class 0 / 1 / 2: 8 / 16 / 32 dwords per row), chosen per strip
 #pragma once
 #include <stdint.h>
@@ -33,11 +36,16 @@ namespace omr {
 constexpr int SL_K = 2;
 constexpr int SL_RING_ROWS = 16;
 constexpr int SL_RING_COLS = 4;
-constexpr int SL_FETCH = 4;
+constexpr int SL_FETCH = 4;                             // loads per row
+constexpr int SL_FREC = 8;                              // dwords per row of the fetch stream
+constexpr int SL_AHEAD = 4;                             // rows between a load and its commit
 constexpr int SL_DUMMY = SL_RING_ROWS * SL_RING_COLS;  // ring register that swallows dummy fetches
-constexpr int SL_PRE = 16;                              // virtual rows ahead of row 0
+constexpr uint32_t SL_PK_MODE = 0x60000u;               // pk >> 5 -> M0[13:12]: SRC0_REL | SRC1_REL
+constexpr uint32_t SL_COMMIT_MODE = 0x8000u;            // M0[15]: DST_REL
+constexpr int SL_PRE = 24;                              // virtual rows ahead of row 0
 constexpr int SL_GX = 4;                                // zero guard word columns on either side
 constexpr int SL_LANES = 64;
+constexpr int SL_DUMP = 17;                             // registers a wave dumps per word: planes p0..p11, carries c0..c4
 
 struct SlaneGeom {
     int rows = 0, cols = 0;  // image
@@ -63,7 +71,7 @@ struct SlaneStrip {     // per (candidate, strip)
 inline int slane_slots(int cls) { return 2 << cls; }
 inline int slane_seg_dwords(int cls) { return SL_K * 2 * slane_slots(cls); }  // per row
 inline int slane_class(int most) { return most <= 2 ? 0 : most <= 4 ? 1 : most <= 8 ? 2 : -1; }
-inline int slane_records(int rows) { return (SL_PRE + rows + 1) & ~1; }
+inline int slane_records(int rows) { return (SL_PRE + rows + 15) & ~15; }  // row counts leave in blocks of 16 rows
 
 // warpAffine's integer tables of one candidate on the host (the expressions of tables_kernel, kernels.hip;
 // built -ffp-contract=off): adelta / bdelta per column, (X0, Y0) per row with round_delta = 512
@@ -74,23 +82,25 @@ void slane_host_tables(const double Minv[6], int rows, int cols, std::vector<int
 // that needs more than SL_RING_COLS word columns, more than 8 segments).
 int slane_strip_segments(const SlaneGeom &g, const int32_t *ad, const int32_t *bd, const int32_t *x0, const int32_t *y0,
                          int strip);
-// Pass 2: the strip's program: slane_records(rows) rows of slane_seg_dwords(cls) dwords into seg, of SL_FETCH dwords
+// Pass 2: the strip's program: slane_records(rows) rows of slane_seg_dwords(cls) dwords into seg, of SL_FREC dwords
 // into fet.  Returns false when the ring schedule fails (the candidate then stays with the run-merging kernel).
 bool slane_strip_program(const SlaneGeom &g, const int32_t *ad, const int32_t *bd, const int32_t *x0, const int32_t *y0,
                          int strip, int cls, uint32_t *seg, uint32_t *fet);
 
-// What a wave of slane_kernel starts from (64 bytes, read by scalar loads; tools/gen_slane_asm.py fixes the layout)
+// What a wave of slane_kernel starts from (read by scalar loads; tools/gen_slane_asm.py fixes the layout)
 struct SlaneTask {
     uint64_t seg, fet;   // the strip's segment / fetch stream
-    uint64_t hrow;       // row counts of (candidate, scan group): u32 [record][scan], record 0 = first virtual row
-    uint64_t planes;     // counter dump of (task, scan group): [word][18][64]
+    uint32_t hrsrc[4];   // buffer descriptor of the row counts of (candidate, scan group): [record / 2][scan], each u32 = the
+                         // counts of records 2 i (low half) and 2 i + 1 (high half)
     uint32_t rsrc[4];    // buffer descriptor of the scan group's interleaved bit image
-    uint32_t nrec;       // records (even)
-    uint32_t hpitch;     // bytes between rows of hrow
+    uint32_t nrec;       // records (a multiple of 4)
+    uint32_t hpitch;     // bytes between pair rows of the row counts
     int32_t cls;         // 0 / 1 / 2 = 2 / 4 / 8 slots per word
-    int32_t pad;
+    int32_t wave;        // the wave's place in its workgroup (strip & 3)
+    uint64_t planes;     // counter dump of (task, scan group): [word][SL_DUMP][64]
+    uint64_t pad1[7];
 };
-static_assert(sizeof(SlaneTask) == 64, "SlaneTask layout (slane_asm.inc loads it by offset)");
+static_assert(sizeof(SlaneTask) == 128, "SlaneTask layout (slane_asm.inc loads it by offset)");
 
 }  // namespace omr
 
@@ -99,9 +109,9 @@ namespace omr {
 hipError_t launch_slane_pack(const uint8_t *d_img, int64_t scan_stride, int64_t step, const SlaneGeom &g, int nscans,
                              int black_max, uint32_t *d_bits, hipStream_t s);
 // nsg_used = scan groups that carry scans in this launch, nsg = scan groups the scratch (and its descriptors) is laid out for
-hipError_t launch_slane(const SlaneTask *d_descs, int nsg_used, int nsg, int ntasks, hipStream_t s);
+hipError_t launch_slane(const SlaneTask *d_descs, int nsg_used, int nsg, int A, int NS, int32_t *d_guard, hipStream_t s);
 hipError_t launch_slane_vproj(const uint32_t *d_planes, const int32_t *d_tasks, int ntasks, int nsg_used, int nsg, int NS,
                               int cols, int nrec, uint32_t *d_vproj, hipStream_t s);
-hipError_t launch_slane_stddev(const uint32_t *d_vproj, const uint32_t *d_hproj, int A, int cols, int rows, int hrows_per_cand,
+hipError_t launch_slane_stddev(const uint32_t *d_vproj, const uint32_t *d_hproj, int A, int cols, int rows, int hpairs_per_cand,
                                int hrow0, int nsg_used, int nsg, int nscans, double *d_v_sd, double *d_h_sd, hipStream_t s);
 }  // namespace omr

@@ -60,21 +60,36 @@ int SlanePlan::build(const SweepTables &t)
         S.seg_offset = off;
         off += ((int64_t)nrec * slane_seg_dwords(S.cls) + 63) & ~63ll;
         S.fet_offset = off;
-        off += ((int64_t)nrec * SL_FETCH + 63) & ~63ll;
+        off += ((int64_t)nrec * SL_FREC + 63) & ~63ll;
     }
-    prog_dwords = off + 256;  // the kernel reads up to two records past a strip's last one
+    // the null program (class 0: nothing to fetch, empty words) for the places of a workgroup beyond the last strip
+    null_seg = off;
+    off += ((int64_t)nrec * slane_seg_dwords(0) + 63) & ~63ll;
+    null_fet = off;
+    off += ((int64_t)nrec * SL_FREC + 63) & ~63ll;
+    prog_dwords = off + 256;  // the kernel reads one record past a stream's last one
     std::vector<uint32_t> host((size_t)prog_dwords, 0u);
     pass(true, host.data());
+    for (int64_t i = 0; i < (int64_t)nrec * slane_seg_dwords(0); i += 2) host[(size_t)(null_seg + i + 1)] = SL_PK_MODE;
+    for (int64_t i = 0; i < (int64_t)nrec * SL_FREC; i++)
+        host[(size_t)(null_fet + i)] = (i % SL_FREC) < SL_FETCH ? 0u : ((uint32_t)SL_DUMMY | SL_COMMIT_MODE);
     if (bad.load()) return fail(OMR_ERR_NOTIMPL, "a strip's ring schedule does not fit (16 source rows x 4 word columns)");
     OMR_HIP(prog.alloc(sizeof(uint32_t) * (size_t)prog_dwords));
     OMR_HIP(hipMemcpy(prog.p, host.data(), sizeof(uint32_t) * (size_t)prog_dwords, hipMemcpyHostToDevice));
-    // ---- tasks: heaviest class first, then strip-major with the candidate fastest (a workgroup's four waves sweep
-    // adjacent candidates of one strip: the same source window)
+    // ---- tasks: candidate-major, all strips of a candidate together (they share the candidate's row counts, see
+    // slane_kernel); the candidates with the most segments per word (the steepest angles) go first, so that the
+    // launch does not end on its longest tasks
+    std::vector<int> order((size_t)A);
+    for (int a = 0; a < A; a++) order[(size_t)a] = a;
+    auto weight = [&](int a) {
+        int w = 0;
+        for (int st = 0; st < NS; st++) w += 2 << strips[(size_t)a * NS + st].cls;
+        return w;
+    };
+    std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return weight(x) > weight(y); });
     tasks.clear();
-    for (int c = 2; c >= 0; c--)
-        for (int st = 0; st < NS; st++)
-            for (int a = 0; a < A; a++)
-                if (strips[(size_t)a * NS + st].cls == c) tasks.push_back(a * NS + st);
+    for (int a : order)
+        for (int st = 0; st < NS; st++) tasks.push_back(a * NS + st);
     OMR_HIP(d_tasks.alloc(sizeof(int32_t) * tasks.size()));
     OMR_HIP(hipMemcpy(d_tasks.p, tasks.data(), sizeof(int32_t) * tasks.size(), hipMemcpyHostToDevice));
     built = true;
@@ -90,35 +105,46 @@ int SlaneScratch::create(const SlanePlan &p, int groups)
     const size_t bits_b = sizeof(uint32_t) * (size_t)nsg * g.entries * SL_LANES;
     OMR_HIP(bits.alloc(bits_b));
     OMR_HIP(hipMemset(bits.p, 0, bits_b));  // entry 0 and the guard columns stay zero for good
-    OMR_HIP(hrows.alloc(sizeof(uint32_t) * (size_t)p.A * p.nrec * nscp));
+    OMR_HIP(hrows.alloc(sizeof(uint32_t) * (size_t)p.A * (p.nrec / 2) * nscp));  // two records per dword
+    OMR_HIP(guard.alloc(sizeof(int32_t)));
+    OMR_HIP(hipMemset(guard.p, 0, sizeof(int32_t)));
     OMR_HIP(vproj.alloc(sizeof(uint32_t) * (size_t)p.A * g.cols * nscp));
-    OMR_HIP(planes.alloc(sizeof(uint32_t) * ntasks * nsg * SL_K * 18 * SL_LANES));
     OMR_HIP(vsd.alloc(sizeof(double) * nscp * p.A));
     OMR_HIP(hsd.alloc(sizeof(double) * nscp * p.A));
     OMR_HIP(best.alloc(sizeof(int32_t) * nscp));
-    // ---- one 64-byte descriptor per (task, scan group)
-    std::vector<SlaneTask> h(ntasks * (size_t)nsg);
+    // ---- one descriptor per (candidate in launch order, place in its workgroups, scan group); places beyond the
+    // last strip get the null program and dump their (all-zero) counters into a spare slot
+    const int NSp = ((g.NS + 3) / 4) * 4;
+    OMR_HIP(planes.alloc(sizeof(uint32_t) * (ntasks * nsg + 1) * SL_K * SL_DUMP * SL_LANES));
+    std::vector<SlaneTask> h((size_t)p.A * NSp * nsg);
     const uint64_t prog0 = (uint64_t)p.prog.p;
-    for (size_t ti = 0; ti < ntasks; ti++) {
-        const int task = p.tasks[ti], a = task / g.NS;
-        const SlaneStrip &S = p.strips[(size_t)task];
-        for (int sg = 0; sg < nsg; sg++) {
-            SlaneTask &k = h[ti * nsg + sg];
-            k.seg = prog0 + 4ull * (uint64_t)S.seg_offset;
-            k.fet = prog0 + 4ull * (uint64_t)S.fet_offset;
-            k.hrow = (uint64_t)hrows.p + 4ull * ((uint64_t)a * p.nrec * nscp + (uint64_t)sg * SL_LANES);
-            k.planes = (uint64_t)planes.p + 4ull * ((ti * nsg + sg) * SL_K * 18 * SL_LANES);
-            const uint64_t base = (uint64_t)bits.p + 4ull * (uint64_t)sg * g.entries * SL_LANES;
-            k.rsrc[0] = (uint32_t)base;
-            k.rsrc[1] = (uint32_t)(base >> 32) & 0xffffu;
-            k.rsrc[2] = (uint32_t)(g.entries * SL_LANES * 4);
-            k.rsrc[3] = 0x00020000u;
-            k.nrec = (uint32_t)p.nrec;
-            k.hpitch = (uint32_t)(nscp * 4);
-            k.cls = S.cls;
-            k.pad = 0;
+    for (int ai = 0; ai < p.A; ai++)
+        for (int st = 0; st < NSp; st++) {
+            const bool real = st < g.NS;
+            const size_t ti = (size_t)ai * g.NS + (real ? st : 0);  // index into p.tasks (launch order)
+            const int task = p.tasks[ti], a = task / g.NS;
+            const SlaneStrip &S = p.strips[(size_t)task];
+            for (int sg = 0; sg < nsg; sg++) {
+                SlaneTask &k = h[((size_t)ai * NSp + st) * nsg + sg];
+                k.seg = prog0 + 4ull * (uint64_t)(real ? S.seg_offset : p.null_seg);
+                k.fet = prog0 + 4ull * (uint64_t)(real ? S.fet_offset : p.null_fet);
+                const uint64_t hb = (uint64_t)hrows.p + 4ull * ((uint64_t)a * (p.nrec / 2) * nscp + (uint64_t)sg * SL_LANES);
+                k.hrsrc[0] = (uint32_t)hb;
+                k.hrsrc[1] = (uint32_t)(hb >> 32) & 0xffffu;
+                k.hrsrc[2] = (uint32_t)((size_t)(p.nrec / 2) * nscp * 4 - (size_t)sg * SL_LANES * 4);
+                k.hrsrc[3] = 0x00020000u;
+                k.planes = (uint64_t)planes.p + 4ull * ((real ? ti * nsg + sg : ntasks * nsg) * SL_K * SL_DUMP * SL_LANES);
+                const uint64_t base = (uint64_t)bits.p + 4ull * (uint64_t)sg * g.entries * SL_LANES;
+                k.rsrc[0] = (uint32_t)base;
+                k.rsrc[1] = (uint32_t)(base >> 32) & 0xffffu;
+                k.rsrc[2] = (uint32_t)(g.entries * SL_LANES * 4);
+                k.rsrc[3] = 0x00020000u;
+                k.nrec = (uint32_t)p.nrec;
+                k.hpitch = (uint32_t)(nscp * 4);
+                k.cls = real ? S.cls : 0;
+                k.wave = st & 3;
+            }
         }
-    }
     OMR_HIP(descs.alloc(sizeof(SlaneTask) * h.size()));
     OMR_HIP(hipMemcpy(descs.p, h.data(), sizeof(SlaneTask) * h.size(), hipMemcpyHostToDevice));
     return OMR_OK;
@@ -133,10 +159,10 @@ int slane_enqueue(const SlanePlan &p, SlaneScratch &s, const uint8_t *d_img, int
     if (step < p.g.cols) return fail(OMR_ERR_BADARG, "step_bytes %lld < cols %d", (long long)step, p.g.cols);
     const int used = (nscans + SL_LANES - 1) / SL_LANES;  // scan groups that hold scans; the descriptors are laid out for s.nsg
     const size_t nscp = (size_t)s.nsg * SL_LANES;
-    OMR_HIP(hipMemsetAsync(s.hrows.p, 0, sizeof(uint32_t) * (size_t)p.A * p.nrec * nscp, stream));
+    OMR_HIP(hipMemsetAsync(s.hrows.p, 0, sizeof(uint32_t) * (size_t)p.A * (p.nrec / 2) * nscp, stream));
     OMR_HIP(launch_slane_pack(d_img, scan_stride, step, p.g, nscans, black_max, s.bits.as<uint32_t>(), stream));
     if (ev0) OMR_HIP(hipEventRecord(ev0, stream));
-    OMR_HIP(launch_slane(s.descs.as<SlaneTask>(), used, s.nsg, (int)p.tasks.size(), stream));
+    OMR_HIP(launch_slane(s.descs.as<SlaneTask>(), used, s.nsg, p.A, p.g.NS, s.guard.as<int32_t>(), stream));
     if (ev1) OMR_HIP(hipEventRecord(ev1, stream));
     if (post_stream && ev_mid) {
         OMR_HIP(hipEventRecord(ev_mid, stream));
@@ -146,7 +172,7 @@ int slane_enqueue(const SlanePlan &p, SlaneScratch &s, const uint8_t *d_img, int
     OMR_HIP(launch_slane_vproj(s.planes.as<uint32_t>(), p.d_tasks.as<int32_t>(), (int)p.tasks.size(), used, s.nsg, p.g.NS, p.g.cols,
                                p.nrec, s.vproj.as<uint32_t>(), stream));
     double *vs = d_v_sd ? d_v_sd : s.vsd.as<double>(), *hs = d_h_sd ? d_h_sd : s.hsd.as<double>();
-    OMR_HIP(launch_slane_stddev(s.vproj.as<uint32_t>(), s.hrows.as<uint32_t>(), p.A, p.g.cols, p.g.rows, p.nrec, SL_PRE, used, s.nsg,
+    OMR_HIP(launch_slane_stddev(s.vproj.as<uint32_t>(), s.hrows.as<uint32_t>(), p.A, p.g.cols, p.g.rows, p.nrec / 2, SL_PRE, used, s.nsg,
                                 nscans, vs, hs, stream));
     if (d_best) OMR_HIP(launch_argmax_path1(vs, hs, p.A, d_best, stream, nscans));
     return OMR_OK;

@@ -11,6 +11,8 @@
 #include <math.h>
 #include <string.h>
 
+#include <algorithm>
+
 namespace omr {
 
 void slane_host_tables(const double M[6], int rows, int cols, std::vector<int32_t> &ad, std::vector<int32_t> &bd,
@@ -121,40 +123,45 @@ bool slane_strip_program(const SlaneGeom &g, const int32_t *ad, const int32_t *b
                 if (r > last[s]) last[s] = r;
             }
         }
-    // ---- fetch schedule.  Record q (row q - SL_PRE) loads its entries while its row is swept; they are in the
-    // ring from the next row on.  Source row s lives in registers (s & 15) * 4 + j: it may be committed only
-    // after the last row that reads source row s - 16 has been swept.
+    // ---- fetch schedule.  Record q (row q - SL_PRE) issues its loads while its row is swept; they are committed to
+    // the ring before row q + SL_AHEAD (in between they sit in the wave's landing registers).  Source row s lives in
+    // registers (s & 15) * 4 + j: it may be committed only after the last row that reads source row s - 16 is done.
     std::vector<uint8_t> used((size_t)NREC, 0);
-    memset(seg, 0, sizeof(uint32_t) * (size_t)NREC * RD);
-    for (size_t i = 0; i < (size_t)NREC * SL_FETCH; i++) fet[i] = SL_DUMMY;
+    for (size_t i = 0; i < (size_t)NREC * RD; i += 2) seg[i] = 0u, seg[i + 1] = SL_PK_MODE;  // empty slots
+    for (size_t i = 0; i < (size_t)NREC * SL_FREC; i++) fet[i] = (i % SL_FREC) < SL_FETCH ? 0u : (SL_DUMMY | SL_COMMIT_MODE);
+    std::vector<uint8_t> freg((size_t)NREC * SL_FETCH, (uint8_t)SL_DUMMY);  // ring register of every fetch
     for (int s = 0; s < R; s++) {
         if (last[(size_t)s] < 0) continue;
         const int ncols = cmax[(size_t)s] - cmin[(size_t)s] + 1;
         if (ncols > SL_RING_COLS) return false;
         if (cmin[(size_t)s] < -SL_GX || cmax[(size_t)s] >= g.NW + SL_GX) return false;
         int lb = -SL_PRE;  // earliest record (as a row number) that may carry this source row
-        if (s >= SL_RING_ROWS && last[(size_t)(s - SL_RING_ROWS)] >= 0) lb = last[(size_t)(s - SL_RING_ROWS)];
-        int rec = first[(size_t)s] - 1;
+        if (s >= SL_RING_ROWS && last[(size_t)(s - SL_RING_ROWS)] >= 0)
+            lb = std::max(lb, last[(size_t)(s - SL_RING_ROWS)] - SL_AHEAD + 1);
+        int rec = first[(size_t)s] - SL_AHEAD;
         for (int j = ncols - 1; j >= 0; j--) {
             while (rec >= lb && used[(size_t)(rec + SL_PRE)] == SL_FETCH) rec--;
-            if (rec < lb || rec < -SL_PRE) return false;
+            if (rec < lb) return false;
             const size_t q = (size_t)(rec + SL_PRE);
             const uint32_t reg = (uint32_t)((s & (SL_RING_ROWS - 1)) * SL_RING_COLS + j);
-            fet[q * SL_FETCH + used[q]++] = (uint32_t)(g.entry(s, cmin[(size_t)s] + j) << 8) | reg;
+            freg[q * SL_FETCH + used[q]] = (uint8_t)reg;
+            fet[q * SL_FREC + used[q]++] = (uint32_t)(g.entry(s, cmin[(size_t)s] + j) << 8);
         }
     }
+    for (int q = SL_AHEAD; q < NREC; q++)  // what row q commits = what row q - SL_AHEAD fetched
+        for (int f = 0; f < SL_FETCH; f++) fet[(size_t)q * SL_FREC + SL_FETCH + f] = freg[(size_t)(q - SL_AHEAD) * SL_FETCH + f] | SL_COMMIT_MODE;
     // ---- the rows' words
     for (int r = 0; r < R; r++)
         for (int k = 0; k < SL_K; k++) {
             const Seg *sg = &segs[((size_t)r * SL_K + k) * MAXSEG];
             uint32_t *w = seg + (size_t)(r + SL_PRE) * RD + (size_t)k * 2 * S;
-            w[1] = (uint32_t)nseg[(size_t)r * SL_K + k] << 16;
+            w[1] |= (uint32_t)nseg[(size_t)r * SL_K + k] << 24;
             for (int j = 0; j < nseg[(size_t)r * SL_K + k]; j++) {
                 const int c = floor_div32(sg[j].base), sh = sg[j].base - 32 * c;
                 const size_t s = (size_t)sg[j].s;
                 const uint32_t idx = (uint32_t)((sg[j].s & (SL_RING_ROWS - 1)) * SL_RING_COLS + (c - cmin[s]));
                 w[2 * j] = sg[j].mask;
-                w[2 * j + 1] |= idx | ((uint32_t)sh << 8);
+                w[2 * j + 1] |= (uint32_t)sh | (idx << 5);
             }
         }
     return true;

@@ -43,7 +43,7 @@ def strip_program(rows, cols, M, strip):
     if rc != 0:
         return None
     seg = np.zeros(rd.value * nrec.value, np.uint32)
-    fet = np.zeros(4 * nrec.value, np.uint32)
+    fet = np.zeros(8 * nrec.value, np.uint32)
     rc = L.omr_slane_strip_program(rows, cols, Mc.ctypes.data_as(f64p), strip, seg.ctypes.data_as(u32p),
                                    fet.ctypes.data_as(u32p), C.byref(rd), C.byref(nrec), C.byref(pre), C.byref(most))
     if rc != 0:
@@ -111,7 +111,7 @@ def test_record_classes_follow_the_angle():
         M = orc.get_rotation_matrix_2d(cols / 2.0, rows / 2.0, ang, 1.0)
         _, rd, nrec, pre, most = strip_program(rows, cols, M, 3)
         assert rd == want, (ang, rd, most)
-        assert nrec == (rows + pre + 1) // 2 * 2
+        assert nrec == (rows + pre + 15) // 16 * 16
 
 
 def test_steep_candidates_are_refused_not_mangled():
