@@ -96,9 +96,11 @@ struct SlaneTask {
     uint32_t nrec;       // records (a multiple of 4)
     uint32_t hpitch;     // bytes between pair rows of the row counts
     int32_t cls;         // 0 / 1 / 2 = 2 / 4 / 8 slots per word
-    int32_t wave;        // the wave's place in its workgroup (strip & 3)
+    int32_t wave;        // the strip's place in its quad (strip & 3): which accumulator rows the wave flushes
     uint64_t planes;     // counter dump of (task, scan group): [word][SL_DUMP][64]
-    uint64_t pad1[7];
+    uint32_t lds_base;   // LDS address of the scan group's row-count accumulators in the workgroup
+    uint32_t pad1;
+    uint64_t pad2[6];
 };
 static_assert(sizeof(SlaneTask) == 128, "SlaneTask layout (slane_asm.inc loads it by offset)");
 
@@ -109,7 +111,7 @@ namespace omr {
 hipError_t launch_slane_pack(const uint8_t *d_img, int64_t scan_stride, int64_t step, const SlaneGeom &g, int nscans,
                              int black_max, uint32_t *d_bits, hipStream_t s);
 // nsg_used = scan groups that carry scans in this launch, nsg = scan groups the scratch (and its descriptors) is laid out for
-hipError_t launch_slane(const SlaneTask *d_descs, int nsg_used, int nsg, int A, int NS, int32_t *d_guard, hipStream_t s);
+hipError_t launch_slane(const SlaneTask *d_descs, int nsg_used, int nsgp, int A, int NS, int32_t *d_guard, hipStream_t s);
 hipError_t launch_slane_vproj(const uint32_t *d_planes, const int32_t *d_tasks, int ntasks, int nsg_used, int nsg, int NS,
                               int cols, int nrec, uint32_t *d_vproj, hipStream_t s);
 hipError_t launch_slane_stddev(const uint32_t *d_vproj, const uint32_t *d_hproj, int A, int cols, int rows, int hpairs_per_cand,

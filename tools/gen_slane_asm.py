@@ -16,10 +16,10 @@ The scalar unit issues one instruction per SIMD every four cycles, like the vect
 (M0 = 0 = nothing indexed), one s_lshr writes index and mode bits of M0 per segment, fetch offsets and commit
 registers come ready-made from the fetch record, the row counts go through a buffer descriptor with a scalar offset.
 
-Register map (fixed; the statement clobbers s0-s13, s16-s99, v1-v127, so lane * 4 arrives in v0):
+Register map (fixed; the statement clobbers s0-s13, s16-s100, v1-v127, so lane * 4 arrives in v0):
   s[0:1] segment stream  s[2:3] fetch stream  s[4:7] row-count buffer descriptor  s[8:11] bit-image descriptor
   s12 rows left  s13 row-count pitch  s[16:23] / s[24:31] fetch records even / odd row  s32 row-count offset
-  s33 row index  s34 slot class, then segments of the word / scratch  s35 wave of the workgroup  s[36:67] / s[68:99] segment records even / odd row
+  s33 row index  s34 slot class, then segments of the word / scratch  s35 strip's place in its quad  s100 LDS base of the scan group's accumulators  s[36:67] / s[68:99] segment records even / odd row
   v[1:17] / v[18:34] column counters of word 0 / 1: planes p0..p11, pending carries c0..c4
   v35 LDS address of the turn's row-count slots  v36 odd row's count
   v37-v40 carries  v41 row count  v42 / v43 odd row's words  v[44:59] four landing sets of four entries
@@ -114,6 +114,7 @@ def flush(out, L):
     if "noatomic" not in ABLATE:
         out += ["s_waitcnt lgkmcnt(0)", "s_barrier",
                 "s_and_b32 s34, s33, 16", "s_lshl_b32 s34, s34, 7",        # buffer (bit 4 of the row index) * 2048
+                "s_add_u32 s34, s34, s100",                                # + this scan group's accumulators
                 "v_add_u32 v%d, s34, %%[lane4]" % CNT2,
                 "s_lshl_b32 s34, s35, 9",                                  # + wave * 2 slots * 256 bytes
                 "v_add_u32 v%d, s34, v%d" % (CNT2, CNT2),
@@ -196,7 +197,7 @@ def body(o, S, L):
     o.append("s_waitcnt lgkmcnt(0)")
     o.append("L%s_loop:" % L)
     # LDS address of this turn's two pair slots: buffer = bit 4 of the row index, slot = bits 3:1
-    o += ["s_bfe_u32 s34, s33, 0x40001", "s_lshl_b32 s34, s34, 8", "v_add_u32 v%d, s34, %%[lane4]" % LADDR]
+    o += ["s_bfe_u32 s34, s33, 0x40001", "s_lshl_b32 s34, s34, 8", "s_add_u32 s34, s34, s100", "v_add_u32 v%d, s34, %%[lane4]" % LADDR]
     for r in range(4):
         w = r & 1
         rec_loads(o, w ^ 1, S, r + 1)       # the next row's records travel while this row is swept
@@ -224,7 +225,7 @@ def kernel():
     o = []
     U = "%="  # unique label suffix per asm statement
     o += ["s_load_dwordx8 s[0:7], %[desc], 0", "s_load_dwordx4 s[8:11], %[desc], 32", "s_load_dwordx2 s[12:13], %[desc], 48",
-          "s_load_dword s34, %[desc], 56", "s_load_dword s35, %[desc], 60"]
+          "s_load_dword s34, %[desc], 56", "s_load_dword s35, %[desc], 60", "s_load_dword s100, %[desc], 72"]
     for v in range(1, 128):
         o.append("v_mov_b32 v%d, 0" % v)
     o.append("s_waitcnt lgkmcnt(0)")
@@ -249,7 +250,7 @@ def kernel():
     return o
 
 
-CLOB = ['"memory"', '"scc"', '"vcc"', '"m0"'] + ['"s%d"' % i for i in list(range(0, 14)) + list(range(16, 100))] + ['"v%d"' % i for i in range(1, 128)]
+CLOB = ['"memory"', '"scc"', '"vcc"', '"m0"'] + ['"s%d"' % i for i in list(range(0, 14)) + list(range(16, 101))] + ['"v%d"' % i for i in range(1, 128)]
 
 out = ["// GENERATED by tools/gen_slane_asm.py -- do not edit; see that file for the register map.\n"]
 body_txt = "\\n\\t\"\n    \"".join(kernel())
