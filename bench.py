@@ -50,6 +50,7 @@ MAX_ANGLE, STEP = 10, 0.05
 HBM_PEAK_GBPS = 8000.0   # 8.0 TB/s spec
 N_CU, N_SIMD, CLOCK_GHZ = 256, 1024, 2.4
 VALU_ISSUE_CYCLES = 2.0  # cycles a plain wave64 VOP2 holds its SIMD with >= 2 waves resident (constants table)
+VALU_LANE_MIX_CYCLES = 3.7  # scan-lane kernel: 31 VALU per row of which 27 are 4-cycle forms (v_alignbit, v_and_or, v_bitop3, v_bcnt) and 4 v_mov
 VALU_MIX_CYCLES = 3.86   # the same for THIS kernel's instruction mix (v_alignbit, v_bfi, v_and_or, v_lshlrev, VOP3 forms take 4:
 #                          tools/valu_issue.hip "sweep-kernel mix", profiles/r02_valu_issue.md): what `bound` is decided with
 METRIC = "deskewed images/sec, 2480x3508 gray, +-10deg@0.05deg sweep; HBM GB/s vs roofline"
@@ -71,6 +72,9 @@ def parse_args(argv=None):
                     help="scans carried by one launch of each kernel (a multiple of 8 keeps one scan per XCD; measured on "
                          "one box: 8 -> 4.61 k, 16 -> 4.78 k, 32 -> 4.79 k images/s: the partial last wave of workgroups "
                          "of a launch is amortised over more work)")
+    ap.add_argument("--lanes", type=int, default=512,
+                    help="scan-lane sweep (DESIGN.md 4.6): scans carried by one launch, 64 scans per wavefront "
+                         "(omr_batch_set_lanes); 0 = the run-merging path with --group scans per launch")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="wall-clock budget of the CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pmc", action="store_true", help="skip the in-run rocprofv3 counter passes")
@@ -157,7 +161,7 @@ def launch_ranks(args, argv):
 
 
 # ------------------------------------------------------------------------------------------------
-def base_record(args, world, value, elapsed, B, A, G, D=None):
+def base_record(args, world, value, elapsed, B, A, G, D=None, path="run-merging"):
     D = B if D is None else D
     return {
         "metric": METRIC,
@@ -178,7 +182,7 @@ def base_record(args, world, value, elapsed, B, A, G, D=None):
                                % (A, B, D),
                    "scans_per_gpu_per_step": B, "distinct_cards_per_gpu": D, "candidates": A, "global_batch": B * world,
                    "parallelism": "scan-sharded x%d, host-side gather" % world, "streams_per_gpu": args.streams,
-                   "scans_per_kernel_launch": G},
+                   "scans_per_kernel_launch": G, "sweep_kernel": path},
     }
 
 
@@ -291,8 +295,11 @@ def pmc_passes(args, cards_path, workdir):
     from oics import pmc
     if pmc.rocprof() is None:
         return {"error": "rocprofv3 not found"}
-    argv = [os.path.abspath(__file__), "--pmc-child", "--steps", "3", "--warmup", "1", "--scans", str(min(args.scans, 64)),
-            "--group", str(args.group), "--streams", str(args.streams), "--cards", cards_path]
+    # (a scan-lane launch carries the whole batch: the children sweep the same number of scans as the parent so that
+    # "per launch" means the same launch)
+    argv = [os.path.abspath(__file__), "--pmc-child", "--steps", "3", "--warmup", "1",
+            "--scans", str(args.scans if args.lanes > 0 else min(args.scans, 64)),
+            "--group", str(args.group), "--lanes", str(args.lanes), "--streams", str(args.streams), "--cards", cards_path]
     res = {"passes": {}}
     for name, ctrs in (("fetch", ["FETCH_SIZE"]), ("write", ["WRITE_SIZE"]), ("sq", pmc.SQ_PASS)):
         c, d = pmc.run_pass(ctrs, argv, os.path.join(workdir, name), timeout_s=240,
@@ -300,7 +307,7 @@ def pmc_passes(args, cards_path, workdir):
         if c is None:
             res["passes"][name] = {"error": d}
             continue
-        k = pmc.pick(c.keys(), "runs_kernel") or pmc.pick(c.keys(), "sweep_lds_kernel")
+        k = pmc.pick(c.keys(), "slane_kernel") or pmc.pick(c.keys(), "runs_kernel") or pmc.pick(c.keys(), "sweep_lds_kernel")
         if k is None:
             res["passes"][name] = {"error": "sweep kernel not in the counter file"}
             continue
@@ -372,8 +379,20 @@ def main():
     vs = torch.zeros((B, A), dtype=torch.float64, device=dev)
     hs = torch.zeros((B, A), dtype=torch.float64, device=dev)
     batch = projection.Batch(ROWS, COLS, MAX_ANGLE, STEP, device=local_rank, n_streams=args.streams)
-    G = max(1, min(args.group, B))
-    batch.set_group(G)  # scans per kernel launch
+    lanes_mode = False
+    if args.lanes > 0:
+        try:
+            batch.set_lanes(min(B, args.lanes))  # builds every strip's program on the host's cores, uploads them once
+            lanes_mode = True
+        except oics.OmrError as e:
+            if e.code != -213:
+                raise
+    if lanes_mode:
+        G = 64 * ((min(B, args.lanes) + 63) // 64)  # scans per launch of the scan-lane kernel
+        G = min(G, B) if B % 64 == 0 else G
+    else:
+        G = max(1, min(args.group, B))
+        batch.set_group(G)  # scans per kernel launch
 
     def step():
         # black_max = 127 fuses transfer_gray_image_to_thresh_binary into the bit-pack
@@ -434,7 +453,7 @@ def main():
     # per scan when some candidates do not qualify for run-merging; the dominant kernel's mean launch
     # time is stage / launches.
     n_runs, n_gather = batch.info()
-    launches = (1 if n_runs > 0 else 0) + (G if n_gather > 0 else 0)
+    launches = 1 if lanes_mode else (1 if n_runs > 0 else 0) + (G if n_gather > 0 else 0)
     batch.set_timing(True)
     for _ in range(min(args.steps, 50)):
         step()
@@ -452,7 +471,7 @@ def main():
     if rank == 0:
         detected = [(int(k) - N) * STEP for k in best.cpu().tolist()]
         acc_ok = all(abs(d - thetas[i % D]) < 0.5 for i, d in enumerate(detected))  # lib.rs:103-113
-        out = base_record(args, world, value, elapsed, B, A, G, D)
+        out = base_record(args, world, value, elapsed, B, A, G, D, "scan-lane" if lanes_mode else "run-merging")
         if deskew:
             out["deskew_images_per_s"] = deskew["linear"]
             out["deskew"] = {"what": "sweep -> arg-max -> CONTAIN warp of every scan by its detected angle inside the timed "
@@ -460,16 +479,20 @@ def main():
                              "linear_images_per_s": deskew["linear"], "nearest_images_per_s": deskew["nearest"],
                              "linear_over_value": deskew["linear"] / value, "nearest_over_value": deskew["nearest"] / value,
                              "warp_hbm_bytes_per_scan": float(ROWS * COLS) + deskew["canvas_bytes_per_scan_mean"]}
-        roof = {"kernel": "omr::runs_kernel (run-merging rotate+project, both projections per launch)"
+        roof = {"kernel": "omr::slane_kernel (scan-lane rotate+project: 64 scans per wavefront, geometry as wave-uniform "
+                          "programs, both projections per launch)" if lanes_mode
+                          else "omr::runs_kernel (run-merging rotate+project, both projections per launch)"
                           if n_runs > 0 else "omr::sweep_lds_kernel (gather rotate+project)",
                 "kernel_ms": kernel_ms, "scans_per_launch": G, "launches_per_group": launches,
                 "sweep_stage_ms_per_scan": stage_ms / G, "kernel_ms_per_8_scans": kernel_ms * 8.0 / G,
                 "launch_groups_timed": k_n,
-                "candidates_run_merged": n_runs, "candidates_gathered": n_gather,
+                "candidates_run_merged": 0 if lanes_mode else n_runs, "candidates_gathered": 0 if lanes_mode else n_gather,
+                "candidates_scan_lane": A if lanes_mode else 0,
                 "algorithmic_bytes_per_launch": algo_bytes, "algorithmic_bytes_per_scan": algo_bytes_scan,
                 "algorithmic_GBps": algo_bytes / kernel_s / 1e9,
                 "algorithmic_note": "SURVEY 8(d) bytes (u8 image streamed once per candidate) / kernel time: a labelled "
-                                    "side figure, not a roofline fraction -- the kernel reads a 1-bit/px image from LDS"}
+                                    "side figure, not a roofline fraction -- the kernel reads a 1-bit/px image, 32 px per "
+                                    "lane-operation"}
         traffic, source = None, None
         sq = None
         if pmc_res and "passes" in pmc_res:
@@ -504,31 +527,41 @@ def main():
         if traffic is not None:
             roof["hbm_measured_GBps"] = traffic / kernel_s / 1e9
             roof["hbm_frac"] = traffic / kernel_s / 1e9 / HBM_PEAK_GBPS
-            roof["compulsory_bytes_per_launch"] = float(G) * (ROWS * ((COLS + 127) // 128 * 16) + A * (ROWS + COLS) * 4)
+            if lanes_mode:
+                # what one launch has to move at least: every strip's program once, the interleaved bit images once, the
+                # row counts (u16 pairs, read-modify-write) and the counter dumps once
+                nw = (COLS + 31) // 32
+                roof["compulsory_bytes_per_launch"] = float(batch.lanes_program_bytes()) + float(G) * (
+                    ROWS * nw * 4 + A * ROWS * 2 * 2 + A * nw * 17 * 4)
+            else:
+                roof["compulsory_bytes_per_launch"] = float(G) * (ROWS * ((COLS + 127) // 128 * 16) + A * (ROWS + COLS) * 4)
         if sq is not None:
             c = sq["per_launch"]
             t_prof = sq["kernel_us_profiled"] * 1e-6  # the counters belong to the profiled launch: use ITS duration
             valu_rate = c["SQ_INSTS_VALU"] / t_prof            # wave-instructions / s
-            valu_peak = N_SIMD * CLOCK_GHZ * 1e9 / VALU_MIX_CYCLES  # at this kernel's measured cycles per instruction
+            valu_peak = N_SIMD * CLOCK_GHZ * 1e9 / VALU_ISSUE_CYCLES  # hardware constant: 2 cycles per wave64 op
             lds_rate = c["SQ_LDS_IDX_ACTIVE"] / t_prof          # LDS-array cycles / s, summed over CUs
             lds_peak = N_CU * CLOCK_GHZ * 1e9
-            roof.update(valu_issue_frac=valu_rate / valu_peak,
-                        valu_issue_frac_at_2_cycles=valu_rate / (N_SIMD * CLOCK_GHZ * 1e9 / VALU_ISSUE_CYCLES),
+            mix = VALU_LANE_MIX_CYCLES if lanes_mode else VALU_MIX_CYCLES
+            roof.update(valu_issue_frac_at_2_cycles=valu_rate / valu_peak,
+                        valu_issue_frac_at_mix=valu_rate / (N_SIMD * CLOCK_GHZ * 1e9 / mix),
+                        valu_mix_cycles=mix,
                         lds_busy_frac=lds_rate / lds_peak,
                         lds_conflict_frac=c["SQ_LDS_BANK_CONFLICT"] / max(1.0, c["SQ_LDS_IDX_ACTIVE"]),
                         sq_counters_per_launch=c, kernel_us_under_profiler=sq["kernel_us_profiled"],
                         valu_insts_per_dst_word=c["SQ_INSTS_VALU"] * 64.0 / (G * A * ROWS * ((COLS + 31) // 32)),
-                        peaks="VALU: %d SIMDs x %.1f GHz / %.2f cycles per wave64 op of this kernel's mix (2 for a plain "
-                              "VOP2: valu_issue_frac_at_2_cycles); LDS: %d CUs x %.1f GHz array cycles (MI355X_MICROARCH.md). "
-                              "The clock the chip holds in this kernel is below the nominal %.1f GHz (SQ_BUSY_CU_CYCLES / 256 / "
-                              "kernel time, profiles/): both fractions are that much higher against the held clock"
-                              % (N_SIMD, CLOCK_GHZ, VALU_MIX_CYCLES, N_CU, CLOCK_GHZ, CLOCK_GHZ))
-            if roof["valu_issue_frac"] >= roof["lds_busy_frac"]:
-                roof.update(bound="valu", achieved=valu_rate / 1e9, peak=valu_peak / 1e9, unit="G wave-instr/s",
-                            frac=valu_rate / valu_peak)
-            else:
-                roof.update(bound="lds", achieved=lds_rate / 1e9, peak=lds_peak / 1e9, unit="G LDS-array cycles/s",
-                            frac=lds_rate / lds_peak)
+                        peaks="frac / peak / bound are priced against hardware constants only (round-3 advice): VALU = %d SIMDs "
+                              "x %.1f GHz / 2 cycles per wave64 op; LDS = %d CUs x %.1f GHz array cycles; HBM = %.0f GB/s "
+                              "(MI355X_MICROARCH.md).  valu_issue_frac_at_mix prices the same instruction count at the issue "
+                              "cost of THIS kernel's opcodes (%.2f cycles: v_alignbit / v_and_or / v_bitop3 / v_bcnt are "
+                              "4-cycle VOP3 forms, profiles/r02_valu_issue.md) -- a side figure"
+                              % (N_SIMD, CLOCK_GHZ, N_CU, CLOCK_GHZ, HBM_PEAK_GBPS, mix))
+            cands = [("valu", roof["valu_issue_frac_at_2_cycles"], valu_rate / 1e9, valu_peak / 1e9, "G wave-instr/s"),
+                     ("lds", roof["lds_busy_frac"], lds_rate / 1e9, lds_peak / 1e9, "G LDS-array cycles/s")]
+            if traffic is not None:
+                cands.append(("hbm", roof["hbm_frac"], roof["hbm_measured_GBps"], HBM_PEAK_GBPS, "GB/s"))
+            b = max(cands, key=lambda t: t[1])
+            roof.update(bound=b[0], frac=b[1], achieved=b[2], peak=b[3], unit=b[4])
         elif traffic is not None:
             # no SQ counters: fall back to the measured HBM fraction (<= 1 by construction)
             roof.update(bound="hbm", achieved=roof["hbm_measured_GBps"], peak=HBM_PEAK_GBPS, unit="GB/s",

@@ -214,6 +214,12 @@ int omr_slane_strip_program(int32_t rows, int32_t cols, const double *fwd_M, int
  * 2480x3508 with 400 candidates).  0 switches back.  OMR_ERR_NOTIMPL, context unchanged, when a candidate does not
  * fit the scheme (beyond about +-10 degrees at unit scale, or more than 4078 rows). */
 int omr_batch_set_lanes(omr_batch_ctx *ctx, int32_t max_scans_per_launch);
+/* Bytes of programs the context's scan-lane plan holds in HBM, its (candidate, strip) tasks, scans per launch
+ * (0 = the context is on the run-merging path).  Pointers may be NULL. */
+int omr_batch_lanes_info(omr_batch_ctx *ctx, int64_t *program_bytes, int32_t *tasks, int32_t *scans_per_launch);
+/* Inspection: with on != 0 a launch leaves its row counts in the scratch set (needed by
+ * omr_batch_lanes_projections); by default they are cleared behind the std-dev kernel, off the sweep's stream. */
+int omr_batch_lanes_keep(omr_batch_ctx *ctx, int32_t on);
 /* The integer projections one scan / candidate of the last scan-lane launch left in scratch set `set` (0 for the
  * first launch of a stream): vproj = cols counts, hproj = rows counts; either may be NULL.  Synchronises. */
 int omr_batch_lanes_projections(omr_batch_ctx *ctx, int32_t set, int32_t scan, int32_t a, uint32_t *vproj,

@@ -1208,6 +1208,29 @@ int omr_batch_set_lanes(omr_batch_ctx *ctx, int32_t max_scans_per_launch)
     return OMR_OK;
 }
 
+// Inspection switch: launches leave their row counts in the scratch set (omr_batch_lanes_projections reads them)
+// instead of clearing them behind the std-dev kernel; the next launch on that set then clears them first.
+int omr_batch_lanes_keep(omr_batch_ctx *ctx, int32_t on)
+{
+    if (!ctx || ctx->lanes <= 0) return fail(OMR_ERR_BADARG, "the context is not in scan-lane mode");
+    int rc = omr_batch_sync(ctx);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    for (auto &sc : ctx->slane_scratch) sc->keep_rows = on != 0;
+    return OMR_OK;
+}
+
+// What the scan-lane plan of a context holds: bytes of programs in HBM, (candidate, strip) tasks, scans per launch.
+int omr_batch_lanes_info(omr_batch_ctx *ctx, int64_t *program_bytes, int32_t *tasks, int32_t *scans_per_launch)
+{
+    if (!ctx) return fail(OMR_ERR_BADARG, "null ctx");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    if (program_bytes) *program_bytes = ctx->slane.built ? ctx->slane.prog_dwords * 4 : 0;
+    if (tasks) *tasks = ctx->slane.built ? (int32_t)ctx->slane.tasks.size() : 0;
+    if (scans_per_launch) *scans_per_launch = ctx->lanes;
+    return OMR_OK;
+}
+
 // Integer projections of one scan and candidate as the LAST scan-lane launch of scratch set `set` left them (for
 // tests and inspection): vproj cols u32, hproj rows u32.  Synchronises the context.
 int omr_batch_lanes_projections(omr_batch_ctx *ctx, int32_t set, int32_t scan, int32_t a, uint32_t *vproj, uint32_t *hproj)
@@ -1219,6 +1242,8 @@ int omr_batch_lanes_projections(omr_batch_ctx *ctx, int32_t set, int32_t scan, i
     OMR_HIP(hipSetDevice(ctx->tables.device));
     if (set < 0 || set >= (int)ctx->slane_scratch.size() || scan < 0 || scan >= ctx->lanes || a < 0 || a >= ctx->slane.A)
         return fail(OMR_ERR_BADARG, "set / scan / candidate out of range");
+    if (hproj && !ctx->slane_scratch[(size_t)set]->keep_rows)
+        return fail(OMR_ERR_BADARG, "row counts are cleared after every launch: call omr_batch_lanes_keep(ctx, 1) first");
     const SlaneScratch &s = *ctx->slane_scratch[(size_t)set];
     const SlanePlan &p = ctx->slane;
     const size_t nscp = (size_t)s.nsg * SL_LANES;

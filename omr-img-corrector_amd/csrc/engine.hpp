@@ -158,6 +158,7 @@ struct SlanePlan {
 };
 struct SlaneScratch {
     int nsg = 0;  // scan groups of 64 scans a launch may carry
+    bool keep_rows = false, rows_dirty = false;  // inspection: leave the row counts in place after a launch
     DevBuf bits, hrows, vproj, planes, descs, vsd, hsd, best, guard;
     int create(const SlanePlan &p, int groups);
 };

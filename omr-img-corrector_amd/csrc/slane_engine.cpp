@@ -108,6 +108,7 @@ int SlaneScratch::create(const SlanePlan &p, int groups)
     OMR_HIP(bits.alloc(bits_b));
     OMR_HIP(hipMemset(bits.p, 0, bits_b));  // entry 0 and the guard columns stay zero for good
     OMR_HIP(hrows.alloc(sizeof(uint32_t) * (size_t)p.A * (p.nrec / 2) * nscp));  // two records per dword
+    OMR_HIP(hipMemset(hrows.p, 0, sizeof(uint32_t) * (size_t)p.A * (p.nrec / 2) * nscp));  // every launch leaves them zero again
     OMR_HIP(guard.alloc(sizeof(int32_t)));
     OMR_HIP(hipMemset(guard.p, 0, sizeof(int32_t)));
     OMR_HIP(vproj.alloc(sizeof(uint32_t) * (size_t)p.A * g.cols * nscp));
@@ -165,7 +166,10 @@ int slane_enqueue(const SlanePlan &p, SlaneScratch &s, const uint8_t *d_img, int
     if (step < p.g.cols) return fail(OMR_ERR_BADARG, "step_bytes %lld < cols %d", (long long)step, p.g.cols);
     const int used = (nscans + SL_LANES - 1) / SL_LANES;  // scan groups that hold scans; the descriptors are laid out for s.nsg
     const size_t nscp = (size_t)s.nsg * SL_LANES;
-    OMR_HIP(hipMemsetAsync(s.hrows.p, 0, sizeof(uint32_t) * (size_t)p.A * (p.nrec / 2) * nscp, stream));
+    if (s.rows_dirty) {  // the previous launch was asked to keep its row counts (omr_batch_lanes_keep)
+        OMR_HIP(hipMemsetAsync(s.hrows.p, 0, sizeof(uint32_t) * (size_t)p.A * (p.nrec / 2) * nscp, stream));
+        s.rows_dirty = false;
+    }
     OMR_HIP(launch_slane_pack(d_img, scan_stride, step, p.g, nscans, black_max, s.bits.as<uint32_t>(), stream));
     if (ev0) OMR_HIP(hipEventRecord(ev0, stream));
     OMR_HIP(launch_slane(s.descs.as<SlaneTask>(), used, ((s.nsg + 3) / 4) * 4, p.A, p.g.NS, s.guard.as<int32_t>(), stream));
@@ -181,6 +185,10 @@ int slane_enqueue(const SlanePlan &p, SlaneScratch &s, const uint8_t *d_img, int
     OMR_HIP(launch_slane_stddev(s.vproj.as<uint32_t>(), s.hrows.as<uint32_t>(), p.A, p.g.cols, p.g.rows, p.nrec / 2, SL_PRE, used, s.nsg,
                                 nscans, vs, hs, stream));
     if (d_best) OMR_HIP(launch_argmax_path1(vs, hs, p.A, d_best, stream, nscans));
+    // the row counts are accumulated with atomics: cleared here, behind their only reader and off the sweep's stream
+    // (the caller orders the next launch on this scratch set behind this stream's work)
+    if (s.keep_rows) s.rows_dirty = true;
+    else OMR_HIP(hipMemsetAsync(s.hrows.p, 0, sizeof(uint32_t) * (size_t)p.A * (p.nrec / 2) * nscp, stream));
     return OMR_OK;
 }
 

@@ -175,6 +175,15 @@ class Batch:
         """Scan-lane sweep: up to this many scans per launch, 64 scans per wavefront (0 = back to the run-merging path)."""
         check(lib().omr_batch_set_lanes(self.handle, int(max_scans_per_launch)))
 
+    def lanes_keep(self, on=True):
+        """Inspection: launches leave their row counts in place for lanes_projections()."""
+        check(lib().omr_batch_lanes_keep(self.handle, 1 if on else 0))
+
+    def lanes_program_bytes(self):
+        b, t, n = C.c_int64(), C.c_int32(), C.c_int32()
+        check(lib().omr_batch_lanes_info(self.handle, C.byref(b), C.byref(t), C.byref(n)))
+        return b.value
+
     def lanes_projections(self, scan, a, rows, cols, scratch_set=0):
         """(vproj, hproj) of one scan / candidate as the last scan-lane launch left them (tests, inspection)."""
         vp, hp = np.zeros(cols, np.uint32), np.zeros(rows, np.uint32)

@@ -48,6 +48,8 @@ def run_lanes(scans, max_angle, step, lanes, want_proj=()):
     hs = torch.zeros((n, A), dtype=torch.float64, device=dev)
     b = projection.Batch(rows, cols, max_angle, step, n_streams=1)
     b.set_lanes(lanes)
+    if want_proj:
+        b.lanes_keep(True)
     b.run_device(buf.data_ptr(), rows * cols, cols, n, 127, best.data_ptr(), vs.data_ptr(), hs.data_ptr())
     b.sync()
     proj = {}
