@@ -202,11 +202,12 @@ int omr_call_pool_stats(int32_t device, int32_t *live_slots, int32_t *idle_slots
  * transfer.rs:459-486) -- is one wave-uniform PROGRAM per (candidate, strip of two word columns), enumerated
  * from warpAffine's integer tables.  This entry point builds one strip's program on the HOST (no GPU needed):
  * n_records rows (pre_rows virtual ones first) of seg_dwords_per_row dwords in the segment stream and of 8 dwords
- * in the fetch stream (layout: csrc/slane.hpp).  NULL output pointers query the sizes.
+ * in the fetch stream (layout: csrc/slane.hpp); guard_cols / guard_rows = the zero guard (word columns, rows) the
+ * program's entry numbers assume around the interleaved bit image.  NULL output pointers query the sizes.
  * OMR_ERR_NOTIMPL when the strip does not fit the scheme (such candidates stay with the run-merging kernel). */
 int omr_slane_strip_program(int32_t rows, int32_t cols, const double *fwd_M, int32_t strip, uint32_t *seg_out,
                             uint32_t *fetch_out, int32_t *seg_dwords_per_row, int32_t *n_records, int32_t *pre_rows,
-                            int32_t *most_segments);
+                            int32_t *most_segments, int32_t *guard_cols, int32_t *guard_rows);
 
 /* Switch a batch context to the scan-lane sweep: every launch then carries up to max_scans_per_launch scans (whole
  * groups of 64, at most 4096), 64 scans per wavefront; results are bit-identical to the run-merging path.  The

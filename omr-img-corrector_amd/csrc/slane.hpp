@@ -8,24 +8,32 @@
 // through the scalar unit; the only per-lane data is the scan's own bits.
 //
 //   bit image  : interleaved, entry E(s, c) = 64 dwords = word column c of source row s of the 64 scans of a
-//                scan group; entry 0 is all zero (dummy fetches), SL_GX zero guard columns left and right
+//                scan group; entry 0 is all zero (dummy fetches); a zero guard of gx word columns and gy rows all round
 //   strip      : SL_K = 2 adjacent destination word columns; a wave owns (scan group, candidate, strip) and
 //                walks ALL destination rows top to bottom
 //   ring       : the wave keeps the source entries it needs in 64 VGPRs: register (s & 15) * 4 + (c - cb(s));
 //                every source row s has its own column base cb(s), chosen by the generator
-//   records    : one per destination row, plus SL_PRE virtual rows ahead of row 0 that only fill the ring and a
-//                virtual rows at the end up to a multiple of 16 (four rows per turn, row counts flushed every 16).
-//                Two streams per strip:
+//   words      : destination word w covers destination columns 32 w - off .. 32 w - off + 31 with off = (32 - cols % 32)
+//                % 32: the row's LAST column is the last bit of the last word, the columns that do not exist are
+//                the first bits of word 0
+//   records    : one per destination row, plus SL_PRE virtual rows ahead of row 0 that only fill the ring and virtual
+//                rows at the end up to a multiple of 64.  Two streams per strip:
 //                  fetch stream, 8 dwords per row: 4 x (E << 8) = the byte offsets of the entries whose loads are
-//                                   ISSUED while this row is swept (0 = the all-zero entry: a dummy), then 4 x
-//                                   (ring register | 0x8000) to COMMIT before this row: where the loads issued
-//                                   SL_AHEAD rows earlier belong (register 64 = dummy; 0x8000 = M0's DST_REL bit)
-//                  segment stream, SL_K words x S x (mask, pk) per row: destination bits `mask` = bits (sh + i) of
-//                                   the register pair (ring[idx + 1] : ring[idx]); pk = sh | idx << 5 | 0x60000
-//                                   (pk >> 5 is M0 for the indexed v_alignbit: index + SRC0_REL | SRC1_REL; pk
-//                                   itself is its shift operand), the first pk of a word also carries its
-//                                   segment count n << 24
-//                S = 2 / 4 / 8 slots per word (class 0 / 1 / 2: 8 / 16 / 32 dwords per row), chosen per strip
+//                                   ISSUED while this row is swept (0 = the all-zero entry: a dummy), then 2 dwords
+//                                   = 4 x u16 (ring register | 0x8000) to COMMIT before this row: where the loads
+//                                   issued SL_AHEAD rows earlier belong (register 65 = dummy; 0x8000 = M0's DST_REL
+//                                   bit), then 2 unused dwords
+//                  segment stream, SL_K words x S dwords per row.  A word is assembled from its segments in
+//                                   increasing bit order by funnel shifts, no masks:
+//                                     X = (ring[idx + 1] : ring[idx]) >> sh      (the segment's bits, bit 0 first)
+//                                     first segment : D = X << q                 (q = 32 - len: top-aligned, zeros below)
+//                                     others        : D = (X : D) >> q           (q = len: X's low bits enter at the top)
+//                                   so a word whose first columns are white (or do not exist) simply has fewer bits,
+//                                   and white runs elsewhere are segments that read ring register 64, which holds 0.
+//                                   pk = sh | idx << 5 | 0x60000 | q << 21 (pk >> 5 is M0 for the indexed v_alignbit:
+//                                   index + SRC0_REL | SRC1_REL; pk itself is its shift operand; pk >> 21 the second
+//                                   shift), the first pk of a word also carries its segment count n << 26 (n >= 1)
+//                S = 2 / 4 / 8 slots per word (class 0 / 1 / 2: 4 / 8 / 16 dwords per row), chosen per strip
 #pragma once
 #include <stdint.h>
 
@@ -39,27 +47,40 @@ constexpr int SL_RING_COLS = 4;
 constexpr int SL_FETCH = 4;                             // loads per row
 constexpr int SL_FREC = 8;                              // dwords per row of the fetch stream
 constexpr int SL_AHEAD = 4;                             // rows between a load and its commit
-constexpr int SL_DUMMY = SL_RING_ROWS * SL_RING_COLS;  // ring register that swallows dummy fetches
+constexpr int SL_ZERO = SL_RING_ROWS * SL_RING_COLS;   // ring register that holds 0 (white runs read it)
+constexpr int SL_DUMMY = SL_ZERO + 1;                   // register that swallows dummy fetches
 constexpr uint32_t SL_PK_MODE = 0x60000u;               // pk >> 5 -> M0[13:12]: SRC0_REL | SRC1_REL
 constexpr uint32_t SL_COMMIT_MODE = 0x8000u;            // M0[15]: DST_REL
 constexpr int SL_PRE = 24;                              // virtual rows ahead of row 0
-constexpr int SL_GX = 4;                                // zero guard word columns on either side
+constexpr int SL_QSHIFT = 21, SL_NSHIFT = 26;           // pk fields: second shift, segment count
+constexpr int SL_GX = 4;                                // least zero guard, word columns on either side
 constexpr int SL_LANES = 64;
 constexpr int SL_DUMP = 17;                             // registers a wave dumps per word: planes p0..p11, carries c0..c4
 
 struct SlaneGeom {
     int rows = 0, cols = 0;  // image
-    int NW = 0;              // words per row
-    int colsG = 0;           // NW + 2 SL_GX
+    int off = 0;             // columns that do not exist at the start of destination word 0
+    int NW = 0;              // destination words per row (= source word columns)
+    int gx = SL_GX, gy = 0;  // zero guard around the bit image: word columns left / right, rows above / below.  A sample
+                             // that falls outside the image (warpAffine: BORDER_CONSTANT white) reads the guard's zeros
+                             // through the same run as its neighbours, so border words need no extra segments
+    int colsG = 0, rowsG = 0;
     int NS = 0;              // strips
-    int64_t entries = 0;     // 1 + rows * colsG
-    void set(int r, int c)
+    int64_t entries = 0;     // 1 + rowsG * colsG
+    void set(int r, int c, int guard_cols = SL_GX, int guard_rows = 0)
     {
-        rows = r, cols = c, NW = (c + 31) / 32, colsG = NW + 2 * SL_GX, NS = (NW + SL_K - 1) / SL_K;
-        entries = 1 + (int64_t)r * colsG;
+        rows = r, cols = c, NW = (c + 31) / 32, off = (32 - c % 32) % 32, NS = (NW + SL_K - 1) / SL_K;
+        gx = guard_cols < SL_GX ? SL_GX : guard_cols, gy = guard_rows < 0 ? 0 : guard_rows;
+        colsG = NW + 2 * gx, rowsG = rows + 2 * gy;
+        entries = 1 + (int64_t)rowsG * colsG;
     }
-    int64_t entry(int s, int c) const { return 1 + (int64_t)s * colsG + (c + SL_GX); }
+    int64_t entry(int s, int c) const { return 1 + (int64_t)(s + gy) * colsG + (c + gx); }
 };
+
+// how far the samples of a candidate reach outside the image: word columns / rows of guard it needs (from the four
+// corners: the fixed-point map is monotone in x and in y)
+void slane_guard_need(const int32_t *ad, const int32_t *bd, const int32_t *x0, const int32_t *y0, int rows, int cols, int *gx,
+                      int *gy);
 
 struct SlaneStrip {     // per (candidate, strip)
     int64_t seg_offset; // of the segment stream, in dwords from the program base (a multiple of 64)
@@ -69,14 +90,16 @@ struct SlaneStrip {     // per (candidate, strip)
 };
 
 inline int slane_slots(int cls) { return 2 << cls; }
-inline int slane_seg_dwords(int cls) { return SL_K * 2 * slane_slots(cls); }  // per row
+inline int slane_seg_dwords(int cls) { return SL_K * slane_slots(cls); }  // per row
 inline int slane_class(int most) { return most <= 2 ? 0 : most <= 4 ? 1 : most <= 8 ? 2 : -1; }
-inline int slane_records(int rows) { return (SL_PRE + rows + 15) & ~15; }  // row counts leave in blocks of 16 rows
+inline int slane_records(int rows) { return (SL_PRE + rows + 63) & ~63; }  // the kernel keeps only the rows LEFT: phases are taken modulo 64
 
 // warpAffine's integer tables of one candidate on the host (the expressions of tables_kernel, kernels.hip;
 // built -ffp-contract=off): adelta / bdelta per column, (X0, Y0) per row with round_delta = 512
 void slane_host_tables(const double Minv[6], int rows, int cols, std::vector<int32_t> &ad, std::vector<int32_t> &bd,
                        std::vector<int32_t> &x0, std::vector<int32_t> &y0);
+
+void slane_null_program(int nrec, int cls, uint32_t *seg, uint32_t *fet);  // empty words, nothing to fetch
 
 // Pass 1: the most segments a word of strip `strip` needs, or -1 when the strip does not fit (a source row
 // that needs more than SL_RING_COLS word columns, more than 8 segments).
@@ -113,7 +136,7 @@ hipError_t launch_slane_pack(const uint8_t *d_img, int64_t scan_stride, int64_t 
 // nsg_used = scan groups that carry scans in this launch, nsg = scan groups the scratch (and its descriptors) is laid out for
 hipError_t launch_slane(const SlaneTask *d_descs, int nsg_used, int nsgp, int A, int NS, int32_t *d_guard, hipStream_t s);
 hipError_t launch_slane_vproj(const uint32_t *d_planes, const int32_t *d_tasks, int ntasks, int nsg_used, int nsg, int NS,
-                              int cols, int nrec, uint32_t *d_vproj, hipStream_t s);
+                              int cols, int off, int nrec, uint32_t *d_vproj, hipStream_t s);
 hipError_t launch_slane_stddev(const uint32_t *d_vproj, const uint32_t *d_hproj, int A, int cols, int rows, int hpairs_per_cand,
                                int hrow0, int nsg_used, int nsg, int nscans, double *d_v_sd, double *d_h_sd, hipStream_t s);
 }  // namespace omr

@@ -22,7 +22,18 @@ int SlanePlan::build(const SweepTables &t)
 {
     const SweepDims &d = t.dims;
     if (d.rows + SL_PRE + 1 >= 4096) return fail(OMR_ERR_NOTIMPL, "scan-lane sweep: more than 4078 rows (12 counter planes)");
-    g.set(d.rows, d.cols);
+    // the zero guard around the bit images: what the steepest candidate reaches outside the image
+    int gx = 0, gy = 0;
+    {
+        std::vector<int32_t> ad, bd, x0, y0;
+        for (int a = 0; a < d.A; a++) {
+            int cx, cy;
+            slane_host_tables(&t.host_minv[6 * (size_t)a], d.rows, d.cols, ad, bd, x0, y0);
+            slane_guard_need(ad.data(), bd.data(), x0.data(), y0.data(), d.rows, d.cols, &cx, &cy);
+            gx = std::max(gx, cx), gy = std::max(gy, cy);
+        }
+    }
+    g.set(d.rows, d.cols, gx, gy);
     A = d.A;
     nrec = slane_records(d.rows);
     const int NS = g.NS, T = host_threads();
@@ -72,9 +83,7 @@ int SlanePlan::build(const SweepTables &t)
     prog_dwords = off + 256;  // the kernel reads one record past a stream's last one
     std::vector<uint32_t> host((size_t)prog_dwords, 0u);
     pass(true, host.data());
-    for (int64_t i = 0; i < (int64_t)nrec * slane_seg_dwords(0); i += 2) host[(size_t)(null_seg + i + 1)] = SL_PK_MODE;
-    for (int64_t i = 0; i < (int64_t)nrec * SL_FREC; i++)
-        host[(size_t)(null_fet + i)] = (i % SL_FREC) < SL_FETCH ? 0u : ((uint32_t)SL_DUMMY | SL_COMMIT_MODE);
+    slane_null_program(nrec, 0, host.data() + null_seg, host.data() + null_fet);
     if (bad.load()) return fail(OMR_ERR_NOTIMPL, "a strip's ring schedule does not fit (16 source rows x 4 word columns)");
     OMR_HIP(prog.alloc(sizeof(uint32_t) * (size_t)prog_dwords));
     OMR_HIP(hipMemcpy(prog.p, host.data(), sizeof(uint32_t) * (size_t)prog_dwords, hipMemcpyHostToDevice));
@@ -180,7 +189,7 @@ int slane_enqueue(const SlanePlan &p, SlaneScratch &s, const uint8_t *d_img, int
         stream = post_stream;
     }
     OMR_HIP(launch_slane_vproj(s.planes.as<uint32_t>(), p.d_tasks.as<int32_t>(), (int)p.tasks.size(), used, s.nsg, p.g.NS, p.g.cols,
-                               p.nrec, s.vproj.as<uint32_t>(), stream));
+                               p.g.off, p.nrec, s.vproj.as<uint32_t>(), stream));
     double *vs = d_v_sd ? d_v_sd : s.vsd.as<double>(), *hs = d_h_sd ? d_h_sd : s.hsd.as<double>();
     OMR_HIP(launch_slane_stddev(s.vproj.as<uint32_t>(), s.hrows.as<uint32_t>(), p.A, p.g.cols, p.g.rows, p.nrec / 2, SL_PRE, used, s.nsg,
                                 nscans, vs, hs, stream));

@@ -31,47 +31,93 @@ void slane_host_tables(const double M[6], int rows, int cols, std::vector<int32_
     }
 }
 
+void slane_guard_need(const int32_t *ad, const int32_t *bd, const int32_t *x0, const int32_t *y0, int rows, int cols, int *gx,
+                      int *gy)
+{
+    int mnx = 0, mxx = cols - 1, mny = 0, mxy = rows - 1;
+    const int xs[2] = {0, cols - 1}, ys[2] = {0, rows - 1};
+    for (int i = 0; i < 2; i++)
+        for (int j = 0; j < 2; j++) {
+            const int sx = (x0[ys[j]] + ad[xs[i]]) >> 10, sy = (y0[ys[j]] + bd[xs[i]]) >> 10;
+            mnx = std::min(mnx, sx), mxx = std::max(mxx, sx), mny = std::min(mny, sy), mxy = std::max(mxy, sy);
+        }
+    const int64_t ox = std::max<int64_t>(-(int64_t)mnx, (int64_t)mxx - (cols - 1)), oy = std::max<int64_t>(-(int64_t)mny, (int64_t)mxy - (rows - 1));
+    // (a map that samples far outside the image -- a magnifying or translating matrix -- gets the cap: what lies beyond
+    // the guard is swept as white runs)
+    *gx = (int)std::min<int64_t>((ox + 31) / 32 + 2, 64);
+    *gy = (int)std::min<int64_t>(oy + 2, 2048);
+}
+
+// The empty program: every word = one white run of 32 bits (first segment: 0 << 0), the other slots no-ops (0 bits
+// shifted in from the zero register), nothing to fetch, dummy commits.
+void slane_null_program(int nrec, int cls, uint32_t *seg, uint32_t *fet)
+{
+    const int RD = slane_seg_dwords(cls), S = slane_slots(cls);
+    const uint32_t white = ((uint32_t)SL_ZERO << 5) | SL_PK_MODE | (1u << SL_NSHIFT), pad = ((uint32_t)SL_ZERO << 5) | SL_PK_MODE;
+    for (size_t q = 0; q < (size_t)nrec; q++)
+        for (int k = 0; k < SL_K; k++)
+            for (int j = 0; j < S; j++) seg[q * RD + (size_t)k * S + j] = j == 0 ? white : pad;
+    const uint32_t nocommit = (uint32_t)SL_DUMMY | SL_COMMIT_MODE;
+    for (size_t q = 0; q < (size_t)nrec; q++) {
+        uint32_t *f = fet + q * SL_FREC;
+        f[0] = f[1] = f[2] = f[3] = 0u;
+        f[4] = f[5] = nocommit | (nocommit << 16);
+        f[6] = f[7] = 0u;
+    }
+}
+
 namespace {
 
 struct Seg {
-    int32_t s;      // source row
-    int32_t base;   // source column of destination bit 0 of the word (sx - i): 32 c + sh
-    uint32_t mask;  // destination bits
+    int32_t s;     // source row; -1 = a white run (reads the zero register)
+    int32_t src;   // source column of the run's first bit
+    int32_t len;   // bits
 };
 constexpr int MAXSEG = 8;
 
 inline int floor_div32(int v) { return v >= 0 ? v >> 5 : -((-v + 31) >> 5); }
 
-// the segments of destination word w of row r; -1 when there are more than MAXSEG
+// The runs of destination word w of row r in increasing bit order.  A white run at the START of the word is left out
+// (the first segment is placed top-aligned with zeros below, slane.hpp); a word that is white altogether is one white
+// run of 32 bits.  Returns the number of runs, -1 when there are more than MAXSEG.
 inline int word_segments(const SlaneGeom &g, const int32_t *ad, const int32_t *bd, int32_t X0, int32_t Y0, int w, Seg *out)
 {
     int n = 0;
-    if (w >= g.NW) return 0;
-    const int xe = g.cols - 32 * w < 32 ? g.cols - 32 * w : 32;
-    for (int i = 0; i < xe; i++) {
-        const int x = 32 * w + i;
-        const int sx = (X0 + ad[x]) >> 10, sy = (Y0 + bd[x]) >> 10;
-        if ((unsigned)sx >= (unsigned)g.cols || (unsigned)sy >= (unsigned)g.rows) continue;  // border: white
-        const int base = sx - i;
-        int j = n - 1;
-        while (j >= 0 && !(out[j].s == sy && out[j].base == base)) j--;
-        if (j < 0) {
-            if (n == MAXSEG) return -1;
-            j = n++;
-            out[j].s = sy, out[j].base = base, out[j].mask = 0;
+    int cur_s = -2, cur_base = 0;  // run under construction: source row (-1 white), sx - i
+    bool leading = true;
+    for (int i = 0; i < 32; i++) {
+        const int x = 32 * w - g.off + i;
+        int sy = -1, base = 0;
+        if (w < g.NW && x >= 0 && x < g.cols) {
+            const int sx = (X0 + ad[x]) >> 10, yy = (Y0 + bd[x]) >> 10;
+            // inside the image, or inside its zero guard (BORDER_CONSTANT white = the guard's zeros, read through the
+            // same run); beyond the guard: a white run.  Source rows are kept as row + gy (never negative).
+            if (sx >= -32 * (g.gx - 1) && sx < g.cols + 32 * (g.gx - 1) && yy >= -g.gy && yy < g.rows + g.gy) sy = yy + g.gy, base = sx - i;
         }
-        out[j].mask |= 1u << i;
+        if (leading && sy < 0) continue;  // white bits at the start of the word need no segment
+        leading = false;
+        if (n > 0 && cur_s == sy && (sy < 0 || cur_base == base)) {
+            out[n - 1].len++;
+        } else {
+            if (n == MAXSEG) return -1;
+            out[n].s = sy, out[n].src = sy < 0 ? 0 : base + i, out[n].len = 1;
+            cur_s = sy, cur_base = base;
+            n++;
+        }
+    }
+    if (n == 0) {  // all white
+        out[0].s = -1, out[0].src = 0, out[0].len = 32;
+        n = 1;
     }
     return n;
 }
 
-// word columns a segment touches: lo always (its register is addressed), hi when a selected bit comes from it
+// word columns a run touches: lo always (its register is addressed), hi when one of its bits comes from it
 inline void seg_columns(const Seg &q, int &c, int &chi)
 {
-    c = floor_div32(q.base);
-    const int sh = q.base - 32 * c;
-    const int top = 31 - __builtin_clz(q.mask);
-    chi = (sh + top >= 32) ? c + 1 : c;
+    c = floor_div32(q.src);
+    const int sh = q.src - 32 * c;
+    chi = (sh + q.len > 32) ? c + 1 : c;
 }
 
 }  // namespace
@@ -79,7 +125,7 @@ inline void seg_columns(const Seg &q, int &c, int &chi)
 int slane_strip_segments(const SlaneGeom &g, const int32_t *ad, const int32_t *bd, const int32_t *x0, const int32_t *y0,
                          int strip)
 {
-    std::vector<int16_t> cmin((size_t)g.rows, 32767), cmax((size_t)g.rows, -32768);
+    std::vector<int16_t> cmin((size_t)g.rowsG, 32767), cmax((size_t)g.rowsG, -32768);
     Seg sg[MAXSEG];
     int most = 0;
     for (int r = 0; r < g.rows; r++)
@@ -88,13 +134,14 @@ int slane_strip_segments(const SlaneGeom &g, const int32_t *ad, const int32_t *b
             if (n < 0) return -1;
             if (n > most) most = n;
             for (int j = 0; j < n; j++) {
+                if (sg[j].s < 0) continue;
                 int c, chi;
                 seg_columns(sg[j], c, chi);
                 if (c < cmin[(size_t)sg[j].s]) cmin[(size_t)sg[j].s] = (int16_t)c;
                 if (chi > cmax[(size_t)sg[j].s]) cmax[(size_t)sg[j].s] = (int16_t)chi;
             }
         }
-    for (int s = 0; s < g.rows; s++)
+    for (int s = 0; s < g.rowsG; s++)
         if (cmax[(size_t)s] >= cmin[(size_t)s] && cmax[(size_t)s] - cmin[(size_t)s] + 1 > SL_RING_COLS) return -1;
     return most;
 }
@@ -105,8 +152,9 @@ bool slane_strip_program(const SlaneGeom &g, const int32_t *ad, const int32_t *b
     const int R = g.rows, RD = slane_seg_dwords(cls), S = slane_slots(cls), NREC = slane_records(R);
     std::vector<Seg> segs((size_t)R * SL_K * MAXSEG);
     std::vector<uint8_t> nseg((size_t)R * SL_K);
-    std::vector<int16_t> cmin((size_t)R, 32767), cmax((size_t)R, -32768);
-    std::vector<int32_t> first((size_t)R, INT32_MAX), last((size_t)R, -1);
+    const int RG = g.rowsG;  // source rows incl. the guard, indexed row + gy
+    std::vector<int16_t> cmin((size_t)RG, 32767), cmax((size_t)RG, -32768);
+    std::vector<int32_t> first((size_t)RG, INT32_MAX), last((size_t)RG, -1);
     for (int r = 0; r < R; r++)
         for (int k = 0; k < SL_K; k++) {
             Seg *sg = &segs[((size_t)r * SL_K + k) * MAXSEG];
@@ -114,6 +162,7 @@ bool slane_strip_program(const SlaneGeom &g, const int32_t *ad, const int32_t *b
             if (n < 0 || n > S) return false;
             nseg[(size_t)r * SL_K + k] = (uint8_t)n;
             for (int j = 0; j < n; j++) {
+                if (sg[j].s < 0) continue;
                 int c, chi;
                 seg_columns(sg[j], c, chi);
                 const size_t s = (size_t)sg[j].s;
@@ -123,18 +172,17 @@ bool slane_strip_program(const SlaneGeom &g, const int32_t *ad, const int32_t *b
                 if (r > last[s]) last[s] = r;
             }
         }
+    slane_null_program(NREC, cls, seg, fet);  // every word one white run, nothing fetched: the real content follows
     // ---- fetch schedule.  Record q (row q - SL_PRE) issues its loads while its row is swept; they are committed to
     // the ring before row q + SL_AHEAD (in between they sit in the wave's landing registers).  Source row s lives in
     // registers (s & 15) * 4 + j: it may be committed only after the last row that reads source row s - 16 is done.
     std::vector<uint8_t> used((size_t)NREC, 0);
-    for (size_t i = 0; i < (size_t)NREC * RD; i += 2) seg[i] = 0u, seg[i + 1] = SL_PK_MODE;  // empty slots
-    for (size_t i = 0; i < (size_t)NREC * SL_FREC; i++) fet[i] = (i % SL_FREC) < SL_FETCH ? 0u : (SL_DUMMY | SL_COMMIT_MODE);
     std::vector<uint8_t> freg((size_t)NREC * SL_FETCH, (uint8_t)SL_DUMMY);  // ring register of every fetch
-    for (int s = 0; s < R; s++) {
+    for (int s = 0; s < RG; s++) {
         if (last[(size_t)s] < 0) continue;
         const int ncols = cmax[(size_t)s] - cmin[(size_t)s] + 1;
         if (ncols > SL_RING_COLS) return false;
-        if (cmin[(size_t)s] < -SL_GX || cmax[(size_t)s] >= g.NW + SL_GX) return false;
+        if (cmin[(size_t)s] < -g.gx || cmax[(size_t)s] >= g.NW + g.gx) return false;
         int lb = -SL_PRE;  // earliest record (as a row number) that may carry this source row
         if (s >= SL_RING_ROWS && last[(size_t)(s - SL_RING_ROWS)] >= 0)
             lb = std::max(lb, last[(size_t)(s - SL_RING_ROWS)] - SL_AHEAD + 1);
@@ -145,24 +193,32 @@ bool slane_strip_program(const SlaneGeom &g, const int32_t *ad, const int32_t *b
             const size_t q = (size_t)(rec + SL_PRE);
             const uint32_t reg = (uint32_t)((s & (SL_RING_ROWS - 1)) * SL_RING_COLS + j);
             freg[q * SL_FETCH + used[q]] = (uint8_t)reg;
-            fet[q * SL_FREC + used[q]++] = (uint32_t)(g.entry(s, cmin[(size_t)s] + j) << 8);
+            fet[q * SL_FREC + used[q]++] = (uint32_t)(g.entry(s - g.gy, cmin[(size_t)s] + j) << 8);
         }
     }
-    for (int q = SL_AHEAD; q < NREC; q++)  // what row q commits = what row q - SL_AHEAD fetched
-        for (int f = 0; f < SL_FETCH; f++) fet[(size_t)q * SL_FREC + SL_FETCH + f] = freg[(size_t)(q - SL_AHEAD) * SL_FETCH + f] | SL_COMMIT_MODE;
+    for (int q = SL_AHEAD; q < NREC; q++) {  // what row q commits = what row q - SL_AHEAD fetched
+        const uint8_t *fr = &freg[(size_t)(q - SL_AHEAD) * SL_FETCH];
+        uint32_t *f = fet + (size_t)q * SL_FREC;
+        f[4] = ((uint32_t)fr[0] | SL_COMMIT_MODE) | (((uint32_t)fr[1] | SL_COMMIT_MODE) << 16);
+        f[5] = ((uint32_t)fr[2] | SL_COMMIT_MODE) | (((uint32_t)fr[3] | SL_COMMIT_MODE) << 16);
+    }
     // ---- the rows' words
     for (int r = 0; r < R; r++)
         for (int k = 0; k < SL_K; k++) {
             const Seg *sg = &segs[((size_t)r * SL_K + k) * MAXSEG];
-            uint32_t *w = seg + (size_t)(r + SL_PRE) * RD + (size_t)k * 2 * S;
-            w[1] |= (uint32_t)nseg[(size_t)r * SL_K + k] << 24;
-            for (int j = 0; j < nseg[(size_t)r * SL_K + k]; j++) {
-                const int c = floor_div32(sg[j].base), sh = sg[j].base - 32 * c;
-                const size_t s = (size_t)sg[j].s;
-                const uint32_t idx = (uint32_t)((sg[j].s & (SL_RING_ROWS - 1)) * SL_RING_COLS + (c - cmin[s]));
-                w[2 * j] = sg[j].mask;
-                w[2 * j + 1] |= (uint32_t)sh | (idx << 5);
+            uint32_t *w = seg + (size_t)(r + SL_PRE) * RD + (size_t)k * S;
+            const int n = nseg[(size_t)r * SL_K + k];
+            for (int j = 0; j < n; j++) {
+                uint32_t idx = SL_ZERO, sh = 0;
+                if (sg[j].s >= 0) {
+                    const int c = floor_div32(sg[j].src);
+                    sh = (uint32_t)(sg[j].src - 32 * c);
+                    idx = (uint32_t)((sg[j].s & (SL_RING_ROWS - 1)) * SL_RING_COLS + (c - cmin[(size_t)sg[j].s]));
+                }
+                const uint32_t q = (uint32_t)(j == 0 ? 32 - sg[j].len : sg[j].len);  // first: shift left; others: funnel
+                w[j] = sh | (idx << 5) | SL_PK_MODE | (q << SL_QSHIFT);
             }
+            w[0] |= (uint32_t)n << SL_NSHIFT;
         }
     return true;
 }

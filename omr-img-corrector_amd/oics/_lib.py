@@ -56,7 +56,7 @@ SYMBOLS = {
     "omr_sweep_plan_set_kernel": (C.c_int, [C.c_void_p, C.c_int32]),
     "omr_sweep_plan_info": (C.c_int, [C.c_void_p, i32p, i32p]),
     "omr_sweep_plan_tables": (C.c_int, [C.c_void_p, C.c_int32, i32p, i32p, i32p, i32p]),
-    "omr_slane_strip_program": (C.c_int, [C.c_int32, C.c_int32, f64p, C.c_int32, u32p, u32p, i32p, i32p, i32p, i32p]),
+    "omr_slane_strip_program": (C.c_int, [C.c_int32, C.c_int32, f64p, C.c_int32, u32p, u32p, i32p, i32p, i32p, i32p, i32p, i32p]),
     "omr_batch_set_lanes": (C.c_int, [C.c_void_p, C.c_int32]),
     "omr_batch_lanes_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), i32p, i32p]),
     "omr_batch_lanes_keep": (C.c_int, [C.c_void_p, C.c_int32]),

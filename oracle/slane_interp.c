@@ -10,19 +10,19 @@
 #define SL_FETCH 4
 #define SL_FREC 8
 #define SL_AHEAD 4
-#define SL_RING 65
+#define SL_RING 66 /* 64 ring registers, register 64 holds 0, register 65 swallows dummy fetches */
 
-/* seg: n_records rows of seg_dwords dwords (K words x S x (mask, pk = sh | idx << 5 | 0x60000)); fet: n_records rows of
- * 8 dwords: 4 byte offsets (E << 8) whose loads are issued in this row, 4 x (ring register | 0x8000) committed before
- * this row (the loads of SL_AHEAD rows earlier, landed in the set of landing registers row % SL_AHEAD);
- * bits: entries[E][lanes] dwords (entry 0 all zero);
+/* seg: n_records rows of seg_dwords dwords (K words x S segments, pk = sh | idx << 5 | 0x60000 | q << 21 | n << 26 in the
+ * first); fet: n_records rows of 8 dwords: 4 byte offsets (E << 8) whose loads are issued in this row, 2 dwords = 4 x u16
+ * (ring register | 0x8000) committed before this row (the loads of SL_AHEAD rows earlier, landed in the set of landing
+ * registers row % SL_AHEAD); bits: entries[E][lanes] dwords (entry 0 all zero);
  * hrow[r * lanes + lane] += black pixels of row r in this strip (r = record - pre_rows, 0 <= r < rows);
- * vcol[(k * 32 + bit) * lanes + lane] += black pixels of column bit of the strip's word k.
+ * vcol[(k * 32 + bit) * lanes + lane] += black pixels of bit `bit` of the strip's word k (the caller maps bits to columns).
  * Returns 0, or -1 when a fetch / register index is out of range or a virtual row carries bits. */
 int orc_slane_run_strip(const uint32_t *seg, int seg_dwords, const uint32_t *fet, int n_records, int pre_rows, int rows,
                         int K, const uint32_t *bits, int64_t n_entries, int lanes, uint32_t *hrow, uint32_t *vcol)
 {
-    const int S = seg_dwords / (2 * K);
+    const int S = seg_dwords / K;
     uint32_t ring[SL_RING][64], T[SL_AHEAD][SL_FETCH][64];
     if (lanes > 64) return -1;
     memset(ring, 0, sizeof ring);
@@ -32,28 +32,30 @@ int orc_slane_run_strip(const uint32_t *seg, int seg_dwords, const uint32_t *fet
         const int set = q % SL_AHEAD;
         /* commit what landed in this row's set of landing registers, then issue this row's loads into it */
         for (int f = 0; f < SL_FETCH; f++) {
-            const uint32_t reg = rec[SL_FETCH + f] & 255u;
-            if (reg >= SL_RING || (rec[SL_FETCH + f] >> 8) != 0x80u) return -1; /* M0 image: register | DST_REL */
+            const uint32_t m0 = (rec[SL_FETCH + f / 2] >> (16 * (f & 1))) & 0xffffu; /* M0 image: register | DST_REL */
+            const uint32_t reg = m0 & 255u;
+            if (reg >= SL_RING || reg == 64u || (m0 >> 8) != 0x80u) return -1;
             memcpy(ring[reg], T[set][f], sizeof(uint32_t) * (size_t)lanes);
         }
         for (int f = 0; f < SL_FETCH; f++) {
             const int64_t e = rec[f] >> 8;
-            if (e >= n_entries) return -1;
+            if (e >= n_entries || (rec[f] & 255u)) return -1;
             memcpy(T[set][f], bits + e * lanes, sizeof(uint32_t) * (size_t)lanes);
         }
         for (int k = 0; k < K; k++) {
-            const uint32_t *w = seg + (int64_t)q * seg_dwords + k * 2 * S;
-            const int n = (int)((w[1] >> 24) & 31u);
-            if (n > S) return -1;
+            const uint32_t *w = seg + (int64_t)q * seg_dwords + k * S;
+            const int n = (int)((w[0] >> 26) & 31u);
+            if (n < 1 || n > S) return -1;
             for (int lane = 0; lane < lanes; lane++) {
-                uint32_t D = 0;
+                uint32_t D = 0xdeadbeefu; /* whatever the register held: the first segment overwrites it */
                 for (int j = 0; j < n; j++) {
-                    const uint32_t mask = w[2 * j], pk = w[2 * j + 1];
-                    const uint32_t idx = (pk >> 5) & 255u, sh = pk & 31u;
-                    if (((pk >> 5) & 0xff00u) != 0x3000u) return -1; /* M0 image: index | SRC0_REL | SRC1_REL */
-                    if (idx + 1 >= SL_RING) return -1;
+                    const uint32_t pk = w[j];
+                    const uint32_t idx = (pk >> 5) & 255u, sh = pk & 31u, qq = (pk >> 21) & 31u;
+                    if (((pk >> 5) & 0xff00u) != 0x3000u || idx + 1 >= SL_RING) return -1; /* M0 image: index | SRC0_REL | SRC1_REL */
                     const uint64_t pair = ((uint64_t)ring[idx + 1][lane] << 32) | ring[idx][lane];
-                    D |= (uint32_t)(pair >> sh) & mask;
+                    const uint32_t X = (uint32_t)(pair >> sh);
+                    if (j == 0) D = X << qq;
+                    else D = (uint32_t)((((uint64_t)X << 32) | D) >> qq);
                 }
                 if (q >= pre_rows && q - pre_rows < rows) hrow[(int64_t)(q - pre_rows) * lanes + lane] += (uint32_t)__builtin_popcount(D);
                 else if (D) return -1; /* virtual rows carry no bits */

@@ -15,40 +15,38 @@ from oracle import oracle as orc
 
 u32p = C.POINTER(C.c_uint32)
 f64p = C.POINTER(C.c_double)
-GX = 4  # slane.hpp SL_GX
-
-
-def interleave(scans):
-    """[lanes] binary u8 images -> entries[1 + rows * colsG][lanes] dwords (entry 0 and the guard columns zero)"""
+def interleave(scans, gx, gy):
+    """[lanes] binary u8 images -> entries[1 + (rows + 2 gy) * colsG][lanes] dwords (entry 0 and the guard zero)"""
     lanes = len(scans)
     rows, cols = scans[0].shape
     NW = (cols + 31) // 32
-    colsG = NW + 2 * GX
-    ent = np.zeros((1 + rows * colsG, lanes), np.uint32)
+    colsG = NW + 2 * gx
+    ent = np.zeros((1 + (rows + 2 * gy) * colsG, lanes), np.uint32)
     for ln, img in enumerate(scans):
         black = np.zeros((rows, NW * 32), np.uint8)
         black[:, :cols] = (img <= 127)
         words = np.packbits(black.reshape(rows, NW, 32), axis=2, bitorder="little").view(np.uint32).reshape(rows, NW)
-        e = ent[1:, ln].reshape(rows, colsG)
-        e[:, GX:GX + NW] = words
+        e = ent[1:, ln].reshape(rows + 2 * gy, colsG)
+        e[gy:gy + rows, gx:gx + NW] = words
     return ent, NW, colsG
 
 
 def strip_program(rows, cols, M, strip):
     L = oics.lib()
-    rd, nrec, pre, most = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
+    rd, nrec, pre, most, gx, gy = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
     Mc = np.ascontiguousarray(M, np.float64)
     rc = L.omr_slane_strip_program(rows, cols, Mc.ctypes.data_as(f64p), strip, None, None, C.byref(rd), C.byref(nrec),
-                                   C.byref(pre), C.byref(most))
+                                   C.byref(pre), C.byref(most), C.byref(gx), C.byref(gy))
     if rc != 0:
         return None
     seg = np.zeros(rd.value * nrec.value, np.uint32)
     fet = np.zeros(8 * nrec.value, np.uint32)
     rc = L.omr_slane_strip_program(rows, cols, Mc.ctypes.data_as(f64p), strip, seg.ctypes.data_as(u32p),
-                                   fet.ctypes.data_as(u32p), C.byref(rd), C.byref(nrec), C.byref(pre), C.byref(most))
+                                   fet.ctypes.data_as(u32p), C.byref(rd), C.byref(nrec), C.byref(pre), C.byref(most), C.byref(gx),
+                                   C.byref(gy))
     if rc != 0:
         return None
-    return (seg, fet), rd.value, nrec.value, pre.value, most.value
+    return (seg, fet, gx.value, gy.value), rd.value, nrec.value, pre.value, most.value
 
 
 def sweep_by_programs(scans, Ms):
@@ -59,9 +57,10 @@ def sweep_by_programs(scans, Ms):
     OL.orc_slane_run_strip.restype = C.c_int
     lanes = len(scans)
     rows, cols = scans[0].shape
-    ent, NW, colsG = interleave(scans)
+    NW = (cols + 31) // 32
     NS = (NW + 1) // 2
     A = len(Ms)
+    ents = {}  # the interleaved bit image per guard size (the single-matrix entry point sizes the guard per matrix)
     vp = np.zeros((lanes, A, cols), np.uint32)
     hp = np.zeros((lanes, A, rows), np.uint32)
     classes = {}
@@ -70,17 +69,23 @@ def sweep_by_programs(scans, Ms):
         for st in range(NS):
             got = strip_program(rows, cols, Ms[a], st)
             assert got is not None, "candidate %d strip %d does not fit: %s" % (a, st, oics.lib().omr_last_error())
-            (seg, fet), rd, nrec, pre, most = got
+            (seg, fet, gx, gy), rd, nrec, pre, most = got
+            if (gx, gy) not in ents:
+                ents[(gx, gy)] = interleave(scans, gx, gy)[0]
+            ent = ents[(gx, gy)]
             classes[rd] = classes.get(rd, 0) + 1
             vcol = np.zeros((64, lanes), np.uint32)
             rc = OL.orc_slane_run_strip(seg.ctypes.data_as(u32p), rd, fet.ctypes.data_as(u32p), nrec, pre, rows, 2,
                                         ent.ctypes.data_as(u32p), ent.shape[0], lanes, hrow.ctypes.data_as(u32p),
                                         vcol.ctypes.data_as(u32p))
             assert rc == 0, "interpreter rejected the program of candidate %d strip %d" % (a, st)
-            c0 = st * 64
-            n = min(64, cols - c0)
-            vp[:, a, c0:c0 + n] = vcol[:n].T
-            assert (vcol[n:] == 0).all()
+            off = (32 - cols % 32) % 32  # slane.hpp: destination word w covers columns 32 w - off ..
+            for b in range(64):
+                col = st * 64 - off + b
+                if 0 <= col < cols:
+                    vp[:, a, col] = vcol[b]
+                else:
+                    assert (vcol[b] == 0).all()
         hp[:, a, :] = hrow.T
     return vp, hp, classes
 
@@ -107,11 +112,11 @@ def test_programs_reproduce_the_oracle_sweep(rows, cols, max_angle, step):
 def test_record_classes_follow_the_angle():
     # small angles need few segments per word (16-dword records), the edge of the headline sweep more
     rows, cols = 400, 640
-    for ang, want in ((0.0, 8), (0.4, 8), (3.0, 16), (10.0, 32)):
+    for ang, want in ((0.0, 4), (0.4, 4), (3.0, 8), (10.0, 16)):
         M = orc.get_rotation_matrix_2d(cols / 2.0, rows / 2.0, ang, 1.0)
         _, rd, nrec, pre, most = strip_program(rows, cols, M, 3)
         assert rd == want, (ang, rd, most)
-        assert nrec == (rows + pre + 15) // 16 * 16
+        assert nrec == (rows + pre + 63) // 64 * 64
 
 
 def test_steep_candidates_are_refused_not_mangled():

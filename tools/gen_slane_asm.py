@@ -1,101 +1,101 @@
 """Generates omr-img-corrector_amd/csrc/slane_asm.inc: the scan-lane sweep's wave program as
-gfx950 assembly text, one variant per segment-slot class (S = 2 / 4 / 8 slots per destination word).
+gfx950 assembly text; ONE asm statement that dispatches on the strip's segment-slot class (S = 2 / 4 / 8 per word).
 
 Why assembly: the wave keeps its source words in a ring of 64 VGPRs addressed through the gfx9 VGPR index mode (M0),
-its segment descriptors (mask, ring index | shift) live in SGPRs filled by s_load_dwordx8/x16, and the column
-counters are a carry-save tree in fixed registers -- none of which HIP C++ can express (no dynamically indexed
-register arrays, no SGPR arrays).  tools/slane_mb.hip / slane_mb2.hip measured the pieces on the hardware.
+its segment descriptors live in SGPRs filled by s_load, and the column counters are a carry-save tree in fixed
+registers -- none of which HIP C++ can express (no dynamically indexed register arrays, no SGPR arrays).
+tools/slane_mb.hip / slane_mb2.hip measured the pieces on the hardware.
 
-Structure of a turn (four destination rows; row r of the turn uses landing set r, segment set r & 1):
-  wait until the loads issued four rows ago have landed (counted: loads return in order, 12 younger ones may fly)
-  -> commit them into the ring (v_mov with DST_REL) -> issue this row's four loads -> request the next row's records
-  -> two words: per segment v_alignbit (SRC0|SRC1_REL) + v_and_or -> row count (pairs of rows meet the workgroup's
-  other strips in LDS, one global atomic per pair row and 16 rows) -> (odd rows) carry-save.
-The scalar unit issues one instruction per SIMD every four cycles, like the vector unit: the first version of this loop
-(63 scalar against 43 vector instructions per row) was SCALAR-bound.  Hence: index mode stays on for the whole loop
-(M0 = 0 = nothing indexed), one s_lshr writes index and mode bits of M0 per segment, fetch offsets and commit
-registers come ready-made from the fetch record, the row counts go through a buffer descriptor with a scalar offset.
+A turn = four destination rows = two batches of two rows.  Scalar loads return out of order, so the only wait there is
+is lgkmcnt(0) -- everything outstanding.  A record requested one row ahead therefore had exactly one row of flight time
+(~100-200 ns against ~400 ns of scalar-cache miss): that wait was the largest single cost of the first version
+(profiles/r04_lanes_ablation.md).  Hence four record sets and ONE wait per TWO rows: while rows 0, 1 are swept from
+sets A, B the records of rows 2, 3 travel into C, D, and vice versa.  Program format v2 makes that fit the SGPR file:
+a segment is ONE dword (slane.hpp) -- no masks, a word is assembled by funnel shifts
+    X = v_alignbit(ring[idx + 1], ring[idx], sh)      (VGPR index mode: M0 = pk >> 5)
+    D = X << q  (first segment)   |   D = v_alignbit(X, D, q)  (the others: X's low q bits enter at the top)
+Per row:  wait until the loads issued four rows ago have landed (counted: vector loads return in order) -> commit them
+into the ring (v_mov with DST_REL) -> issue this row's four loads -> two words -> row count (pairs of rows meet the
+workgroup's other strips in LDS; one global atomic per pair row and 16 rows) -> (odd rows) carry-save column counters.
 
-Register map (fixed; the statement clobbers s0-s13, s16-s100, v1-v127, so lane * 4 arrives in v0):
-  s[0:1] segment stream  s[2:3] fetch stream  s[4:7] row-count buffer descriptor  s[8:11] bit-image descriptor
-  s12 rows left  s13 row-count pitch  s[16:23] / s[24:31] fetch records even / odd row  s32 row-count offset
-  s33 row index  s34 slot class, then segments of the word / scratch  s35 strip's place in its quad  s100 LDS base of the scan group's accumulators  s[36:67] / s[68:99] segment records even / odd row
+Register map (fixed; the statement clobbers s0-s13, s16-s101, v1-v127, so lane * 4 arrives in v0):
+  s[0:1] segment stream  s[2:3] fetch stream  s[4:7] bit-image descriptor  s8 rows left (a multiple of 64 at the start:
+  row phases are taken from -s8)  s9 strip's place in its quad | LDS base of the scan group's accumulators
+  s10 second shift / scratch  s11 segments of the word / scratch  s[14:15] the task (input)
+  segment sets A-D: s[16:31] s[32:47] s[48:63] s[64:79]   fetch offsets A-D: s[80:83] s[84:87] s[88:91] s[92:95]
+  commit pairs A-D: s[96:97] s[98:99] s[100:101] s[12:13]
   v[1:17] / v[18:34] column counters of word 0 / 1: planes p0..p11, pending carries c0..c4
-  v35 LDS address of the turn's row-count slots  v36 odd row's count
-  v37-v40 carries  v41 row count  v42 / v43 odd row's words  v[44:59] four landing sets of four entries
-  v[60:123] ring  v[124:127] aligned windows (v124 doubles as the ring's dummy register 64)
+  v35 LDS address of the turn's row-count slots  v36 odd row's count / fourth aligned window  v37-v40 carries
+  v41 row count  v42 / v43 odd row's words  v[44:59] four landing sets of four entries  v[60:123] ring
+  v124 zero (ring register 64: white runs)  v[125:127] aligned windows (v125 = ring register 65: dummy commits)
 Usage: python tools/gen_slane_asm.py   (writes the .inc; the build only reads it)"""
 import os
 
 ABLATE = os.environ.get("SLANE_ABLATE", "").split(",")  # timing probes only (results are wrong): norec, noatomic, nofetch
-NOP = []  # ["s_nop 0"]: wait state between a scalar write of M0 and the indexed VALU instruction (probe)
 RING = 60
 T0 = 44
-W0 = 124
+XR = (125, 126, 127, 36)       # aligned windows of a group of four segments
 DODD = (42, 43)
-CNT = 41
+CNT, CNT2 = 41, 36
+LADDR = 35
 CARRY = ((37, 38), (39, 40))   # per word: tA, tB
 P = (1, 18)                    # planes p0..p11 of word k
 ST = (13, 30)                  # pending carries c0..c4 of word k
-NST = 5                        # carry-save levels with a parked carry; the carry out of the last ripples into the planes
-LADDR, CNT2 = 35, 36           # LDS address of the turn's row-count slots (lane * 4 + slot offset); odd row's count
+NST = 5
 NDUMP = 34
-FSET = (16, 24)                # fetch record of the even / odd row (8 SGPRs each)
-SSET = (36, 68)                # segment record of the even / odd row
+SEG = (16, 32, 48, 64)         # segment sets A..D
+FOFF = (80, 84, 88, 92)        # fetch offsets of sets A..D
+FCOM = (96, 98, 100, 12)       # commit pairs of sets A..D
 AHEAD = 4
 
 
-def word(out, k, sbase, S, dreg, tag):
-    """segments of word k from the SGPR set at sbase -> VGPR dreg.  The wave stays in VGPR index mode for good: M0 = 0
-    means "nothing indexed"; per segment ONE scalar instruction (s_lshr m0, pk, 5: ring index + SRC0_REL | SRC1_REL)
-    arms the v_alignbit, whose shift operand is pk itself (bits 4:0)."""
+def word(out, k, sset, S, dreg, tag):
+    """segments of word k (pk dwords in s[sset + k * S ...]) -> VGPR dreg"""
     G = {2: 2, 4: 2, 8: 4}[S]
-    m = lambda j: "s%d" % (sbase + k * 2 * S + 2 * j)
-    p = lambda j: "s%d" % (sbase + k * 2 * S + 2 * j + 1)
+    p = lambda j: "s%d" % (sset + k * S + j)
     if S > G:
-        out.append("s_lshr_b32 s34, %s, 24" % p(0))
+        out.append("s_lshr_b32 s11, %s, 26" % p(0))
     for g in range(S // G):
         js = list(range(g * G, (g + 1) * G))
         for n, j in enumerate(js):
-            out.append("s_lshr_b32 m0, %s, 5" % p(j))
-            out += NOP
-            out.append("v_alignbit_b32 v%d, v%d, v%d, %s" % (W0 + n, RING + 1, RING, p(j)))
+            out.append("s_lshr_b32 m0, %s, 5" % p(j))        # ring index + SRC0_REL | SRC1_REL
+            out.append("v_alignbit_b32 v%d, v%d, v%d, %s" % (XR[n], RING + 1, RING, p(j)))
         out.append("s_mov_b32 m0, 0")
-        out += NOP
         for n, j in enumerate(js):
+            out.append("s_lshr_b32 s10, %s, 21" % p(j))
             if g == 0 and n == 0:
-                out.append("v_and_b32 v%d, %s, v%d" % (dreg, m(j), W0 + n))
+                out.append("v_lshlrev_b32 v%d, s10, v%d" % (dreg, XR[n]))
             else:
-                out.append("v_and_or_b32 v%d, v%d, %s, v%d" % (dreg, W0 + n, m(j), dreg))
+                out.append("v_alignbit_b32 v%d, v%d, v%d, s10" % (dreg, XR[n], dreg))
         if g + 1 < S // G:
-            out.append("s_cmp_le_u32 s34, %d" % ((g + 1) * G))
+            out.append("s_cmp_le_u32 s11, %d" % ((g + 1) * G))
             out.append("s_cbranch_scc1 %s" % tag)
     if S > G:
         out.append("%s:" % tag)
 
 
-def commit_and_fetch(out, fset, tset):
-    """loads return in order: at most (AHEAD - 1) * 4 younger loads may still fly when this row's set has landed
-    (row-count atomics in flight only make the wait longer)"""
+def commit_and_fetch(out, x, tset):
+    """x = record set of this row; loads return in order: at most (AHEAD - 1) * 4 younger loads may still fly when this
+    row's landing set has arrived (row-count atomics in flight only make the wait longer)"""
     t = T0 + 4 * tset
     out.append("s_waitcnt vmcnt(%d)" % ((AHEAD - 1) * 4))
-    for f in range(4):
-        out.append("s_mov_b32 m0, s%d" % (fset + 4 + f))   # ring register | DST_REL
-        out += NOP
+    c0, c1 = FCOM[x], FCOM[x] + 1
+    for f, ins in enumerate(("s_and_b32 m0, s%d, 0xffff" % c0, "s_lshr_b32 m0, s%d, 16" % c0,
+                             "s_and_b32 m0, s%d, 0xffff" % c1, "s_lshr_b32 m0, s%d, 16" % c1)):
+        out.append(ins)                                          # ring register | DST_REL
         out.append("v_mov_b32 v%d, v%d" % (RING, t + f))
     out.append("s_mov_b32 m0, 0")
-    out += NOP
     for f in range(4):
         if "nofetch" not in ABLATE:
-            out.append("buffer_load_dword v%d, %%[lane4], s[8:11], s%d offen" % (t + f, fset + f))
+            out.append("buffer_load_dword v%d, %%[lane4], s[4:7], s%d offen" % (t + f, FOFF[x] + f))
 
 
 def row_count(out, d0, d1, odd, second):
     """Row counts leave the wave as PAIRS: even row in the low half of a dword, odd row in the high half (a count is at
-    most 64 per wave and 2480 per row, so neither half can overflow).  The four waves of a workgroup -- four adjacent
-    strips of one candidate and scan group -- add their pairs in LDS (ds_add_u32); every 16 rows the workgroup meets
-    and each wave sends two of the eight accumulated pair rows on with ONE global atomic per pair row (flush()).
-    Without this the kernel issued one global atomic per wave and row: 1.8e9 L2 atomic requests per launch, 25 ms."""
+    most 64 per wave and 2480 per row, so neither half can overflow).  The four waves of a scan group in the workgroup --
+    four adjacent strips -- add their pairs in LDS (ds_add_u32); every 16 rows the workgroup meets and each wave sends
+    two of the eight accumulated pair rows on with ONE global atomic per pair row (flush()).  With one global atomic
+    per wave and row the kernel issued 1.8e9 L2 atomic requests per launch: 25 ms."""
     if not odd:
         out.append("v_bcnt_u32_b32 v%d, v%d, 0" % (CNT, d0))
         out.append("v_bcnt_u32_b32 v%d, v%d, v%d" % (CNT, d1, CNT))
@@ -108,25 +108,29 @@ def row_count(out, d0, d1, odd, second):
 
 
 def flush(out, L):
-    """after rows 12..15 of a block of 16: the workgroup meets, wave w reads pair rows 2w, 2w + 1 of the block's LDS
-    buffer, clears them and adds them to the candidate's row counts in memory (s32 = offset of the block's first pair)"""
-    out += ["s_and_b32 s34, s33, 12", "s_cmp_lg_u32 s34, 12", "s_cbranch_scc1 %s_nofl" % L]
+    """after rows 12..15 of a block of 16: the workgroup meets, the wave of strip place w reads pair rows 2w, 2w + 1 of its
+    scan group's LDS buffer, clears them and adds them to the candidate's row counts in memory.  Segment set C is dead
+    here: it takes the row-count descriptor, the record count and the pitch (s[48:53]) and the scratch (s54-s56)."""
+    out += ["s_sub_u32 s10, 0, s8", "s_and_b32 s10, s10, 12", "s_cmp_lg_u32 s10, 12", "s_cbranch_scc1 %s_nofl" % L]
     if "noatomic" not in ABLATE:
-        out += ["s_waitcnt lgkmcnt(0)", "s_barrier",
-                "s_and_b32 s34, s33, 16", "s_lshl_b32 s34, s34, 7",        # buffer (bit 4 of the row index) * 2048
-                "s_add_u32 s34, s34, s100",                                # + this scan group's accumulators
-                "v_add_u32 v%d, s34, %%[lane4]" % CNT2,
-                "s_lshl_b32 s34, s35, 9",                                  # + wave * 2 slots * 256 bytes
-                "v_add_u32 v%d, s34, v%d" % (CNT2, CNT2),
+        out += ["s_load_dwordx4 s[48:51], %[desc], 16", "s_load_dwordx2 s[52:53], %[desc], 48",
+                "s_waitcnt lgkmcnt(0)", "s_barrier",
+                "s_sub_u32 s54, s52, s8",                                  # row index of the turn (12 mod 16)
+                "s_and_b32 s55, s54, 16", "s_lshl_b32 s55, s55, 7",        # buffer (bit 4 of the row index) * 2048
+                "s_andn2_b32 s56, s9, 3", "s_add_u32 s55, s55, s56",       # + this scan group's accumulators
+                "s_and_b32 s56, s9, 3", "s_lshl_b32 s56, s56, 9", "s_add_u32 s55, s55, s56",  # + place * 2 slots * 256 bytes
+                "v_add_u32 v%d, s55, %%[lane4]" % CNT2,
                 "ds_read_b32 v%d, v%d" % (CARRY[0][0], CNT2), "ds_read_b32 v%d, v%d offset:256" % (CARRY[0][1], CNT2),
                 "v_mov_b32 v%d, 0" % CARRY[1][0],
                 "ds_write_b32 v%d, v%d" % (CNT2, CARRY[1][0]), "ds_write_b32 v%d, v%d offset:256" % (CNT2, CARRY[1][0]),
-                "s_mul_i32 s34, s35, s13", "s_lshl_b32 s34, s34, 1", "s_add_u32 s34, s34, s32",
+                "s_lshr_b32 s54, s54, 4", "s_lshl_b32 s54, s54, 3",        # first pair row of the block
+                "s_and_b32 s56, s9, 3", "s_lshl1_add_u32 s54, s56, s54",   # + 2 * place
+                "s_mul_i32 s54, s54, s53",                                 # * pitch
                 "s_waitcnt lgkmcnt(0)",
-                "buffer_atomic_add v%d, %%[lane4], s[4:7], s34 offen" % CARRY[0][0],
-                "s_add_u32 s34, s34, s13",
-                "buffer_atomic_add v%d, %%[lane4], s[4:7], s34 offen" % CARRY[0][1]]
-    out += ["s_lshl_b32 s34, s13, 3", "s_add_u32 s32, s32, s34", "%s_nofl:" % L]
+                "buffer_atomic_add v%d, %%[lane4], s[48:51], s54 offen" % CARRY[0][0],
+                "s_add_u32 s54, s54, s53",
+                "buffer_atomic_add v%d, %%[lane4], s[48:51], s54 offen" % CARRY[0][1]]
+    out.append("%s_nofl:" % L)
 
 
 def maj(out, d, a, b, c):
@@ -138,9 +142,9 @@ def xor3(out, d, a, b, c):
 
 
 def carry_save(out, L, second):
-    """odd row of a pair: (even row's word in c0, this row's word in DODD) -> the carry-save tree.  Row index = s6 + 1
-    (first pair of the turn: bit 1 clear, the carry is parked in c1) or s6 + 3 (second pair: bit 1 set, c1 is consumed and
-    bits 2.. of s6 say how far the carry travels)."""
+    """odd row of a pair: (even row's word in c0, this row's word in DODD) -> the carry-save tree.  First pair of the turn:
+    bit 1 of the row index is clear, the carry is parked in c1; second pair: c1 is consumed and bits 2.. of the row index
+    (= -rows left, modulo 64) say how far the carry travels."""
     for k in range(2):
         maj(out, CARRY[k][0], P[k], ST[k], DODD[k])
         xor3(out, P[k], P[k], ST[k], DODD[k])
@@ -148,13 +152,13 @@ def carry_save(out, L, second):
         for k in range(2):
             out.append("v_mov_b32 v%d, v%d" % (ST[k] + 1, CARRY[k][0]))
         return
-    cur = 0
     for k in range(2):
         maj(out, CARRY[k][1], P[k] + 1, ST[k] + 1, CARRY[k][0])
         xor3(out, P[k] + 1, P[k] + 1, ST[k] + 1, CARRY[k][0])
     cur = 1
+    out.append("s_sub_u32 s11, 0, s8")
     for lv in range(2, NST):
-        out.append("s_bitcmp1_b32 s33, %d" % lv)
+        out.append("s_bitcmp1_b32 s11, %d" % lv)
         out.append("s_cbranch_scc1 %s_add%d" % (L, lv))
         for k in range(2):
             out.append("v_mov_b32 v%d, v%d" % (ST[k] + lv, CARRY[k][cur]))
@@ -173,49 +177,44 @@ def carry_save(out, L, second):
     out.append("%s_done:" % L)
 
 
-def rec_loads(out, which, S, row, force=False):
-    """request the records of row `row` of the turn (relative to the stream pointers) into set `which`"""
+def rec_loads(out, x, S, row, force=False):
+    """request the records of row `row` of the turn (relative to the stream pointers) into set x"""
     if "norec" in ABLATE and not force:
         return
-    out.append("s_load_dwordx8 s[%d:%d], s[2:3], %d" % (FSET[which], FSET[which] + 7, row * 32))
-    nd = 4 * S
-    byte = row * nd * 4
-    sb = SSET[which]
-    if nd == 8:
-        out.append("s_load_dwordx8 s[%d:%d], s[0:1], %d" % (sb, sb + 7, byte))
-    elif nd == 16:
-        out.append("s_load_dwordx16 s[%d:%d], s[0:1], %d" % (sb, sb + 15, byte))
-    else:
-        out.append("s_load_dwordx16 s[%d:%d], s[0:1], %d" % (sb, sb + 15, byte))
-        out.append("s_load_dwordx16 s[%d:%d], s[0:1], %d" % (sb + 16, sb + 31, byte + 64))
+    nd = 2 * S  # segment dwords per row
+    out.append("s_load_dwordx%d s[%d:%d], s[0:1], %d" % (nd, SEG[x], SEG[x] + nd - 1, row * nd * 4))
+    out.append("s_load_dwordx4 s[%d:%d], s[2:3], %d" % (FOFF[x], FOFF[x] + 3, row * 32))
+    out.append("s_load_dwordx2 s[%d:%d], s[2:3], %d" % (FCOM[x], FCOM[x] + 1, row * 32 + 16))
 
 
 def body(o, S, L):
     """the row loop of one slot class"""
     rec_loads(o, 0, S, 0, True)
     rec_loads(o, 1, S, 1, True)
-    o.append("s_waitcnt lgkmcnt(0)")
+    if "norec" in ABLATE:
+        rec_loads(o, 2, S, 2, True)
+        rec_loads(o, 3, S, 3, True)
     o.append("L%s_loop:" % L)
     # LDS address of this turn's two pair slots: buffer = bit 4 of the row index, slot = bits 3:1
-    o += ["s_bfe_u32 s34, s33, 0x40001", "s_lshl_b32 s34, s34, 8", "s_add_u32 s34, s34, s100", "v_add_u32 v%d, s34, %%[lane4]" % LADDR]
+    o += ["s_sub_u32 s10, 0, s8", "s_bfe_u32 s10, s10, 0x40001", "s_lshl_b32 s10, s10, 8", "s_andn2_b32 s11, s9, 3",
+          "s_add_u32 s10, s10, s11", "v_add_u32 v%d, s10, %%[lane4]" % LADDR]
     for r in range(4):
-        w = r & 1
-        rec_loads(o, w ^ 1, S, r + 1)       # the next row's records travel while this row is swept
-        commit_and_fetch(o, FSET[w], r)
-        d = (ST[0], ST[1]) if w == 0 else DODD
-        word(o, 0, SSET[w], S, d[0], "L%s_r%dw0" % (L, r))
-        word(o, 1, SSET[w], S, d[1], "L%s_r%dw1" % (L, r))
-        row_count(o, d[0], d[1], w == 1, r == 3)
-        if w:
+        if r % 2 == 0:  # a batch of two rows: everything requested two rows ago is here; request the next two rows
+            o.append("s_waitcnt lgkmcnt(0)")
+            rec_loads(o, (r + 2) % 4, S, r + 2)
+            rec_loads(o, (r + 3) % 4, S, r + 3)
+        odd = r & 1
+        commit_and_fetch(o, r, r)
+        d = (ST[0], ST[1]) if not odd else DODD
+        word(o, 0, SEG[r], S, d[0], "L%s_r%dw0" % (L, r))
+        word(o, 1, SEG[r], S, d[1], "L%s_r%dw1" % (L, r))
+        row_count(o, d[0], d[1], odd == 1, r == 3)
+        if odd:
             carry_save(o, "L%s_cs%d" % (L, r), r == 3)
-        if r == 3:
-            flush(o, "L%s" % L)
-            o += ["s_add_u32 s33, s33, 4",
-                  "s_add_u32 s0, s0, %d" % (4 * 4 * S * 4), "s_addc_u32 s1, s1, 0",
-                  "s_add_u32 s2, s2, 128", "s_addc_u32 s3, s3, 0",
-                  "s_sub_u32 s12, s12, 4"]
-        o.append("s_waitcnt lgkmcnt(0)")
-    o += ["s_cmp_lg_u32 s12, 0", "s_cbranch_scc1 L%s_loop" % L]
+    flush(o, "L%s" % L)
+    o += ["s_add_u32 s0, s0, %d" % (4 * 2 * S * 4), "s_addc_u32 s1, s1, 0",
+          "s_add_u32 s2, s2, 128", "s_addc_u32 s3, s3, 0",
+          "s_sub_u32 s8, s8, 4", "s_cmp_lg_u32 s8, 0", "s_cbranch_scc1 L%s_loop" % L]
 
 
 def kernel():
@@ -224,14 +223,14 @@ def kernel():
     VGPR -- a whole wave per SIMD.)"""
     o = []
     U = "%="  # unique label suffix per asm statement
-    o += ["s_load_dwordx8 s[0:7], %[desc], 0", "s_load_dwordx4 s[8:11], %[desc], 32", "s_load_dwordx2 s[12:13], %[desc], 48",
-          "s_load_dword s34, %[desc], 56", "s_load_dword s35, %[desc], 60", "s_load_dword s100, %[desc], 72"]
+    o += ["s_load_dwordx4 s[0:3], %[desc], 0", "s_load_dwordx4 s[4:7], %[desc], 32", "s_load_dword s8, %[desc], 48",
+          "s_load_dword s11, %[desc], 56", "s_load_dword s9, %[desc], 60", "s_load_dword s10, %[desc], 72"]
     for v in range(1, 128):
         o.append("v_mov_b32 v%d, 0" % v)
     o.append("s_waitcnt lgkmcnt(0)")
-    o += ["s_mov_b32 s32, 0", "s_mov_b32 s33, 0"]
-    o += ["s_set_gpr_idx_on s32, gpr_idx(SRC0)", "s_mov_b32 m0, 0"]  # index mode on for good; M0 = 0: nothing indexed
-    o += ["s_cmp_eq_u32 s34, 0", "s_cbranch_scc1 L%s_c0" % U, "s_cmp_eq_u32 s34, 1", "s_cbranch_scc1 L%s_c1" % U]
+    o.append("s_or_b32 s9, s9, s10")
+    o += ["s_set_gpr_idx_on s10, gpr_idx(SRC0)", "s_mov_b32 m0, 0"]  # index mode on for good; M0 = 0: nothing indexed
+    o += ["s_cmp_eq_u32 s11, 0", "s_cbranch_scc1 L%s_c0" % U, "s_cmp_eq_u32 s11, 1", "s_cbranch_scc1 L%s_c1" % U]
     for cls, S in ((2, 8), (1, 4), (0, 2)):
         o.append("L%s_c%d:" % (U, cls))
         body(o, S, "%s_c%d" % (U, cls))
@@ -240,22 +239,24 @@ def kernel():
     # ---- dump the 34 counter registers: [word][p0..p11, c0..c4][lane]
     o.append("L%s_dump:" % U)
     o.append("s_set_gpr_idx_off")
-    o.append("s_load_dwordx2 s[32:33], %[desc], 64")
+    o.append("s_load_dwordx2 s[16:17], %[desc], 64")
     o.append("s_waitcnt vmcnt(0) lgkmcnt(0)")
     for i in range(NDUMP):
         if i and i % 16 == 0:
-            o += ["s_add_u32 s32, s32, 4096", "s_addc_u32 s33, s33, 0"]
-        o.append("global_store_dword %%[lane4], v%d, s[32:33] offset:%d" % (1 + i, (i % 16) * 256))
+            o += ["s_add_u32 s16, s16, 4096", "s_addc_u32 s17, s17, 0"]
+        o.append("global_store_dword %%[lane4], v%d, s[16:17] offset:%d" % (1 + i, (i % 16) * 256))
     o.append("s_waitcnt vmcnt(0)")
     return o
 
 
-CLOB = ['"memory"', '"scc"', '"vcc"', '"m0"'] + ['"s%d"' % i for i in list(range(0, 14)) + list(range(16, 101))] + ['"v%d"' % i for i in range(1, 128)]
+CLOB = ['"memory"', '"scc"', '"vcc"', '"m0"'] + ['"s%d"' % i for i in list(range(0, 14)) + list(range(16, 102))] + \
+       ['"v%d"' % i for i in range(1, 128)]
 
 out = ["// GENERATED by tools/gen_slane_asm.py -- do not edit; see that file for the register map.\n"]
 body_txt = "\\n\\t\"\n    \"".join(kernel())
 out.append("#define SLANE_ASM \\\n    \"%s\\n\\t\"\n" % body_txt.replace("\n", " \\\n"))
 out.append("#define SLANE_ASM_CLOBBERS %s\n" % ", ".join(CLOB))
-path = os.environ.get("SLANE_ASM_OUT") or os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "omr-img-corrector_amd", "csrc", "slane_asm.inc")
+path = os.environ.get("SLANE_ASM_OUT") or os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                                       "omr-img-corrector_amd", "csrc", "slane_asm.inc")
 open(path, "w").write("".join(out))
 print("wrote", path, len(kernel()), "instructions")
