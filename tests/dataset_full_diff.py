@@ -2,7 +2,7 @@
 
   GPU side : tools/dataset_full.py on the GPU box -> part files with one row per case
              (sheet, test_iter_idx, injected, detected, need_check[, input_crc32])
-  oracle   : tests/golden/dataset_full_expected.npz (tests/golden/make_dataset_full.py, CPU): detected-angle f64 bits,
+  oracle   : tests/golden/full/full_run_expected.npz (tests/golden/make_dataset_full.py, CPU): detected-angle f64 bits,
              need_check, projection status and the CRC-32 of the image handed to correct_default, for all
              104 x 900 cases of lib.rs:130-245
 
@@ -19,7 +19,7 @@ import sys
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-EXPECTED = os.path.join(HERE, "golden", "dataset_full_expected.npz")
+EXPECTED = os.path.join(HERE, "golden", "full", "full_run_expected.npz")
 
 
 def load_expected():

@@ -1,4 +1,4 @@
-"""Makes tests/golden/dataset_full_expected.npz: the CPU ORACLE's answer for every case of the reference's enabled
+"""Makes tests/golden/full/full_run_expected.npz: the CPU ORACLE's answer for every case of the reference's enabled
 library test (packages/lib/src/lib.rs:130-245) -- 104 sheets x 900 injected angles (-45.0 .. +44.9 by 0.1,
 lib.rs:153-154) = 93 600 runs of correct_default(45, 0.2, 248, 230, 150.0, 50.0) (lib.rs:192-205).
 
@@ -23,7 +23,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 
-OUT = os.path.join(HERE, "dataset_full_expected.npz")
+OUT = os.path.join(HERE, "full", "full_run_expected.npz")
 IDXS = list(range(-450, 450))
 
 

@@ -153,7 +153,7 @@ def test_full_run_error_cases_are_the_oracles_too(oracle, golden_dir):
             assert not gchk and abs(ang - recorded) < 1e-9 and abs(idx * 0.1 - ang) > 0.5, (sheet, idx, ang, recorded)
 
 
-FULL = os.path.join(HERE, "golden", "dataset_full_expected.npz")
+FULL = os.path.join(HERE, "golden", "full", "full_run_expected.npz")
 
 
 def _full_expected():
@@ -162,7 +162,7 @@ def _full_expected():
 
 
 def test_full_expectation_is_complete_and_reproduces_the_run():
-    """tests/golden/dataset_full_expected.npz (make_dataset_full.py, CPU oracle): all 104 x 900 cases of lib.rs:130-245.
+    """tests/golden/full/full_run_expected.npz (make_dataset_full.py, CPU oracle): all 104 x 900 cases of lib.rs:130-245.
     Its class histogram is the one the GPU run recorded (profiles/r03_dataset_full.md) -- profiles/r04_dataset_diff.md is
     the case-by-case diff of that run against this file: 93 600 of 93 600 identical -- and it agrees with the 936-case
     fixture wherever the two overlap."""
