@@ -226,8 +226,24 @@ int omr_batch_lanes_keep(omr_batch_ctx *ctx, int32_t on);
 int omr_batch_lanes_projections(omr_batch_ctx *ctx, int32_t set, int32_t scan, int32_t a, uint32_t *vproj,
                                 uint32_t *hproj);
 
+/* ---- batches that start in host memory ("wall-clock including H2D"; core/src/main.rs:68-95) --- */
+/* A context for repeated host-memory batches of one shape and sweep: per device the sweep plan (the scan-lane sweep when
+ * the candidates fit it and at least 128 scans per device are expected, else the run-merging path), a pinned ring of three
+ * 64-scan slots and two device stages of one launch (up to 256 scans) each.  n_devices <= 0 = every visible device,
+ * n_devices > omr_device_count() is OMR_ERR_BADARG.  max_scans = the largest n a run may carry. */
+typedef struct omr_host_batch omr_host_batch;
+int omr_host_batch_create(int32_t rows, int32_t cols, uint16_t max_angle, double step, int32_t n_devices,
+                          int32_t max_scans, omr_host_batch **out);
+void omr_host_batch_destroy(omr_host_batch *hb);
+int omr_host_batch_info(const omr_host_batch *hb, int32_t *n_devices, int32_t *scans_per_launch, int32_t *scan_lane);
+/* scans[i] -> device i % n_devices: host memory -> (pageable: copier threads -> pinned ring; source_is_pinned != 0: DMA
+ * straight from the caller's page-locked memory) -> device stage -> sweep; the copy of one launch overlaps the sweep of
+ * the previous one.  Pixels == 0 are black (binarised scans, as omr_sweep_batch).  Outputs as omr_sweep_batch. */
+int omr_host_batch_run(omr_host_batch *hb, const omr_image *scans, int32_t n, int32_t source_is_pinned,
+                       int32_t *best_idx, double *best_angle, double *v_sd_opt, double *h_sd_opt);
+
 /* Host-buffer batch over the visible devices (SURVEY.md 8b `omr_sweep_batch`): scans[i] goes
- * to device i % n_devices (pinned staging ring, copy / sweep overlapped, four scans per launch);
+ * to device i % n_devices (an omr_host_batch made for this one call: plan and ring creation are inside the call);
  * the only "collective" is the host-side gather of the results.  n_devices <= 0 = every visible device;
  * n_devices > omr_device_count() is OMR_ERR_BADARG (never a silent clamp).
  * best_angle[i] = (best_idx[i] - N) * step (projection.rs:189-190). */

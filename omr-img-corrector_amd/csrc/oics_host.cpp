@@ -786,137 +786,19 @@ int omr_get_standard_deviation(const double *v, size_t n, double *out)
     return OMR_OK;
 }
 
-// Host-buffer batch over the visible devices: scan i -> device i % n_devices, one host worker
-// per device, two streams per device; results are gathered on the host (no collective).
+// Host-buffer batch over the visible devices: omr_host_batch (oics_hostbatch.cpp) made for this one call.
 int omr_sweep_batch(const omr_image *scans, int32_t n, uint16_t max_angle, double step, int32_t n_devices,
                     int32_t *best_idx, double *best_angle, double *v_sd_opt, double *h_sd_opt)
 {
     if (!scans || n < 0 || !best_idx) return fail(OMR_ERR_BADARG, "bad batch arguments");
     if (n == 0) return OMR_OK;
-    int ndev = omr_device_count();
-    if (ndev <= 0) return fail(OMR_ERR_GPU, "no usable HIP device (there is no CPU fallback)");
-    // 0 (or less) = every visible device; more than are visible is an error, not a silent clamp: a caller that
-    // asked for 8 devices must not believe it ran on 8
-    if (n_devices > ndev) return fail(OMR_ERR_BADARG, "n_devices exceeds omr_device_count()");
-    if (n_devices <= 0) n_devices = ndev;
-    int N, A = candidate_count(max_angle, step, &N);
-    if (A <= 0) return fail(OMR_ERR_BADARG, "empty candidate range");
-    const int rows = scans[0].rows, cols = scans[0].cols;
-    for (int i = 0; i < n; i++) {
-        int rc = check_image(&scans[i], true);
-        if (rc) return rc;
-        if (scans[i].rows != rows || scans[i].cols != cols)
-            return fail(OMR_ERR_ASSERT, "all scans of a batch must share one size");
-    }
-    std::vector<int> rcs((size_t)n_devices, OMR_OK);
-    std::vector<std::string> errs((size_t)n_devices);
-    // Per device: groups of G scans travel host -> pinned ring (copier threads; the caller's memory is
-    // pageable) -> device slot (async DMA on a copy stream) -> one launch of each kernel for the group
-    // (omr_batch_set_group) with std-dev / arg-max on the post stream.  Two slots keep copy and sweep of
-    // consecutive groups overlapped; results come back once at the end.
-    auto worker = [&](int dv) {
-        auto run = [&]() -> int {
-            OMR_HIP(hipSetDevice(dv));
-            std::vector<int> mine;
-            for (int i = dv; i < n; i += n_devices) mine.push_back(i);
-            const int m = (int)mine.size();
-            if (m == 0) return OMR_OK;
-            const int G = std::min(4, m);
-            omr_batch_ctx *raw = nullptr;
-            int rc = omr_batch_create(rows, cols, max_angle, step, 1.0, dv, 1, &raw);
-            if (rc) return rc;
-            std::unique_ptr<omr_batch_ctx> ctx(raw);
-            if ((rc = omr_batch_set_group(ctx.get(), G))) return rc;
-            const size_t img_bytes = (size_t)rows * cols;
-            struct Pinned {
-                uint8_t *p = nullptr;
-                ~Pinned()
-                {
-                    if (p) (void)hipHostFree(p);
-                }
-            } pin[2];
-            DevBuf dimg[2], dbest, dvs, dhs;
-            hipStream_t copy = nullptr;
-            hipEvent_t ev_copy[2] = {nullptr, nullptr}, ev_used[2] = {nullptr, nullptr};
-            struct Cleanup {
-                hipStream_t *s;
-                hipEvent_t *a, *b;
-                ~Cleanup()
-                {
-                    for (int k = 0; k < 2; k++) {
-                        if (a[k]) (void)hipEventDestroy(a[k]);
-                        if (b[k]) (void)hipEventDestroy(b[k]);
-                    }
-                    if (*s) (void)hipStreamDestroy(*s);
-                }
-            } cleanup{&copy, ev_copy, ev_used};
-            OMR_HIP(hipStreamCreateWithFlags(&copy, hipStreamNonBlocking));
-            for (int k = 0; k < 2; k++) {
-                OMR_HIP(hipHostMalloc((void **)&pin[k].p, img_bytes * G, hipHostMallocDefault));
-                OMR_HIP(dimg[k].alloc(img_bytes * G));
-                OMR_HIP(hipEventCreateWithFlags(&ev_copy[k], hipEventDisableTiming));
-                OMR_HIP(hipEventCreateWithFlags(&ev_used[k], hipEventDisableTiming));
-            }
-            OMR_HIP(dbest.alloc(sizeof(int32_t) * (size_t)m));
-            OMR_HIP(dvs.alloc(sizeof(double) * (size_t)m * A));
-            OMR_HIP(dhs.alloc(sizeof(double) * (size_t)m * A));
-            hipStream_t main_s = ctx->streams[0];
-            for (int j0 = 0, grp = 0; j0 < m; j0 += G, grp++) {
-                const int g = std::min(G, m - j0), k = grp & 1;
-                if (grp >= 2) OMR_HIP(hipEventSynchronize(ev_copy[k]));  // the ring slot's last DMA has read it
-                std::vector<std::thread> cp;
-                for (int z = 0; z < g; z++)
-                    cp.emplace_back([&, z]() {
-                        const omr_image &im = scans[mine[(size_t)j0 + z]];
-                        uint8_t *dst = pin[k].p + (size_t)z * img_bytes;
-                        if (im.step_bytes == cols) {
-                            memcpy(dst, im.data, img_bytes);
-                        } else {
-                            for (int r = 0; r < rows; r++) memcpy(dst + (size_t)r * cols, im.data + (size_t)r * im.step_bytes, (size_t)cols);
-                        }
-                    });
-                for (auto &t : cp) t.join();
-                if (grp >= 2) OMR_HIP(hipStreamWaitEvent(copy, ev_used[k], 0));  // the device slot's last sweep has packed it
-                OMR_HIP(hipMemcpyAsync(dimg[k].p, pin[k].p, img_bytes * g, hipMemcpyHostToDevice, copy));
-                OMR_HIP(hipEventRecord(ev_copy[k], copy));
-                OMR_HIP(hipStreamWaitEvent(main_s, ev_copy[k], 0));
-                rc = omr_batch_run_device(ctx.get(), dimg[k].as<uint8_t>(), (int64_t)img_bytes, cols, g, 0,
-                                          dbest.as<int32_t>() + j0, dvs.as<double>() + (size_t)j0 * A,
-                                          dhs.as<double>() + (size_t)j0 * A);
-                if (rc) return rc;
-                OMR_HIP(hipEventRecord(ev_used[k], main_s));
-            }
-            if ((rc = omr_batch_sync(ctx.get()))) return rc;
-            std::vector<int32_t> hb((size_t)m);
-            OMR_HIP(hipMemcpy(hb.data(), dbest.p, sizeof(int32_t) * (size_t)m, hipMemcpyDeviceToHost));
-            std::vector<double> hv, hh;
-            if (v_sd_opt) {
-                hv.resize((size_t)m * A);
-                OMR_HIP(hipMemcpy(hv.data(), dvs.p, sizeof(double) * hv.size(), hipMemcpyDeviceToHost));
-            }
-            if (h_sd_opt) {
-                hh.resize((size_t)m * A);
-                OMR_HIP(hipMemcpy(hh.data(), dhs.p, sizeof(double) * hh.size(), hipMemcpyDeviceToHost));
-            }
-            for (int j = 0; j < m; j++) {
-                const int i = mine[(size_t)j];
-                best_idx[i] = hb[(size_t)j];
-                if (v_sd_opt) memcpy(v_sd_opt + (size_t)i * A, hv.data() + (size_t)j * A, sizeof(double) * (size_t)A);
-                if (h_sd_opt) memcpy(h_sd_opt + (size_t)i * A, hh.data() + (size_t)j * A, sizeof(double) * (size_t)A);
-            }
-            return OMR_OK;
-        };
-        rcs[dv] = run();
-        if (rcs[dv]) errs[dv] = last_error();
-    };
-    std::vector<std::thread> th;
-    for (int dv = 0; dv < n_devices; dv++) th.emplace_back(worker, dv);
-    for (auto &t : th) t.join();
-    for (int dv = 0; dv < n_devices; dv++)
-        if (rcs[dv]) return fail(rcs[dv], "device %d: %s", dv, errs[dv].c_str());
-    if (best_angle)
-        for (int i = 0; i < n; i++) best_angle[i] = ((double)best_idx[i] - (double)N) * step;  // projection.rs:189-190
-    return OMR_OK;
+    int rc = check_image(&scans[0], true);
+    if (rc) return rc;
+    omr_host_batch *hb = nullptr;
+    if ((rc = omr_host_batch_create(scans[0].rows, scans[0].cols, max_angle, step, n_devices, n, &hb))) return rc;
+    rc = omr_host_batch_run(hb, scans, n, 0, best_idx, best_angle, v_sd_opt, h_sd_opt);
+    omr_host_batch_destroy(hb);
+    return rc;
 }
 
 }  // extern "C"

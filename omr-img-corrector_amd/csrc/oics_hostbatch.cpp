@@ -1,0 +1,238 @@
+// oics_hostbatch.cpp -- batches that start in HOST memory (SURVEY.md 8b `omr_sweep_batch`, 8d's end-to-end figure):
+// a context that owns, per device, the sweep plan, a pinned ring and two device stages, so that the copy of one launch's
+// scans overlaps the sweep of the previous one and nothing is allocated inside a run.
+//
+//   caller's scans (pageable: copier threads -> pinned ring slot of 64 scans; or already pinned: straight from the
+//   caller's memory) --async DMA on a copy stream--> device stage (one launch = up to 256 scans, two stages)
+//   --omr_batch_run_device (scan-lane sweep when the candidates fit it, else the run-merging path)--> results, one
+//   download at the end.  Scan i goes to device i % n_devices; the only "collective" is the host-side gather.
+#include <string.h>
+
+#include <algorithm>
+#include <memory>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/omrdeskew.h"
+#include "engine.hpp"
+
+using namespace omr;
+
+namespace {
+constexpr int HB_CHUNK = 64;    // scans per ring slot / DMA
+constexpr int HB_LAUNCH = 256;  // scans per sweep launch in scan-lane mode (four scan groups: one workgroup row)
+constexpr int HB_SLOTS = 3;
+
+struct HostBatchDev {
+    int dev = 0, launch = 0, cap = 0;
+    bool lanes = false;
+    std::unique_ptr<omr_batch_ctx> ctx;
+    uint8_t *ring[HB_SLOTS] = {nullptr, nullptr, nullptr};
+    DevBuf stage[2], dbest, dvs, dhs;
+    hipStream_t copy = nullptr;
+    hipEvent_t ev_slot[HB_SLOTS] = {nullptr, nullptr, nullptr}, ev_ready[2] = {nullptr, nullptr}, ev_used[2] = {nullptr, nullptr};
+    bool slot_busy[HB_SLOTS] = {false, false, false}, stage_used[2] = {false, false};
+    ~HostBatchDev()
+    {
+        (void)hipSetDevice(dev);
+        for (auto &r : ring)
+            if (r) (void)hipHostFree(r);
+        for (auto e : ev_slot)
+            if (e) (void)hipEventDestroy(e);
+        for (int k = 0; k < 2; k++) {
+            if (ev_ready[k]) (void)hipEventDestroy(ev_ready[k]);
+            if (ev_used[k]) (void)hipEventDestroy(ev_used[k]);
+        }
+        if (copy) (void)hipStreamDestroy(copy);
+    }
+};
+}  // namespace
+
+struct omr_host_batch {
+    int rows = 0, cols = 0, N = 0, A = 0, n_devices = 0;
+    double step = 0;
+    std::vector<std::unique_ptr<HostBatchDev>> devs;
+    std::mutex mu;
+};
+
+extern "C" {
+
+int omr_host_batch_create(int32_t rows, int32_t cols, uint16_t max_angle, double step, int32_t n_devices,
+                          int32_t max_scans, omr_host_batch **out)
+{
+    if (!out || max_scans < 1) return fail(OMR_ERR_BADARG, "bad host-batch arguments");
+    *out = nullptr;
+    int ndev = omr_device_count();
+    if (ndev <= 0) return fail(OMR_ERR_GPU, "no usable HIP device (there is no CPU fallback)");
+    // 0 (or less) = every visible device; more than are visible is an error, not a silent clamp: a caller that asked
+    // for 8 devices must not believe it ran on 8
+    if (n_devices > ndev) return fail(OMR_ERR_BADARG, "n_devices exceeds omr_device_count()");
+    if (n_devices <= 0) n_devices = ndev;
+    std::unique_ptr<omr_host_batch> hb(new omr_host_batch);
+    hb->A = candidate_count(max_angle, step, &hb->N);
+    if (hb->A <= 0) return fail(OMR_ERR_BADARG, "empty candidate range");
+    hb->rows = rows, hb->cols = cols, hb->step = step, hb->n_devices = n_devices;
+    const int per_dev = (max_scans + n_devices - 1) / n_devices;
+    const size_t img = (size_t)rows * cols;
+    NoPoolScope owned;
+    for (int dv = 0; dv < n_devices; dv++) {
+        std::unique_ptr<HostBatchDev> d(new HostBatchDev);
+        d->dev = dv;
+        OMR_HIP(hipSetDevice(dv));
+        omr_batch_ctx *raw = nullptr;
+        int rc = omr_batch_create(rows, cols, max_angle, step, 1.0, dv, 1, &raw);
+        if (rc) return rc;
+        d->ctx.reset(raw);
+        // the scan-lane sweep pays for its plan (seconds of host time, gigabytes of programs) from a few launches on
+        if (per_dev >= 2 * HB_CHUNK) {
+            d->launch = std::min(HB_LAUNCH, ((per_dev + HB_CHUNK - 1) / HB_CHUNK) * HB_CHUNK);
+            rc = omr_batch_set_lanes(d->ctx.get(), d->launch);
+            if (rc == OMR_OK) d->lanes = true;
+            else if (rc != OMR_ERR_NOTIMPL) return rc;
+        }
+        if (!d->lanes) {
+            d->launch = std::min(32, per_dev);
+            if ((rc = omr_batch_set_group(d->ctx.get(), d->launch))) return rc;
+        }
+        d->cap = per_dev;
+        OMR_HIP(hipStreamCreateWithFlags(&d->copy, hipStreamNonBlocking));
+        const int chunk = std::min(HB_CHUNK, d->launch);
+        for (int k = 0; k < HB_SLOTS; k++) {
+            OMR_HIP(hipHostMalloc((void **)&d->ring[k], img * chunk, hipHostMallocDefault));
+            OMR_HIP(hipEventCreateWithFlags(&d->ev_slot[k], hipEventDisableTiming));
+        }
+        for (int k = 0; k < 2; k++) {
+            OMR_HIP(d->stage[k].alloc(img * d->launch));
+            OMR_HIP(hipEventCreateWithFlags(&d->ev_ready[k], hipEventDisableTiming));
+            OMR_HIP(hipEventCreateWithFlags(&d->ev_used[k], hipEventDisableTiming));
+        }
+        OMR_HIP(d->dbest.alloc(sizeof(int32_t) * (size_t)per_dev));
+        OMR_HIP(d->dvs.alloc(sizeof(double) * (size_t)per_dev * hb->A));
+        OMR_HIP(d->dhs.alloc(sizeof(double) * (size_t)per_dev * hb->A));
+        hb->devs.push_back(std::move(d));
+    }
+    *out = hb.release();
+    return OMR_OK;
+}
+
+void omr_host_batch_destroy(omr_host_batch *hb) { delete hb; }
+
+int omr_host_batch_info(const omr_host_batch *hb, int32_t *n_devices, int32_t *scans_per_launch, int32_t *scan_lane)
+{
+    if (!hb || hb->devs.empty()) return fail(OMR_ERR_BADARG, "null host batch");
+    if (n_devices) *n_devices = hb->n_devices;
+    if (scans_per_launch) *scans_per_launch = hb->devs[0]->launch;
+    if (scan_lane) *scan_lane = hb->devs[0]->lanes ? 1 : 0;
+    return OMR_OK;
+}
+
+int omr_host_batch_run(omr_host_batch *hb, const omr_image *scans, int32_t n, int32_t source_is_pinned, int32_t *best_idx,
+                       double *best_angle, double *v_sd_opt, double *h_sd_opt)
+{
+    if (!hb || !scans || n < 0 || !best_idx) return fail(OMR_ERR_BADARG, "bad batch arguments");
+    if (n == 0) return OMR_OK;
+    std::lock_guard<std::mutex> lk(hb->mu);
+    const int rows = hb->rows, cols = hb->cols, A = hb->A, ND = hb->n_devices;
+    for (int i = 0; i < n; i++) {
+        const omr_image &im = scans[i];
+        if (!im.data || im.channels != 1 || im.rows != rows || im.cols != cols || im.step_bytes < cols)
+            return fail(OMR_ERR_ASSERT, "scan %d: every scan of the batch must be a %dx%d 1-channel image", i, cols, rows);
+    }
+    if ((n + ND - 1) / ND > hb->devs[0]->cap) return fail(OMR_ERR_BADARG, "%d scans: the context was made for %d per device", n, hb->devs[0]->cap);
+    std::vector<int> rcs((size_t)ND, OMR_OK);
+    std::vector<std::string> errs((size_t)ND);
+    const size_t img = (size_t)rows * cols;
+    auto worker = [&](int dv) {
+        auto run = [&]() -> int {
+            HostBatchDev &d = *hb->devs[(size_t)dv];
+            OMR_HIP(hipSetDevice(dv));
+            std::vector<int> mine;
+            for (int i = dv; i < n; i += ND) mine.push_back(i);
+            const int m = (int)mine.size();
+            if (m == 0) return OMR_OK;
+            const int chunk = std::min(HB_CHUNK, d.launch);
+            hipStream_t main_s = d.ctx->streams[0];
+            int slot_no = 0;
+            for (int j0 = 0, li = 0; j0 < m; j0 += d.launch, li++) {
+                const int g = std::min(d.launch, m - j0), b = li & 1;
+                // the stage's previous launch must have packed it before new scans land on it
+                if (d.stage_used[b]) OMR_HIP(hipStreamWaitEvent(d.copy, d.ev_used[b], 0));
+                for (int c0 = 0; c0 < g; c0 += chunk) {
+                    const int cg = std::min(chunk, g - c0);
+                    uint8_t *dst = d.stage[b].as<uint8_t>() + (size_t)c0 * img;
+                    if (source_is_pinned) {  // the caller's memory is page-locked: DMA straight out of it
+                        for (int z = 0; z < cg; z++) {
+                            const omr_image &im = scans[mine[(size_t)(j0 + c0 + z)]];
+                            if (im.step_bytes == cols)
+                                OMR_HIP(hipMemcpyAsync(dst + (size_t)z * img, im.data, img, hipMemcpyHostToDevice, d.copy));
+                            else
+                                OMR_HIP(hipMemcpy2DAsync(dst + (size_t)z * img, (size_t)cols, im.data, (size_t)im.step_bytes, (size_t)cols,
+                                                         (size_t)rows, hipMemcpyHostToDevice, d.copy));
+                        }
+                        continue;
+                    }
+                    const int k = slot_no++ % HB_SLOTS;
+                    if (d.slot_busy[k]) OMR_HIP(hipEventSynchronize(d.ev_slot[k]));  // the slot's last DMA has read it
+                    const int T = std::min(cg, 16);
+                    std::vector<std::thread> cp;
+                    for (int t = 0; t < T; t++)
+                        cp.emplace_back([&, t]() {
+                            for (int z = t; z < cg; z += T) {
+                                const omr_image &im = scans[mine[(size_t)(j0 + c0 + z)]];
+                                uint8_t *to = d.ring[k] + (size_t)z * img;
+                                if (im.step_bytes == cols) memcpy(to, im.data, img);
+                                else
+                                    for (int r = 0; r < rows; r++) memcpy(to + (size_t)r * cols, im.data + (size_t)r * im.step_bytes, (size_t)cols);
+                            }
+                        });
+                    for (auto &t : cp) t.join();
+                    OMR_HIP(hipMemcpyAsync(dst, d.ring[k], img * cg, hipMemcpyHostToDevice, d.copy));
+                    OMR_HIP(hipEventRecord(d.ev_slot[k], d.copy));
+                    d.slot_busy[k] = true;
+                }
+                OMR_HIP(hipEventRecord(d.ev_ready[b], d.copy));
+                OMR_HIP(hipStreamWaitEvent(main_s, d.ev_ready[b], 0));
+                int rc = omr_batch_run_device(d.ctx.get(), d.stage[b].as<uint8_t>(), (int64_t)img, cols, g, 0,
+                                              d.dbest.as<int32_t>() + j0, d.dvs.as<double>() + (size_t)j0 * A,
+                                              d.dhs.as<double>() + (size_t)j0 * A);
+                if (rc) return rc;
+                OMR_HIP(hipEventRecord(d.ev_used[b], main_s));
+                d.stage_used[b] = true;
+            }
+            int rc = omr_batch_sync(d.ctx.get());
+            if (rc) return rc;
+            OMR_HIP(hipStreamSynchronize(d.copy));
+            std::vector<int32_t> hbest((size_t)m);
+            OMR_HIP(hipMemcpy(hbest.data(), d.dbest.p, sizeof(int32_t) * (size_t)m, hipMemcpyDeviceToHost));
+            std::vector<double> hv, hh;
+            if (v_sd_opt) {
+                hv.resize((size_t)m * A);
+                OMR_HIP(hipMemcpy(hv.data(), d.dvs.p, sizeof(double) * hv.size(), hipMemcpyDeviceToHost));
+            }
+            if (h_sd_opt) {
+                hh.resize((size_t)m * A);
+                OMR_HIP(hipMemcpy(hh.data(), d.dhs.p, sizeof(double) * hh.size(), hipMemcpyDeviceToHost));
+            }
+            for (int j = 0; j < m; j++) {
+                const int i = mine[(size_t)j];
+                best_idx[i] = hbest[(size_t)j];
+                if (v_sd_opt) memcpy(v_sd_opt + (size_t)i * A, hv.data() + (size_t)j * A, sizeof(double) * (size_t)A);
+                if (h_sd_opt) memcpy(h_sd_opt + (size_t)i * A, hh.data() + (size_t)j * A, sizeof(double) * (size_t)A);
+            }
+            return OMR_OK;
+        };
+        rcs[(size_t)dv] = run();
+        if (rcs[(size_t)dv]) errs[(size_t)dv] = last_error();
+    };
+    std::vector<std::thread> th;
+    for (int dv = 0; dv < ND; dv++) th.emplace_back(worker, dv);
+    for (auto &t : th) t.join();
+    for (int dv = 0; dv < ND; dv++)
+        if (rcs[(size_t)dv]) return fail(rcs[(size_t)dv], "device %d: %s", dv, errs[(size_t)dv].c_str());
+    if (best_angle)
+        for (int i = 0; i < n; i++) best_angle[i] = ((double)best_idx[i] - (double)hb->N) * hb->step;  // projection.rs:189-190
+    return OMR_OK;
+}
+
+}  // extern "C"

@@ -205,6 +205,51 @@ class Batch:
         return s.value, n.value
 
 
+class HostBatch:
+    """omr_host_batch: repeated batches that start in host memory (plan, pinned ring and device stages made once)."""
+
+    def __init__(self, rows, cols, max_angle, step, max_scans, n_devices=0):
+        self.handle = C.c_void_p()
+        self.rows, self.cols = rows, cols
+        _, self.A = candidate_count(max_angle, step)
+        check(lib().omr_host_batch_create(rows, cols, int(max_angle), float(step), n_devices, int(max_scans),
+                                          C.byref(self.handle)))
+
+    def info(self):
+        nd, spl, sl = C.c_int32(), C.c_int32(), C.c_int32()
+        check(lib().omr_host_batch_info(self.handle, C.byref(nd), C.byref(spl), C.byref(sl)))
+        return nd.value, spl.value, bool(sl.value)
+
+    def run(self, scans, pinned=False, want_sd=False):
+        """scans: list of 2-D u8 arrays (pixels == 0 black).  pinned=True: the arrays live in page-locked memory."""
+        from ._lib import OmrImage
+        keep, arr = [], (OmrImage * len(scans))()
+        for i, s in enumerate(scans):
+            a, im = as_image(_mat(s))
+            keep.append(a)
+            arr[i] = im
+        n = len(scans)
+        best = np.zeros(n, np.int32)
+        ang = np.zeros(n, np.float64)
+        vs = np.zeros((n, self.A)) if want_sd else None
+        hs = np.zeros((n, self.A)) if want_sd else None
+        check(lib().omr_host_batch_run(self.handle, arr, n, 1 if pinned else 0, best.ctypes.data_as(i32p),
+                                       ang.ctypes.data_as(f64p), vs.ctypes.data_as(f64p) if want_sd else None,
+                                       hs.ctypes.data_as(f64p) if want_sd else None))
+        return best, ang, vs, hs
+
+    def close(self):
+        if self.handle:
+            lib().omr_host_batch_destroy(self.handle)
+            self.handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
+
+
 def sweep_batch(scans, max_angle, step, n_devices=0, want_sd=False):
     """omr_sweep_batch: host images, scan i -> device i % n_devices, host-side gather."""
     from ._lib import OmrImage

@@ -132,3 +132,32 @@ def test_steep_sweep_is_refused(oracle):
         b.set_lanes(64)
     assert e.value.code == -213
     b.close()
+
+
+def test_host_batch_pageable_and_pinned(oracle):
+    """omr_host_batch: 150 binarised scans from host memory (>= 128 per device: the scan-lane sweep), pageable and
+    page-locked sources, two runs on one context; every scan's scores equal the oracle's bit for bit."""
+    rows, cols, n = 180, 260, 150
+    scans = [np.where(s <= 127, 0, 255).astype(np.uint8) for s in make_scans(rows, cols, n, 31)]
+    hb = projection.HostBatch(rows, cols, 6, 0.5, n, n_devices=1)
+    nd, spl, lane = hb.info()
+    assert nd == 1 and lane and spl % 64 == 0
+    best, ang, vs, hs = hb.run(scans, want_sd=True)
+    pinned_t = torch.empty((n, rows, cols), dtype=torch.uint8).pin_memory()
+    pn = pinned_t.numpy()
+    for i in range(n):
+        pn[i] = scans[i]
+    best2, _, vs2, hs2 = hb.run([pn[i] for i in range(n)], pinned=True, want_sd=True)
+    hb.close()
+    assert (best == best2).all() and (vs.view(np.uint64) == vs2.view(np.uint64)).all() and (hs.view(np.uint64) == hs2.view(np.uint64)).all()
+    N, A = oracle.candidate_count(6, 0.5)
+    for i in range(0, n, 7):
+        _, _, evs, ehs = oracle.sweep(scans[i], 6, 0.5)
+        assert (vs[i].view(np.uint64) == evs.view(np.uint64)).all() and (hs[i].view(np.uint64) == ehs.view(np.uint64)).all()
+        assert best[i] == oracle.argmax_path1(evs, ehs)[0] and ang[i] == (best[i] - N) * 0.5
+
+
+def test_host_batch_refuses_more_devices_than_visible():
+    with pytest.raises(oics.OmrError) as e:
+        projection.HostBatch(100, 100, 5, 1.0, 8, n_devices=64)
+    assert e.value.code == -5
