@@ -18,7 +18,14 @@ src = os.path.join(ROOT, "gpurun_out", tag)
 dst = os.path.join(ROOT, "profiles")
 os.makedirs(dst, exist_ok=True)
 commit = open(os.path.join(src, "COMMIT")).read().strip() if os.path.exists(os.path.join(src, "COMMIT")) else "unknown"
-STAMP = "Measured at commit `%s` on one MI355X (gpurun boxes), `bash tools/profile_round.sh %s a|b`.\n\n" % (commit, tag)
+status = {}
+for ln in (open(os.path.join(src, "STATUS")).read().splitlines() if os.path.exists(os.path.join(src, "STATUS")) else []):
+    if " rc=" in ln:
+        status[ln.split(" rc=")[0]] = int(ln.split(" rc=")[1])
+failed = sorted(k for k, v in status.items() if v != 0)
+STAMP = "Measured at commit `%s` on one MI355X (gpurun boxes), `bash tools/profile_round.sh %s a|b`.%s\n\n" % (
+    commit, tag, ("  **Steps that did not end with exit code 0 (their sections below are missing or stale): %s.**" % ", ".join(failed))
+    if failed else "  Every step of the recipe ended with exit code 0 (gpurun_out/%s/STATUS)." % tag if status else "")
 
 
 def read(name):
@@ -91,13 +98,15 @@ line = last_json(read("bench_line.json"))
 json.dump(line, open(os.path.join(dst, tag + "_bench_line.json"), "w"), indent=1)
 with open(os.path.join(dst, tag + "_rocprofv3_kernel_stats_bench.md"), "w") as f:
     f.write("# %s -- `rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline --no-pmc`\n\n" % tag + STAMP)
-    f.write("Default bench: %d scans per GPU per step (%d distinct cards), %d scans per kernel launch, 1 sweep stream + 1 post "
-            "stream; the `value` leg (angle detection) is followed by the two deskew legs (`deskew_warp_kernel<true>` = LINEAR, "
-            "`<false>` = NEAREST; they share the chip with the sweep of the next launch group, so their durations here are longer "
-            "than in `%s_deskew.md`); `runtab_kernel` / `runblk_kernel` / `rungeo_kernel` / `tables_kernel` are plan creation, one "
-            "extra `runs_kernel` launch is the plan's dry run.\n\n" % (line["config"]["scans_per_gpu_per_step"],
-                                                                      line["config"]["distinct_cards_per_gpu"],
-                                                                      line["config"]["scans_per_kernel_launch"], tag))
+    f.write("Default bench: %d scans per GPU per step (%d distinct cards), %d scans per kernel launch (sweep kernel: %s), 1 sweep "
+            "stream + 1 post stream; the `value` leg (angle detection) is followed by the two deskew legs (`deskew_warp_kernel<true>` "
+            "= LINEAR, `<false>` = NEAREST; they share the chip with the sweep of the next launch, so their durations here are "
+            "longer than in `%s_deskew.md`); `slane_pack_kernel` / `slane_vproj_kernel` / `slane_stddev_kernel` are the scan-lane "
+            "sweep's pack, column-count and std-dev stages; `runtab_kernel` / `runblk_kernel` / `rungeo_kernel` / `tables_kernel` and one "
+            "`runs_kernel` launch are the creation of the run-merging plan every context still makes.  (The profiled command "
+            "takes its cards from a file made beforehand and skips the host-memory leg: nothing under the profiler forks.)\n\n"
+            % (line["config"]["scans_per_gpu_per_step"], line["config"]["distinct_cards_per_gpu"],
+               line["config"]["scans_per_kernel_launch"], line["config"].get("sweep_kernel", "run-merging"), tag))
     rows = stats_table("stats", f)
     ks = glob.glob(os.path.join(src, "stats", "**", "*kernel_stats.csv"), recursive=True)
     if ks:
@@ -107,24 +116,29 @@ with open(os.path.join(dst, tag + "_rocprofv3_kernel_stats_bench.md"), "w") as f
             "%.4f ms per launch of %d scans (HIP events on the launch stream, %d launches), bound `%s` frac %.3f; VALU issue %.3f, "
             "LDS busy %.3f (conflict share %.3f), HBM %.3f of 8 TB/s from the run's own FETCH_SIZE / WRITE_SIZE passes.\n" % (
                 tag, line["value"], rl["kernel_ms"], rl["scans_per_launch"], rl["launch_groups_timed"], rl.get("bound"),
-                rl.get("frac") or float("nan"), rl.get("valu_issue_frac", float("nan")), rl.get("lds_busy_frac", float("nan")),
+                rl.get("frac") or float("nan"), rl.get("valu_issue_frac_at_2_cycles", float("nan")), rl.get("lds_busy_frac", float("nan")),
                 rl.get("lds_conflict_frac", float("nan")), rl.get("hbm_frac", float("nan"))))
     if line.get("deskew"):
         dk = line["deskew"]
         f.write("With the deskewed image produced inside the timed region (`omr_batch_deskew_device`): **%.0f images/s** LINEAR "
                 "(%.3f of `value`), %.0f NEAREST (%.3f).\n" % (dk["linear_images_per_s"], dk["linear_over_value"],
                                                                dk["nearest_images_per_s"], dk["nearest_over_value"]))
-    run = [r for r in rows if "runs_kernel" in r["Name"]]
+    dom = "slane_kernel" if line["config"].get("sweep_kernel") == "scan-lane" else "runs_kernel"
+    run = [r for r in rows if dom in r["Name"]]
     if run:
-        f.write("The profiler's average for `omr::runs_kernel` (%.1f us) must agree with `roofline.kernel_ms` (%.1f us) up to the "
-                "profiler's clock effect.\n" % (float(run[0]["AverageNs"]) / 1e3, rl["kernel_ms"] * 1e3))
+        f.write("The profiler's average for `omr::%s` (%.1f us) must agree with `roofline.kernel_ms` (%.1f us) up to the "
+                "profiler's clock effect.\n" % (dom, float(run[0]["AverageNs"]) / 1e3, rl["kernel_ms"] * 1e3))
+    if line.get("e2e_host"):
+        f.write("Host-memory end to end (`e2e_host`): %s\n" % json.dumps(line["e2e_host"]))
 
 # ---- sweep counters
 with open(os.path.join(dst, tag + "_pmc_sweep.md"), "w") as f:
     f.write("# %s -- counters of the sweep kernel (C2: 2480x3508, A = 400)\n\n" % tag + STAMP)
-    f.write("## HBM-side traffic and SQ counters measured INSIDE the bench run (bench.py's child passes, 8 scans per launch)\n")
+    dom = "slane_kernel" if line and line["config"].get("sweep_kernel") == "scan-lane" else "runs_kernel"
+    f.write("## HBM-side traffic and SQ counters measured INSIDE the bench run (bench.py's child passes, %d scans per launch, `%s`)\n"
+            % (line["config"]["scans_per_kernel_launch"] if line else 0, dom))
     for sub in ("bench_pmc/fetch", "bench_pmc/write", "bench_pmc/sq"):
-        counter_table(sub, "runs_kernel", f)
+        counter_table(sub, dom, f)
     if line and line["roofline"].get("traffic"):
         rl = line["roofline"]
         f.write("\n(2 x FETCH_SIZE + WRITE_SIZE) x 1024 = **%.0f MB per launch of %d scans** = %.0f GB/s = %.3f of the 8 TB/s HBM peak, "
@@ -136,7 +150,12 @@ with open(os.path.join(dst, tag + "_pmc_sweep.md"), "w") as f:
                    "sweep_kernel_hbm_bytes_per_launch": rl["traffic"], "scans_per_launch": rl["scans_per_launch"],
                    "correction": "gfx950: FETCH_SIZE x2 (MI355X_MICROARCH.md HBM section), WRITE_SIZE as is, x1024 B"},
                   open(os.path.join(dst, "hbm_traffic.json"), "w"), indent=1)
-    f.write("\n## Batch mode (tools/kbatch.py: 8 scans per launch), two SQ passes\n")
+    if os.path.exists(os.path.join(src, "pmc_lanes", "summary.md")):
+        f.write("\n## The scan-lane kernel, one launch of 512 scans (`bash tools/pmc_lanes.sh`: six passes, mean of the launches)\n\n")
+        f.write(open(os.path.join(src, "pmc_lanes", "summary.md")).read())
+        f.write("\n`python3 tools/klanes.py 512 512 3` (un-profiled, HIP events around the sweep kernel):\n\n```\n%s```\n"
+                % read("klanes.log").replace("/opt/amdgpu/share/libdrm/amdgpu.ids: No such file or directory\n", ""))
+    f.write("\n## The run-merging kernel in batch mode (tools/kbatch.py: 8 scans per launch), two SQ passes\n")
     r1 = {}
     for sub in ("pmc_sq1", "pmc_sq2"):
         r1.update(counter_table(sub, "runs_kernel", f))

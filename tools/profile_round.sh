@@ -7,16 +7,25 @@
 #   usage: bash tools/profile_round.sh r03 a     (bench line, sweep kernel, batch warp)
 #          bash tools/profile_round.sh r03 b     (stage kernels, FFT, Hough, per-call latencies, micro-benchmarks)
 #          bash tools/profile_round.sh r03 c     (Hough batch: int32 against 16-bit accumulator, scans in flight)
-set -eo pipefail
+set -o pipefail
 TAG=${1:-r03}
 PART=${2:-a}
 OUT=gpurun_out/$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+# Every step removes what an earlier run left under its name and records its exit code in $OUT/STATUS (round-3 advice:
+# a step that fails or times out must not leave the previous run's files to be stamped with the new commit;
+# tools/make_profiles.py marks steps whose code is not 0).
+step() { # step <name> <command...>: un-profiled measurement, output to $OUT/<name>.log
+  local n=$1; shift
+  rm -f "$OUT/$n.log"
+  "$@" > "$OUT/$n.log" 2>&1; echo "$n rc=$?" >> "$OUT/STATUS"
+}
 prof() { # prof <outdir> <counters or --stats> -- program...
   local d=$1; shift
-  if [ "$1" = "--stats" ]; then shift; timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/$d" "$@" > "$OUT/$d.log" 2>&1 || true
-  else local c=$1; shift; timeout -k 10 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$OUT/$d" "$@" > "$OUT/$d.log" 2>&1 || true; fi
+  rm -rf "$OUT/$d" "$OUT/$d.log"
+  if [ "$1" = "--stats" ]; then shift; timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/$d" "$@" > "$OUT/$d.log" 2>&1; echo "$d rc=$?" >> "$OUT/STATUS"
+  else local c=$1; shift; timeout -k 10 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$OUT/$d" "$@" > "$OUT/$d.log" 2>&1; echo "$d rc=$?" >> "$OUT/STATUS"; fi
 }
 SQ1="SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CU_CYCLES"
 SQ2="SQ_WAIT_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAVES"
@@ -24,38 +33,46 @@ if [ "$PART" = "c" ]; then
   # 7. Hough batch: accumulator width and scans in flight, side by side on this box (builds the 16-bit variant here)
   bash tools/hough_ab.sh "$TAG"
 elif [ "$PART" = "a" ]; then
+  rm -f "$OUT/STATUS"
   # 1. the bench line exactly as the driver runs it (its own FETCH_SIZE / WRITE_SIZE / SQ child passes included)
-  timeout -k 10 900 python3 bench.py > "$OUT/bench_line.json" 2> "$OUT/bench_line.err"
-  rm -rf "$OUT/bench_pmc" && cp -r gpurun_out/bench_pmc "$OUT/bench_pmc" 2>/dev/null || true
+  rm -f "$OUT/bench_line.json" "$OUT/bench_line.err"; rm -rf "$OUT/bench_pmc" gpurun_out/bench_pmc
+  timeout -k 10 900 python3 bench.py > "$OUT/bench_line.json" 2> "$OUT/bench_line.err"; echo "bench_line rc=$?" >> "$OUT/STATUS"
+  cp -r gpurun_out/bench_pmc "$OUT/bench_pmc" 2>/dev/null || true
   echo "[profile] bench line done"
-  # 2. kernel stats of the same command (no counters in this run)
-  prof stats --stats -- python3 bench.py --no-cpu-baseline --no-pmc
+  # 2. kernel stats of the same command (no counters in this run).  The cards are made BEFORE the profiled run and
+  # handed over by --cards: the program under `--` creates no child process (bench.py's card pool forks workers)
+  rm -f "$OUT/cards.npy"
+  python3 -c "import sys; sys.argv=['x']; import numpy as np, bench; c,_=bench.make_cards(64, 2); np.save('$OUT/cards.npy', c)" > "$OUT/cards.log" 2>&1; echo "cards rc=$?" >> "$OUT/STATUS"
+  prof stats --stats -- python3 bench.py --no-cpu-baseline --no-pmc --no-e2e --cards "$OUT/cards.npy"
+  rm -f "$OUT/cards.npy"
   echo "[profile] kernel stats done"
-  # 3. the sweep kernel in batch mode (8 scans per launch): two SQ passes, timings, phase clocks of the debug build
+  # 3a. the scan-lane sweep kernel (one launch of 512 scans): timings, counters (tools/pmc_lanes.sh: six passes)
+  step klanes timeout -k 10 300 python3 tools/klanes.py 512 512 3
+  rm -rf "$OUT/pmc_lanes"; bash tools/pmc_lanes.sh "$OUT/pmc_lanes" all > "$OUT/pmc_lanes.log" 2>&1; echo "pmc_lanes rc=$?" >> "$OUT/STATUS"
+  # 3b. the run-merging kernel (single scans and batches that do not fit the scan-lane scheme): as in round 3
   prof pmc_sq1 "$SQ1" -- python3 tools/kbatch.py 4 8
   prof pmc_sq2 "$SQ2" -- python3 tools/kbatch.py 4 8
-  timeout -k 10 300 python3 tools/kbatch.py 16 8 > "$OUT/kbatch.log" 2>&1 || true
-  for g in 16 32; do timeout -k 10 300 python3 tools/kbatch.py 8 $g 2>&1 | grep "pass 2" >> "$OUT/kbatch_groups.log" || true; done
-  timeout -k 10 300 python3 tools/kbench.py 20 > "$OUT/kbench.log" 2>&1 || true
-  timeout -k 10 300 python3 tools/kstamps.py > "$OUT/kstamps.log" 2>&1 || true
-  echo "[profile] sweep kernel done"
+  step kbatch timeout -k 10 300 python3 tools/kbatch.py 16 8
+  step kbench timeout -k 10 300 python3 tools/kbench.py 20
+  step kstamps timeout -k 10 300 python3 tools/kstamps.py
+  echo "[profile] sweep kernels done"
   # 4. the batch warp on its own (sweep and warp never share the chip: the context is synchronised per call)
-  timeout -k 10 300 python3 tools/bench_deskew.py 10 > "$OUT/deskew.log" 2>&1 || true
+  step deskew timeout -k 10 300 python3 tools/bench_deskew.py 10
   prof deskew_stats --stats -- python3 tools/bench_deskew.py 10
   prof deskew_fetch FETCH_SIZE -- python3 tools/bench_deskew.py 4
   prof deskew_write WRITE_SIZE -- python3 tools/bench_deskew.py 4
   echo "[profile] batch warp done"
-  timeout -k 10 300 python3 tools/bench_calls.py > "$OUT/calls.log" 2>&1 || true
-  timeout -k 10 300 python3 tools/bench_host.py > "$OUT/host.log" 2>&1 || true
-  timeout -k 10 300 python3 tools/bench_threads.py > "$OUT/threads.log" 2>&1 || true
+  step calls timeout -k 10 300 python3 tools/bench_calls.py
+  step host timeout -k 10 300 python3 tools/bench_host.py 512 3
+  step threads timeout -k 10 300 python3 tools/bench_threads.py
 else
   # 5. stage kernels, FFT, Hough: un-profiled numbers, kernel stats, FETCH_SIZE / WRITE_SIZE each alone
-  timeout -k 10 300 python3 tools/bench_stages.py 30 > "$OUT/stages.log" 2>&1 || true
+  step stages timeout -k 10 300 python3 tools/bench_stages.py 30
   prof stages_stats --stats -- python3 tools/bench_stages.py 10
   prof stages_fetch FETCH_SIZE -- python3 tools/bench_stages.py 5
   prof stages_write WRITE_SIZE -- python3 tools/bench_stages.py 5
   echo "[profile] stages done"
-  timeout -k 10 300 python3 tools/bench_fft.py 64 4 > "$OUT/fft.log" 2>&1 || true
+  step fft timeout -k 10 300 python3 tools/bench_fft.py 64 4
   prof fft_stats --stats -- python3 tools/bench_fft.py 32 3
   for w in c5 a4; do
     prof fft_fetch_$w FETCH_SIZE -- python3 tools/bench_fft.py 16 2 $w
@@ -63,15 +80,15 @@ else
     prof fft_sq_$w "$SQ1" -- python3 tools/bench_fft.py 16 2 $w
   done
   echo "[profile] fft done"
-  timeout -k 10 600 python3 tools/bench_hough.py 256 8 2 > "$OUT/hough.log" 2>&1 || true
-  timeout -k 10 300 python3 tools/hough_run.py 1 1 5 > "$OUT/hough_single.log" 2>&1 || true
-  timeout -k 10 300 python3 tools/hstamps.py > "$OUT/hstamps_a4.log" 2>&1 || true
+  step hough timeout -k 10 600 python3 tools/bench_hough.py 256 8 2
+  step hough_single timeout -k 10 300 python3 tools/hough_run.py 1 1 5
+  step hstamps_a4 timeout -k 10 300 python3 tools/hstamps.py
   prof hough_stats --stats -- python3 tools/hough_run.py 64 4 1
   prof hough_fetch FETCH_SIZE -- python3 tools/hough_run.py 64 4 1
   prof hough_write WRITE_SIZE -- python3 tools/hough_run.py 64 4 1
   prof hough_sq "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAVE_CYCLES SQ_BUSY_CYCLES" -- python3 tools/hough_run.py 64 4 1
   echo "[profile] hough done"
-  timeout -k 10 600 python3 tools/core_protocol.py > "$OUT/core_protocol.log" 2>&1 || true
+  step core_protocol timeout -k 10 600 python3 tools/core_protocol.py
   # 6. micro-benchmarks behind DESIGN.md's statements
   for t in lds_dma_window; do
     hipcc -O2 --offload-arch=gfx950 tools/$t.hip -o /tmp/$t > "$OUT/$t.build.log" 2>&1 && timeout -k 10 200 /tmp/$t > "$OUT/$t.log" 2>&1 || true
