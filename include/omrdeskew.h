@@ -185,7 +185,10 @@ int omr_batch_kernel_ms(omr_batch_ctx *ctx, double *sum_ms, int32_t *launches);
  * lands in d_out_size[2 i] (rows) and [2 i + 1] (cols); every slot must hold the largest canvas of the candidate
  * set, omr_batch_deskew_canvas().  The result is what omr_rotate_device(angle = (best_idx - N) * step, scale 1,
  * OMR_CLIP_CONTAIN) writes for the same scan, bit for bit.  d_best_idx (n int32) and d_out_size (2 n int32) may be
- * NULL.  Returns after enqueueing, like omr_batch_run_device. */
+ * NULL.  Returns after enqueueing, like omr_batch_run_device.
+ * Performance note: the warp stages every tile's source box in LDS with dword loads, which needs d_scans,
+ * scan_stride_bytes, step_bytes and the scan width to be multiples of 4; otherwise (e.g. a 453-column scan, tightly
+ * packed) every tile takes a byte-wise per-tap path straight from memory -- same result, several times slower. */
 int omr_batch_deskew_canvas(omr_batch_ctx *ctx, int32_t *max_rows, int32_t *max_cols);
 int omr_batch_deskew_device(omr_batch_ctx *ctx, const uint8_t *d_scans, int64_t scan_stride_bytes,
                             int64_t step_bytes, int32_t n, int32_t black_max, int32_t interp,

@@ -347,8 +347,10 @@ hipError_t launch_transpose_bits(const uint32_t *d_bits, int rows, int wpr, uint
 //   row counts   : popcount of the lane's words, added to the chunk's per-row count in LDS (two u16 per
 //                  dword); written once per workgroup as a u16 partial per (row, chunk)
 //   column counts: every lane keeps a 3-plane bit-sliced counter per word (its rows of up to 7 bands);
-//                  at the end of a group lane pairs add their counters (DPP), park them in the window
-//                  buffer that was just consumed, and wave w sums the 256 parked numbers of (word w/2,
+//                  at the end of a group lane pairs add their counters (DPP), park them in their own LDS
+//                  region (RUN_PARK_OFS -- NOT in the wave's window buffer: the next window's LDS-DMA has
+//                  already been issued into that buffer when flush_columns() runs, so reusing it would race
+//                  with the DMA), and wave w sums the 256 parked numbers of (word w/2,
 //                  column half w%2) lane-wise, then over its 64 lanes with one v_add_co_u32 (shift +
 //                  carry-out = ballot of the top bit) and one s_bcnt1 per bit.  Plain stores, no atomics.
 // LDS accesses of the inner loop take INTEGER byte addresses (the dynamic segment starts at LDS address

@@ -44,9 +44,11 @@ def _run_batch(cards, max_angle, step, interp, group):
     return out.cpu().numpy(), size.cpu().numpy(), best.cpu().numpy(), N
 
 
-@pytest.mark.parametrize("interp", [NEAREST, LINEAR])
-def test_batch_deskew_small_batch_every_scan(oracle, interp):
-    rows, cols, max_angle, step = 640, 452, 10, 0.5
+@pytest.mark.parametrize("interp,cols", [(NEAREST, 452), (LINEAR, 452), (NEAREST, 453), (LINEAR, 453)])
+def test_batch_deskew_small_batch_every_scan(oracle, interp, cols):
+    # cols = 453: width, pitch and scan stride are not multiples of 4, so every tile of deskew_warp_kernel takes its
+    # unstaged per-tap path (csrc/deskew.hip; round-3 advice: pin that path in the GPU suite, not only in the fuzzer)
+    rows, max_angle, step = 640, 10, 0.5
     skews = [-9.3, -4.0, -0.2, 0.0, 0.7, 3.1, 6.6, 9.4, 2.2, -7.5, 5.0]  # 11 scans: a last group of 3 at group = 4
     cards = np.stack([synth.make_card(rows, cols, 100 + i, skew=s)[0] for i, s in enumerate(skews)])
     out, size, best, N = _run_batch(cards, max_angle, step, interp, group=4)
