@@ -32,7 +32,7 @@
 //                                   and white runs elsewhere are segments that read ring register 64, which holds 0.
 //                                   pk = sh | idx << 5 | 0x60000 | q << 21 (pk >> 5 is M0 for the indexed v_alignbit:
 //                                   index + SRC0_REL | SRC1_REL; pk itself is its shift operand; pk >> 21 the second
-//                                   shift), the first pk of a word also carries its segment count n << 26 (n >= 1)
+//                                   shift), the first pk of a word also carries its segment count n << 26 (n >= 1) and bit 31 when n <= 4
 //                S = 2 / 4 / 8 slots per word (class 0 / 1 / 2: 4 / 8 / 16 dwords per row), chosen per strip
 #pragma once
 #include <stdint.h>
@@ -53,6 +53,7 @@ constexpr uint32_t SL_PK_MODE = 0x60000u;               // pk >> 5 -> M0[13:12]:
 constexpr uint32_t SL_COMMIT_MODE = 0x8000u;            // M0[15]: DST_REL
 constexpr int SL_PRE = 24;                              // virtual rows ahead of row 0
 constexpr int SL_QSHIFT = 21, SL_NSHIFT = 26;           // pk fields: second shift, segment count
+constexpr uint32_t SL_SHORT = 0x80000000u;              // first pk of a word: at most four segments
 constexpr int SL_GX = 4;                                // least zero guard, word columns on either side
 constexpr int SL_LANES = 64;
 constexpr int SL_DUMP = 17;                             // registers a wave dumps per word: planes p0..p11, carries c0..c4

@@ -219,6 +219,7 @@ bool slane_strip_program(const SlaneGeom &g, const int32_t *ad, const int32_t *b
                 w[j] = sh | (idx << 5) | SL_PK_MODE | (q << SL_QSHIFT);
             }
             w[0] |= (uint32_t)n << SL_NSHIFT;
+            if (n <= 4) w[0] |= SL_SHORT;  // the kernel skips the second group of four slots
         }
     return true;
 }

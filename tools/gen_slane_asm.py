@@ -21,7 +21,7 @@ workgroup's other strips in LDS; one global atomic per pair row and 16 rows) -> 
 Register map (fixed; the statement clobbers s0-s13, s16-s101, v1-v127, so lane * 4 arrives in v0):
   s[0:1] segment stream  s[2:3] fetch stream  s[4:7] bit-image descriptor  s8 rows left (a multiple of 64 at the start:
   row phases are taken from -s8)  s9 strip's place in its quad | LDS base of the scan group's accumulators
-  s10 second shift / scratch  s11 segments of the word / scratch  s[14:15] the task (input)
+  s[10:11] second shifts of a segment pair / scratch  s[14:15] the task (input)
   segment sets A-D: s[16:31] s[32:47] s[48:63] s[64:79]   fetch offsets A-D: s[80:83] s[84:87] s[88:91] s[92:95]
   commit pairs A-D: s[96:97] s[98:99] s[100:101] s[12:13]
   v[1:17] / v[18:34] column counters of word 0 / 1: planes p0..p11, pending carries c0..c4
@@ -50,12 +50,13 @@ AHEAD = 4
 
 
 def word(out, k, sset, S, dreg, tag):
-    """segments of word k (pk dwords in s[sset + k * S ...]) -> VGPR dreg"""
+    """segments of word k (pk dwords in s[sset + k * S ...]) -> VGPR dreg.  Scalar work per segment: one s_lshr writes M0
+    (ring index + mode bits); the second shift amounts of TWO segments come out of one s_lshr_b64 of their SGPR pair
+    (low dword's bits 4:0 = q of the even segment, high dword's = q of the odd one; the junk above bit 4 is ignored by
+    v_alignbit / v_lshlrev)."""
     G = {2: 2, 4: 4, 8: 4}[S]
     SKIP = "noskip" not in ABLATE  # a word of at most four segments skips the second group of four (measured: 45.1 ms with, 45.9 without)
     p = lambda j: "s%d" % (sset + k * S + j)
-    if S > G and SKIP:
-        out.append("s_lshr_b32 s11, %s, 26" % p(0))
     for g in range(S // G):
         js = list(range(g * G, (g + 1) * G))
         for n, j in enumerate(js):
@@ -63,13 +64,15 @@ def word(out, k, sset, S, dreg, tag):
             out.append("v_alignbit_b32 v%d, v%d, v%d, %s" % (XR[n], RING + 1, RING, p(j)))
         out.append("s_mov_b32 m0, 0")
         for n, j in enumerate(js):
-            out.append("s_lshr_b32 s10, %s, 21" % p(j))
+            if n % 2 == 0:  # the pair (j, j + 1) sits in an even-aligned SGPR pair: sets and slot counts are even
+                out.append("s_lshr_b64 s[10:11], s[%d:%d], 21" % (sset + k * S + j, sset + k * S + j + 1))
+            q = "s%d" % (10 + (n & 1))
             if g == 0 and n == 0:
-                out.append("v_lshlrev_b32 v%d, s10, v%d" % (dreg, XR[n]))
+                out.append("v_lshlrev_b32 v%d, %s, v%d" % (dreg, q, XR[n]))
             else:
-                out.append("v_alignbit_b32 v%d, v%d, v%d, s10" % (dreg, XR[n], dreg))
+                out.append("v_alignbit_b32 v%d, v%d, v%d, %s" % (dreg, XR[n], dreg, q))
         if g + 1 < S // G and SKIP:
-            out.append("s_cmp_le_u32 s11, %d" % ((g + 1) * G))
+            out.append("s_bitcmp1_b32 %s, 31" % p(0))        # the generator's flag: at most G segments
             out.append("s_cbranch_scc1 %s" % tag)
     if S > G and SKIP:
         out.append("%s:" % tag)
