@@ -1247,9 +1247,12 @@ int omr_batch_lanes_projections(omr_batch_ctx *ctx, int32_t set, int32_t scan, i
     const SlaneScratch &s = *ctx->slane_scratch[(size_t)set];
     const SlanePlan &p = ctx->slane;
     const size_t nscp = (size_t)s.nsg * SL_LANES;
-    if (vproj)
-        OMR_HIP(hipMemcpy2D(vproj, 4, s.vproj.as<uint32_t>() + (size_t)a * p.g.cols * nscp + scan, nscp * 4, 4, (size_t)p.g.cols,
+    if (vproj) {  // column counts are u16 on the device
+        std::vector<uint16_t> c16((size_t)p.g.cols);
+        OMR_HIP(hipMemcpy2D(c16.data(), 2, s.vproj.as<uint16_t>() + (size_t)a * p.g.cols * nscp + scan, nscp * 2, 2, c16.size(),
                             hipMemcpyDeviceToHost));
+        for (int c = 0; c < p.g.cols; c++) vproj[c] = c16[(size_t)c];
+    }
     if (hproj) {  // rows travel packed in pairs: record 2 i in the low half of a dword, 2 i + 1 in the high half
         std::vector<uint32_t> pairs((size_t)p.nrec / 2);
         OMR_HIP(hipMemcpy2D(pairs.data(), 4, s.hrows.as<uint32_t>() + (size_t)a * (p.nrec / 2) * nscp + scan, nscp * 4, 4,

@@ -22,6 +22,7 @@ int SlanePlan::build(const SweepTables &t)
 {
     const SweepDims &d = t.dims;
     if (d.rows + SL_PRE + 1 >= 4096) return fail(OMR_ERR_NOTIMPL, "scan-lane sweep: more than 4078 rows (12 counter planes)");
+    if (d.cols > 65535) return fail(OMR_ERR_NOTIMPL, "scan-lane sweep: more than 65535 columns (row counts travel as u16)");
     // the zero guard around the bit images: what the steepest candidate reaches outside the image
     int gx = 0, gy = 0;
     {
@@ -120,7 +121,7 @@ int SlaneScratch::create(const SlanePlan &p, int groups)
     OMR_HIP(hipMemset(hrows.p, 0, sizeof(uint32_t) * (size_t)p.A * (p.nrec / 2) * nscp));  // every launch leaves them zero again
     OMR_HIP(guard.alloc(sizeof(int32_t)));
     OMR_HIP(hipMemset(guard.p, 0, sizeof(int32_t)));
-    OMR_HIP(vproj.alloc(sizeof(uint32_t) * (size_t)p.A * g.cols * nscp));
+    OMR_HIP(vproj.alloc(sizeof(uint16_t) * (size_t)p.A * g.cols * nscp));  // column counts <= rows <= 65535
     OMR_HIP(vsd.alloc(sizeof(double) * nscp * p.A));
     OMR_HIP(hsd.alloc(sizeof(double) * nscp * p.A));
     OMR_HIP(best.alloc(sizeof(int32_t) * nscp));
@@ -189,9 +190,9 @@ int slane_enqueue(const SlanePlan &p, SlaneScratch &s, const uint8_t *d_img, int
         stream = post_stream;
     }
     OMR_HIP(launch_slane_vproj(s.planes.as<uint32_t>(), p.d_tasks.as<int32_t>(), (int)p.tasks.size(), used, s.nsg, p.g.NS, p.g.cols,
-                               p.g.off, p.nrec, s.vproj.as<uint32_t>(), stream));
+                               p.g.off, p.nrec, s.vproj.as<uint16_t>(), stream));
     double *vs = d_v_sd ? d_v_sd : s.vsd.as<double>(), *hs = d_h_sd ? d_h_sd : s.hsd.as<double>();
-    OMR_HIP(launch_slane_stddev(s.vproj.as<uint32_t>(), s.hrows.as<uint32_t>(), p.A, p.g.cols, p.g.rows, p.nrec / 2, SL_PRE, used, s.nsg,
+    OMR_HIP(launch_slane_stddev(s.vproj.as<uint16_t>(), s.hrows.as<uint32_t>(), p.A, p.g.cols, p.g.rows, p.nrec / 2, SL_PRE, used, s.nsg,
                                 nscans, vs, hs, stream));
     if (d_best) OMR_HIP(launch_argmax_path1(vs, hs, p.A, d_best, stream, nscans));
     // the row counts are accumulated with atomics: cleared here, behind their only reader and off the sweep's stream
