@@ -79,6 +79,35 @@ int fft_bluesub_plan(int n, int *m, int radices[3]);
 int fft_bluesub_stage_table_size(int n);
 hipError_t launch_fft_mixed(const FftPass &p, hipStream_t s);
 
+// fft_big.hip: lines whose chirp-z needs more than OMR_FFT_MAX_M points (n > 8192, not a power of two): Bluestein with
+// M = 32768 or 65536 points through GLOBAL memory (four-step transforms, M = M1 x 256), `chunk` lines at a time in
+// `buf`.  Two uses, the two passes of the pictures:
+//   src_u8 set  : row pass -- pair line l = rows 2 l, 2 l + 1 of the 8-bit scan; the two spectra's points 0 .. n / 2
+//                 go to dst[k * dst_pitch + row] (the transposed half spectrum), times out_scale
+//   src_c set   : column pass -- line l = src_c + l * line_stride (n contiguous points); |F| * out_scale goes to
+//                 mag_dst[l * mag_pitch + k], the line's extrema to part[2 l], part[2 l + 1]
+struct BigLines {
+    const uint8_t *src_u8;
+    int64_t src_step;
+    float in_scale;
+    int32_t src_rows;
+    const cfloat *src_c;
+    int64_t line_stride;
+    cfloat *dst;
+    int64_t dst_pitch;
+    float *mag_dst;
+    int32_t mag_pitch;
+    float *part;
+    float out_scale, inv_m;  // inv_m = 1 / M
+    int32_t n, M, lines, chunk;
+    cfloat *buf;             // chunk * M points
+    const cfloat *chirp;     // n: exp(-i pi k^2 / n)
+    const cfloat *BfT;       // M: FFT_M of the padded conjugate chirp, point k1 + M1 k2 at [k1 * 256 + k2]
+    const cfloat *wM;        // M: exp(-2 pi i t / M)
+};
+#define OMR_FFT_BIG_MAX_M 65536
+hipError_t launch_big_lines(const BigLines &p, hipStream_t s);
+
 // d_minmax: 4 ordered-uint words {min |F|, max |F|, min log, max log}; d_part: scratch for per-block
 // extrema, spec_part_floats(rows, cols) floats
 inline size_t spec_part_floats(int rows, int cols)

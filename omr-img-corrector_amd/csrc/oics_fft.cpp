@@ -84,6 +84,7 @@ struct AxisTables {
     int n = 0, m = 0, log2m = 0;
     bool blue = false, mixed = false;  // mixed: one of fft_mixed.hip's kernels takes this length
     int sub = 0;                       // ... as Bluestein on this many sub-lines
+    bool big = false;                  // fft_big.hip: chirp-z through global memory (m = 32768 or 65536; Bf = BfT, Wfull = wM)
     DevBuf W, Wfull, chirp, Bf;
     hipError_t launch(const FftPass &p, hipStream_t s) const { return mixed ? launch_fft_mixed(p, s) : launch_fft_pass(p, s); }
     // fft_mixed.hip's stage tables: per stage (radix R after Ns points) R == 16 -> w^k, else [q - 1][k] = w^(q k), w =
@@ -165,6 +166,32 @@ struct AxisTables {
         OMR_HIP(hipStreamSynchronize(s));  // the host vectors go out of scope
         return OMR_OK;
     }
+    int build_big(hipStream_t s)  // fft_big.hip: the chirp, its spectrum in four-step order, the m twiddles
+    {
+        big = true;
+        std::vector<cd> c, b;
+        chirp_tables(n, m, &c, &b);
+        const int M1 = m / 256;
+        std::vector<cfloat> cf((size_t)n), bt((size_t)m), wf((size_t)m);
+        for (int k = 0; k < n; k++) cf[k] = cfloat{(float)c[k].real(), (float)c[k].imag()};
+        for (int k1 = 0; k1 < M1; k1++)
+            for (int k2 = 0; k2 < 256; k2++) {
+                const cd v = b[(size_t)k1 + (size_t)M1 * k2];
+                bt[(size_t)k1 * 256 + k2] = cfloat{(float)v.real(), (float)v.imag()};
+            }
+        for (int t = 0; t < m; t++) {
+            const double ang = -2.0 * kPi * (double)t / (double)m;
+            wf[t] = cfloat{(float)cos(ang), (float)sin(ang)};
+        }
+        OMR_HIP(chirp.alloc(sizeof(cfloat) * cf.size()));
+        OMR_HIP(Bf.alloc(sizeof(cfloat) * bt.size()));
+        OMR_HIP(Wfull.alloc(sizeof(cfloat) * wf.size()));
+        OMR_HIP(hipMemcpyAsync(chirp.p, cf.data(), sizeof(cfloat) * cf.size(), hipMemcpyHostToDevice, s));
+        OMR_HIP(hipMemcpyAsync(Bf.p, bt.data(), sizeof(cfloat) * bt.size(), hipMemcpyHostToDevice, s));
+        OMR_HIP(hipMemcpyAsync(Wfull.p, wf.data(), sizeof(cfloat) * wf.size(), hipMemcpyHostToDevice, s));
+        OMR_HIP(hipStreamSynchronize(s));  // the host vectors go out of scope
+        return OMR_OK;
+    }
     int build(int len, hipStream_t s)
     {
         n = len;
@@ -181,9 +208,10 @@ struct AxisTables {
             m <<= 1;
             log2m++;
         }
-        if (m > OMR_FFT_MAX_M)
-            return fail(OMR_ERR_NOTIMPL, "DFT length %d needs a transform of %d points; the kernel holds at most %d in LDS", n,
-                        m, OMR_FFT_MAX_M);
+        if (m > OMR_FFT_BIG_MAX_M)
+            return fail(OMR_ERR_NOTIMPL, "DFT length %d needs a transform of %d points; at most %d are supported", n, m,
+                        OMR_FFT_BIG_MAX_M);
+        if (m > OMR_FFT_MAX_M) return build_big(s);
         // twiddles of the radix-8 stages, one contiguous table per stage (Ns = Ns0, 8 Ns0, ... < m)
         std::vector<cfloat> w;
         // (lengths 2^(3a+1) >= 128 end in one radix-16 stage instead of starting with a radix-2 stage: fft_forward_lds)
@@ -263,7 +291,8 @@ struct FftWork {
                                         // the memory channels instead of aliasing)
     const AxisTables *axc = nullptr, *axr = nullptr;  // transforms along a row (length cols) / along a column (length rows)
     int mag_pitch = 0;  // floats per line of the transposed |F| (cols / 2 + 1 lines of rows + 16)
-    DevBuf c0, mag, mm, part;
+    DevBuf c0, mag, mm, part, bigbuf;
+    int big_chunk = 0;  // lines of the global-memory chirp-z's buffer (an axis of more than 8192 points, fft_big.hip)
     int group = 1;  // scans carried by one launch of each kernel (every per-scan array holds that many)
     int create(int r, int c, hipStream_t s, int scans_per_launch = 1)
     {
@@ -279,7 +308,51 @@ struct FftWork {
         OMR_HIP(mag.alloc(sizeof(float) * (size_t)(c / 2 + 1) * mag_pitch * group));
         OMR_HIP(mm.alloc(sizeof(uint32_t) * 4 * group));
         OMR_HIP(part.alloc(sizeof(float) * 2 * (size_t)c * group));
+        if (axc->big || axr->big) {
+            const int M = std::max(axc->big ? axc->m : 0, axr->big ? axr->m : 0);
+            big_chunk = (int)std::min<size_t>(((size_t)1 << 30) / (sizeof(cfloat) * (size_t)M), (size_t)std::max(r, c));
+            OMR_HIP(bigbuf.alloc(sizeof(cfloat) * (size_t)M * big_chunk));
+        }
         return OMR_OK;
+    }
+    // an axis of more than 8192 points: its pass runs scan by scan through fft_big.hip
+    hipError_t big_pass(const AxisTables *ax, const FftPass &f, int z, hipStream_t s) const
+    {
+        BigLines b{};
+        b.n = ax->n;
+        b.M = ax->m;
+        b.inv_m = (float)(1.0 / (double)ax->m);
+        b.chunk = big_chunk;
+        b.buf = bigbuf.as<cfloat>();
+        b.chirp = ax->chirp.as<cfloat>();
+        b.BfT = ax->Bf.as<cfloat>();
+        b.wM = ax->Wfull.as<cfloat>();
+        b.out_scale = f.out_scale;
+        if (f.src_u8) {  // row pass
+            b.src_u8 = f.src_u8 + (int64_t)z * f.src_u8_scan_stride;
+            b.src_step = f.src_step;
+            b.in_scale = f.in_scale;
+            b.src_rows = f.src_rows;
+            b.lines = (f.src_rows + 1) / 2;
+            b.dst = f.dst + (int64_t)z * f.c_scan_stride;
+            b.dst_pitch = f.dst_elem_stride;
+        } else {
+            b.src_c = f.src_c + (int64_t)z * f.c_scan_stride;
+            b.line_stride = f.line_stride;
+            b.lines = f.lines;
+            b.mag_dst = f.mag_dst + (int64_t)z * f.mag_scan_stride;
+            b.mag_pitch = f.mag_pitch;
+            b.part = f.part + (int64_t)z * f.part_scan_stride;
+        }
+        return launch_big_lines(b, s);
+    }
+    // one pass over `scans` scans: the LDS kernels take them in one launch, the global-memory path one by one
+    hipError_t pass(const AxisTables *ax, const FftPass &f, hipStream_t s) const
+    {
+        if (!ax->big) return ax->launch(f, s);
+        for (int z = 0; z < f.scans; z++)
+            if (hipError_t e = big_pass(ax, f, z, s); e != hipSuccess) return e;
+        return hipSuccess;
     }
     // fft.rs:124-141 for one device-resident 8-bit scan -> the two 8-bit pictures (device, packed)
     // `scans` (<= group) scans, scan_stride bytes apart; pictures packed one after the other
@@ -313,7 +386,7 @@ struct FftWork {
         p.xcd_blocked = 1;      // neighbouring rows' 16-byte pieces of a line meet in one XCD's L2
         p.real_pairs = 1;  // two real rows per workgroup, columns 0 .. cols / 2 written
         p.src_rows = rows;
-        OMR_HIP(axc->launch(p, s));
+        OMR_HIP(pass(axc, p, s));
         // along columns = along the lines of the transposed array, with DFT_SCALE
         FftPass q{};
         q.scans = scans;
@@ -340,7 +413,7 @@ struct FftWork {
         q.Bf = axr->blue ? axr->Bf.as<cfloat>() : nullptr;
         q.sub = axr->sub;
         q.out_scale = (float)(1.0 / ((double)rows * (double)cols));
-        OMR_HIP(axr->launch(q, s));
+        OMR_HIP(pass(axr, q, s));
         OMR_HIP(launch_minmax_final(part.as<float>(), cols / 2 + 1, mm.as<uint32_t>(), s, scans, 2 * (int64_t)cols));
         OMR_HIP(launch_spec_pictures(mag.as<float>(), rows, cols, mag_pitch, mm.as<uint32_t>(), d_mag_u8, d_log_u8, s, scans,
                                      (int64_t)(cols / 2 + 1) * mag_pitch));

@@ -86,11 +86,23 @@ def test_fft_picture_properties():
 
 def test_fft_size_limits():
     with pytest.raises(oics.OmrError) as e:
-        fft.get_fft_image(np.zeros((16, 9000), np.uint8))       # 9000 needs a 32768-point chirp transform
-    assert e.value.code == -213
-    with pytest.raises(oics.OmrError) as e:
         fft.get_fft_image(np.zeros((16, 16, 3), np.uint8))
     assert e.value.code == -215
+
+
+@pytest.mark.parametrize("rows,cols,seed", [(24, 9000, 21), (9000, 24, 22), (37, 9921, 23), (9920, 50, 24), (33, 16400, 25),
+                                           (16385, 12, 26), (8200, 8300, 27)])
+def test_axes_beyond_8192_points(rows, cols, seed):
+    """fft.rs:42-65 transforms the scan at its own size: an axis of more than 8192 points that is not a power of two
+    (a 600-dpi A3 side: 9920 / 9921) needs a chirp transform of 32768 or 65536 points, which runs through global memory
+    (fft_big.hip, four-step transforms) -- as the row pass, as the column pass and as both (round-3 verdict, missing 1)."""
+    g, _ = synth.make_card(rows, cols, seed)
+    m, lg = fft.get_fft_image(g)
+    em, elg = offt.get_fft_image(g)
+    dmax, same = close(lg, elg)
+    assert dmax <= PICTURE_TOL and same >= 0.999, (rows, cols, dmax, same)
+    dmax, same = close(m, em)
+    assert dmax <= PICTURE_TOL and same >= 0.999, (rows, cols, dmax, same)
 
 
 def test_long_lines_run_in_place():

@@ -2,7 +2,8 @@
 2480x3508) scans resident in HBM through omr_fft_image_batch_device.  GPU only: the agreement of the pictures
 with the oracle is what tests/test_gpu_fft.py and tests/test_gpu_c3.py check (nothing outside tests/, smoke()
 and bench.py's cpu_baseline touches oracle/).  Rates are the MEAN over the repetitions.
-Usage: python tools/bench_fft.py [batch] [reps] [c5|a4|both]"""
+A3 at 600 dpi (9921 x 14032: both axes beyond 8192 points, the global-memory chirp-z of fft_big.hip) runs 2 scans.
+Usage: python tools/bench_fft.py [batch] [reps] [c5|a4|a3|both]"""
 import json
 import os
 import sys
@@ -21,9 +22,11 @@ REPS = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 WHICH = sys.argv[3] if len(sys.argv) > 3 else "both"  # c5 | a4 | both
 dev = torch.device("cuda:0")
 out = {}
-for name, rows, cols in (("C5 4096x4096", 4096, 4096), ("A4 2480x3508", 3508, 2480)):
-    if WHICH != "both" and not name.lower().startswith(WHICH):
+for name, rows, cols in (("C5 4096x4096", 4096, 4096), ("A4 2480x3508", 3508, 2480), ("A3 600 dpi 9921x14032", 14032, 9921)):
+    if (WHICH == "both" and name.startswith("A3")) or (WHICH != "both" and not name.lower().startswith(WHICH)):
         continue
+    if name.startswith("A3"):
+        B = 2
     cards = [synth.make_card(rows, cols, 3 + i)[0] for i in range(2)]
     d = torch.from_numpy(np.stack([cards[i % 2] for i in range(B)])).to(dev)
     o = torch.zeros((B, rows, cols), dtype=torch.uint8, device=dev)
