@@ -402,8 +402,9 @@ int omr_correct_default(const omr_image *src_bgr, uint16_t projection_max_angle,
  * The 2-D DFT is float32 like the reference's (dft on CV_32F); it is a different factorisation than
  * OpenCV's (radix-2 Stockham / Bluestein chirp-z in LDS), so the 8-bit spectrum pictures agree with
  * the CPU restatement to about one grey level, not bit for bit.  Everything after the picture
- * (Canny, HoughLinesP, votes) is the exact chain of the Hough-line path.  Each axis length must be a
- * power of two <= 16384 or any length <= 8192 (-213 otherwise): a 600-dpi A4 scan (4960 x 7016) fits. */
+ * (Canny, HoughLinesP, votes) is the exact chain of the Hough-line path.  Any axis length up to the image
+ * limit (32766) is transformed: lengths <= 8192 and the power of two 16384 inside LDS, longer lines by a chirp-z
+ * through global memory (slower: a 600-dpi A3 scan, 9921 x 14032, takes about 12 ms). */
 
 /* oics::fft::get_fft_image(&TransformableMatrix) -> Result<(Mat, Mat)> (fft.rs:124-141):
  * (magnitude_image, magnitude_log_image), both 8-bit single channel.  Either output may be NULL. */
