@@ -53,7 +53,7 @@ void slane_guard_need(const int32_t *ad, const int32_t *bd, const int32_t *x0, c
 void slane_null_program(int nrec, int cls, uint32_t *seg, uint32_t *fet)
 {
     const int RD = slane_seg_dwords(cls), S = slane_slots(cls);
-    const uint32_t white = ((uint32_t)SL_ZERO << 5) | SL_PK_MODE | (1u << SL_NSHIFT), pad = ((uint32_t)SL_ZERO << 5) | SL_PK_MODE;
+    const uint32_t white = ((uint32_t)SL_ZERO << 5) | SL_PK_MODE | (1u << SL_NSHIFT) | SL_SHORT, pad = ((uint32_t)SL_ZERO << 5) | SL_PK_MODE;
     for (size_t q = 0; q < (size_t)nrec; q++)
         for (int k = 0; k < SL_K; k++)
             for (int j = 0; j < S; j++) seg[q * RD + (size_t)k * S + j] = j == 0 ? white : pad;

@@ -55,6 +55,7 @@ def word(out, k, sset, S, dreg, tag):
     (low dword's bits 4:0 = q of the even segment, high dword's = q of the odd one; the junk above bit 4 is ignored by
     v_alignbit / v_lshlrev)."""
     G = {2: 2, 4: 4, 8: 4}[S]
+    Q32 = "q32" in ABLATE  # timing probe: one s_lshr_b32 per segment for the second shift instead of one s_lshr_b64 per pair
     SKIP = "noskip" not in ABLATE  # a word of at most four segments skips the second group of four (measured: 45.1 ms with, 45.9 without)
     p = lambda j: "s%d" % (sset + k * S + j)
     for g in range(S // G):
@@ -64,9 +65,13 @@ def word(out, k, sset, S, dreg, tag):
             out.append("v_alignbit_b32 v%d, v%d, v%d, %s" % (XR[n], RING + 1, RING, p(j)))
         out.append("s_mov_b32 m0, 0")
         for n, j in enumerate(js):
-            if n % 2 == 0:  # the pair (j, j + 1) sits in an even-aligned SGPR pair: sets and slot counts are even
-                out.append("s_lshr_b64 s[10:11], s[%d:%d], 21" % (sset + k * S + j, sset + k * S + j + 1))
-            q = "s%d" % (10 + (n & 1))
+            if Q32:
+                out.append("s_lshr_b32 s10, %s, 21" % p(j))
+                q = "s10"
+            else:
+                if n % 2 == 0:  # the pair (j, j + 1) sits in an even-aligned SGPR pair: sets and slot counts are even
+                    out.append("s_lshr_b64 s[10:11], s[%d:%d], 21" % (sset + k * S + j, sset + k * S + j + 1))
+                q = "s%d" % (10 + (n & 1))
             if g == 0 and n == 0:
                 out.append("v_lshlrev_b32 v%d, %s, v%d" % (dreg, q, XR[n]))
             else:
