@@ -30,7 +30,7 @@ for name, rows, cols in (("C5 4096x4096", 4096, 4096), ("A4 2480x3508", 3508, 24
     cards = [synth.make_card(rows, cols, 3 + i)[0] for i in range(2)]
     d = torch.from_numpy(np.stack([cards[i % 2] for i in range(B)])).to(dev)
     o = torch.zeros((B, rows, cols), dtype=torch.uint8, device=dev)
-    fft.fft_image_batch_device(d.data_ptr(), 2, rows * cols, rows, cols, cols, o.data_ptr())  # warm-up
+    fft.fft_image_batch_device(d.data_ptr(), B, rows * cols, rows, cols, cols, o.data_ptr())  # warm-up: the same launches as the timed calls, so that per-kernel profiles average equal launches
     ts = []
     for _ in range(REPS):
         torch.cuda.synchronize()

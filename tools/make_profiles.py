@@ -220,8 +220,15 @@ with open(os.path.join(dst, tag + "_fft.md"), "w") as f:
                 v["algorithmic_GBps"] / 8000, v["kernel_GBps"], v["kernel_GBps"] / 8000))
     f.write("\nKernel stats (`rocprofv3 --kernel-trace --stats -- python3 tools/bench_fft.py 32 3`, both sizes):\n\n")
     stats_table("fft_stats", f, 8)
+    j3 = last_json(read("fft_a3.log"))
+    if j3:
+        f.write("\nAxes beyond 8192 points (`csrc/fft_big.hip`: chirp-z through global memory), `python3 tools/bench_fft.py 2 3 a3`:\n\n")
+        for k, v in j3.items():
+            f.write("* %s: **%.2f ms per scan** (%.1f scans/s)\n" % (k, v["ms_per_scan"], v["scans_per_s"]))
+        f.write("\nKernel stats of the same script:\n\n")
+        stats_table("fft_a3_stats", f, 10)
     for w, nm in (("c5", "4096 x 4096"), ("a4", "2480 x 3508")):
-        f.write("\nMeasured HBM-side traffic, %s, 16 scans per call (FETCH_SIZE and WRITE_SIZE each in a pass of its own):\n\n" % nm)
+        f.write("\nMeasured HBM-side traffic, %s, 16 scans per call = two launches of 8 scans, warm-up included and of the same size (FETCH_SIZE and WRITE_SIZE each in a pass of its own):\n\n" % nm)
         hbm_table("fft_fetch_" + w, "fft_write_" + w, f, needles=("fft_pass_kernel", "fft_mixed_kernel", "fft_bluesub_kernel", "spec_pictures_kernel"))
         for needle in ("fft_pass_kernel", "fft_mixed_kernel", "fft_bluesub_kernel"):
             counter_table("fft_sq_" + w, needle, f)

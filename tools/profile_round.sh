@@ -73,6 +73,8 @@ else
   prof stages_write WRITE_SIZE -- python3 tools/bench_stages.py 5
   echo "[profile] stages done"
   step fft timeout -k 10 300 python3 tools/bench_fft.py 64 4
+  step fft_a3 timeout -k 10 300 python3 tools/bench_fft.py 2 3 a3
+  prof fft_a3_stats --stats -- python3 tools/bench_fft.py 2 2 a3
   prof fft_stats --stats -- python3 tools/bench_fft.py 32 3
   for w in c5 a4; do
     prof fft_fetch_$w FETCH_SIZE -- python3 tools/bench_fft.py 16 2 $w
