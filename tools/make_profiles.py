@@ -19,13 +19,17 @@ dst = os.path.join(ROOT, "profiles")
 os.makedirs(dst, exist_ok=True)
 commit = open(os.path.join(src, "COMMIT")).read().strip() if os.path.exists(os.path.join(src, "COMMIT")) else "unknown"
 status = {}
-for ln in (open(os.path.join(src, "STATUS")).read().splitlines() if os.path.exists(os.path.join(src, "STATUS")) else []):
+import glob
+_status_lines = []
+for _f in sorted(glob.glob(os.path.join(src, "STATUS_*"))):
+    _status_lines += open(_f).read().splitlines()
+for ln in _status_lines:
     if " rc=" in ln:
         status[ln.split(" rc=")[0]] = int(ln.split(" rc=")[1])
 failed = sorted(k for k, v in status.items() if v != 0)
 STAMP = "Measured at commit `%s` on one MI355X (gpurun boxes), `bash tools/profile_round.sh %s a|b`.%s\n\n" % (
     commit, tag, ("  **Steps that did not end with exit code 0 (their sections below are missing or stale): %s.**" % ", ".join(failed))
-    if failed else "  Every step of the recipe ended with exit code 0 (gpurun_out/%s/STATUS)." % tag if status else "")
+    if failed else "  Every step of the recipe ended with exit code 0 (gpurun_out/%s/STATUS_a, STATUS_b)." % tag if status else "")
 
 
 def read(name):

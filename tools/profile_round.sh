@@ -13,19 +13,19 @@ PART=${2:-a}
 OUT=gpurun_out/$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-# Every step removes what an earlier run left under its name and records its exit code in $OUT/STATUS (round-3 advice:
+# Every step removes what an earlier run left under its name and records its exit code in $OUT/STATUS_<part> (one file per gpurun call: each call starts on a fresh box and its files are merged back over the earlier ones; round-3 advice:
 # a step that fails or times out must not leave the previous run's files to be stamped with the new commit;
 # tools/make_profiles.py marks steps whose code is not 0).
 step() { # step <name> <command...>: un-profiled measurement, output to $OUT/<name>.log
   local n=$1; shift
   rm -f "$OUT/$n.log"
-  "$@" > "$OUT/$n.log" 2>&1; echo "$n rc=$?" >> "$OUT/STATUS"
+  "$@" > "$OUT/$n.log" 2>&1; echo "$n rc=$?" >> "$OUT/STATUS_$PART"
 }
 prof() { # prof <outdir> <counters or --stats> -- program...
   local d=$1; shift
   rm -rf "$OUT/$d" "$OUT/$d.log"
-  if [ "$1" = "--stats" ]; then shift; timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/$d" "$@" > "$OUT/$d.log" 2>&1; echo "$d rc=$?" >> "$OUT/STATUS"
-  else local c=$1; shift; timeout -k 10 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$OUT/$d" "$@" > "$OUT/$d.log" 2>&1; echo "$d rc=$?" >> "$OUT/STATUS"; fi
+  if [ "$1" = "--stats" ]; then shift; timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/$d" "$@" > "$OUT/$d.log" 2>&1; echo "$d rc=$?" >> "$OUT/STATUS_$PART"
+  else local c=$1; shift; timeout -k 10 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$OUT/$d" "$@" > "$OUT/$d.log" 2>&1; echo "$d rc=$?" >> "$OUT/STATUS_$PART"; fi
 }
 SQ1="SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CU_CYCLES"
 SQ2="SQ_WAIT_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAVES"
@@ -33,22 +33,22 @@ if [ "$PART" = "c" ]; then
   # 7. Hough batch: accumulator width and scans in flight, side by side on this box (builds the 16-bit variant here)
   bash tools/hough_ab.sh "$TAG"
 elif [ "$PART" = "a" ]; then
-  rm -f "$OUT/STATUS"
+  rm -f "$OUT/STATUS_$PART"
   # 1. the bench line exactly as the driver runs it (its own FETCH_SIZE / WRITE_SIZE / SQ child passes included)
   rm -f "$OUT/bench_line.json" "$OUT/bench_line.err"; rm -rf "$OUT/bench_pmc" gpurun_out/bench_pmc
-  timeout -k 10 900 python3 bench.py > "$OUT/bench_line.json" 2> "$OUT/bench_line.err"; echo "bench_line rc=$?" >> "$OUT/STATUS"
+  timeout -k 10 900 python3 bench.py > "$OUT/bench_line.json" 2> "$OUT/bench_line.err"; echo "bench_line rc=$?" >> "$OUT/STATUS_$PART"
   cp -r gpurun_out/bench_pmc "$OUT/bench_pmc" 2>/dev/null || true
   echo "[profile] bench line done"
   # 2. kernel stats of the same command (no counters in this run).  The cards are made BEFORE the profiled run and
   # handed over by --cards: the program under `--` creates no child process (bench.py's card pool forks workers)
   rm -f "$OUT/cards.npy"
-  python3 -c "import sys; sys.argv=['x']; import numpy as np, bench; c,_=bench.make_cards(64, 2); np.save('$OUT/cards.npy', c)" > "$OUT/cards.log" 2>&1; echo "cards rc=$?" >> "$OUT/STATUS"
+  python3 -c "import sys; sys.argv=['x']; import numpy as np, bench; c,_=bench.make_cards(64, 2); np.save('$OUT/cards.npy', c)" > "$OUT/cards.log" 2>&1; echo "cards rc=$?" >> "$OUT/STATUS_$PART"
   prof stats --stats -- python3 bench.py --no-cpu-baseline --no-pmc --no-e2e --cards "$OUT/cards.npy"
   rm -f "$OUT/cards.npy"
   echo "[profile] kernel stats done"
   # 3a. the scan-lane sweep kernel (one launch of 512 scans): timings, counters (tools/pmc_lanes.sh: six passes)
   step klanes timeout -k 10 300 python3 tools/klanes.py 512 512 3
-  rm -rf "$OUT/pmc_lanes"; bash tools/pmc_lanes.sh "$OUT/pmc_lanes" all > "$OUT/pmc_lanes.log" 2>&1; echo "pmc_lanes rc=$?" >> "$OUT/STATUS"
+  rm -rf "$OUT/pmc_lanes"; bash tools/pmc_lanes.sh "$OUT/pmc_lanes" all > "$OUT/pmc_lanes.log" 2>&1; echo "pmc_lanes rc=$?" >> "$OUT/STATUS_$PART"
   # 3b. the run-merging kernel (single scans and batches that do not fit the scan-lane scheme): as in round 3
   prof pmc_sq1 "$SQ1" -- python3 tools/kbatch.py 4 8
   prof pmc_sq2 "$SQ2" -- python3 tools/kbatch.py 4 8
