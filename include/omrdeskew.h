@@ -224,6 +224,11 @@ int omr_batch_lanes_info(omr_batch_ctx *ctx, int64_t *program_bytes, int32_t *ta
 /* Inspection: with on != 0 a launch leaves its row counts in the scratch set (needed by
  * omr_batch_lanes_projections); by default they are cleared behind the std-dev kernel, off the sweep's stream. */
 int omr_batch_lanes_keep(omr_batch_ctx *ctx, int32_t on);
+/* The scan-lane programs of a context are generated on the device; this regenerates them with the host generator (the
+ * reference implementation behind omr_slane_strip_program) and compares: *dwords = dwords of programs, *differing = how
+ * many differ (0 = identical).  For tests and inspection; seconds at A4. */
+int omr_batch_lanes_check_programs(omr_batch_ctx *ctx, int64_t *dwords, int64_t *differing);
+
 /* The integer projections one scan / candidate of the last scan-lane launch left in scratch set `set` (0 for the
  * first launch of a stream): vproj = cols counts, hproj = rows counts; either may be NULL.  Synchronises. */
 int omr_batch_lanes_projections(omr_batch_ctx *ctx, int32_t set, int32_t scan, int32_t a, uint32_t *vproj,

@@ -1231,6 +1231,41 @@ int omr_batch_lanes_info(omr_batch_ctx *ctx, int64_t *program_bytes, int32_t *ta
     return OMR_OK;
 }
 
+// The plan's programs were generated on the device (slane_build.hip).  This regenerates them with the host generator
+// (slane_plan.cpp, the reference implementation that tests/test_slane_program.py runs through the CPU interpreter) and
+// compares the two buffers dword by dword: *dwords = size of the program buffer, *differing = dwords that differ
+// (layout differences count as "everything differs").  For tests and inspection; takes seconds at A4.
+int omr_batch_lanes_check_programs(omr_batch_ctx *ctx, int64_t *dwords, int64_t *differing)
+{
+    if (!ctx || ctx->lanes <= 0 || !ctx->slane.built) return fail(OMR_ERR_BADARG, "the context is not in scan-lane mode");
+    if (!dwords || !differing) return fail(OMR_ERR_BADARG, "null output");
+    int rc = omr_batch_sync(ctx);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    OMR_HIP(hipSetDevice(ctx->tables.device));
+    SlanePlan ref;
+    if ((rc = ref.build(ctx->tables, true))) return rc;
+    const SlanePlan &p = ctx->slane;
+    *dwords = p.prog_dwords;
+    *differing = p.prog_dwords;
+    if (ref.prog_dwords != p.prog_dwords || ref.tasks != p.tasks || ref.strips.size() != p.strips.size()) return OMR_OK;
+    for (size_t i = 0; i < p.strips.size(); i++)
+        if (ref.strips[i].cls != p.strips[i].cls || ref.strips[i].seg_offset != p.strips[i].seg_offset ||
+            ref.strips[i].fet_offset != p.strips[i].fet_offset || ref.strips[i].nseg != p.strips[i].nseg)
+            return OMR_OK;
+    int64_t diff = 0;
+    const size_t piece = (size_t)64 << 20;  // dwords per piece
+    std::vector<uint32_t> x(std::min<size_t>(piece, (size_t)p.prog_dwords)), y(x.size());
+    for (size_t o = 0; o < (size_t)p.prog_dwords; o += piece) {
+        const size_t n = std::min(piece, (size_t)p.prog_dwords - o);
+        OMR_HIP(hipMemcpy(x.data(), p.prog.as<uint32_t>() + o, 4 * n, hipMemcpyDeviceToHost));
+        OMR_HIP(hipMemcpy(y.data(), ref.prog.as<uint32_t>() + o, 4 * n, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < n; i++) diff += x[i] != y[i];
+    }
+    *differing = diff;
+    return OMR_OK;
+}
+
 // Integer projections of one scan and candidate as the LAST scan-lane launch of scratch set `set` left them (for
 // tests and inspection): vproj cols u32, hproj rows u32.  Synchronises the context.
 int omr_batch_lanes_projections(omr_batch_ctx *ctx, int32_t set, int32_t scan, int32_t a, uint32_t *vproj, uint32_t *hproj)

@@ -154,7 +154,9 @@ struct SlanePlan {
     DevBuf prog, d_tasks;
     std::vector<SlaneStrip> strips;  // [A][NS]
     std::vector<int32_t> tasks;      // candidate * NS + strip, in launch order
-    int build(const SweepTables &t);  // OMR_ERR_NOTIMPL when a candidate does not fit the scheme
+    // OMR_ERR_NOTIMPL when a candidate does not fit the scheme.  on_host: slane_plan.cpp's generator (the reference
+    // implementation, 16 host threads + upload) instead of slane_build.hip's
+    int build(const SweepTables &t, bool on_host = false);
 };
 struct SlaneScratch {
     int nsg = 0;  // scan groups of 64 scans a launch may carry

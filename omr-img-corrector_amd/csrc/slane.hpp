@@ -128,10 +128,29 @@ struct SlaneTask {
 };
 static_assert(sizeof(SlaneTask) == 128, "SlaneTask layout (slane_asm.inc loads it by offset)");
 
+// slane_build.hip: the same programs generated on the device (the default; the host generator above is the reference
+// implementation).  Scratch per task (= candidate * NS + strip): cmin / cmax / first / last [task][rowsG], most [task],
+// used [task][nrec] (zeroed), freg [task][nrec][SL_FETCH] (filled with SL_DUMMY).
+struct int2_t;
+struct SlaneBuild {
+    SlaneGeom g;
+    int32_t nrec;
+    const int32_t *adelta, *bdelta;  // [A][cols]
+    const int2_t *xy0;               // [A][rows], round delta 512 included
+    int32_t *cmin, *cmax, *first, *last, *most, *bad;
+    uint8_t *used, *freg;
+    uint32_t *prog;
+    const int64_t *seg_off, *fet_off;  // [task], dwords from prog
+    const int32_t *cls;                // [task]
+    int64_t null_seg, null_fet;
+};
+
 }  // namespace omr
 
 #include <hip/hip_runtime_api.h>
 namespace omr {
+hipError_t launch_slane_build_scan(const SlaneBuild &b, int ntasks, hipStream_t s);   // -> most, cmin, cmax, first, last
+hipError_t launch_slane_build_emit(const SlaneBuild &b, int ntasks, hipStream_t s);   // -> prog (needs cls, seg_off, fet_off)
 hipError_t launch_slane_pack(const uint8_t *d_img, int64_t scan_stride, int64_t step, const SlaneGeom &g, int nscans,
                              int black_max, uint32_t *d_bits, hipStream_t s);
 // nsg_used = scan groups that carry scans in this launch, nsg = scan groups the scratch (and its descriptors) is laid out for

@@ -61,6 +61,7 @@ SYMBOLS = {
     "omr_batch_lanes_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), i32p, i32p]),
     "omr_batch_lanes_keep": (C.c_int, [C.c_void_p, C.c_int32]),
     "omr_batch_lanes_projections": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, u32p, u32p]),
+    "omr_batch_lanes_check_programs": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "omr_batch_create": (C.c_int, [C.c_int32, C.c_int32, C.c_uint16, C.c_double, C.c_double, C.c_int32, C.c_int32,
                                    C.POINTER(C.c_void_p)]),
     "omr_batch_destroy": (None, [C.c_void_p]),

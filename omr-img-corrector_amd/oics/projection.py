@@ -184,6 +184,13 @@ class Batch:
         check(lib().omr_batch_lanes_info(self.handle, C.byref(b), C.byref(t), C.byref(n)))
         return b.value
 
+    def lanes_check_programs(self):
+        """(dwords of programs, dwords that differ from the host generator's): the device-built plan against the
+        reference implementation (tests, inspection)."""
+        n, d = C.c_int64(), C.c_int64()
+        check(lib().omr_batch_lanes_check_programs(self.handle, C.byref(n), C.byref(d)))
+        return n.value, d.value
+
     def lanes_projections(self, scan, a, rows, cols, scratch_set=0):
         """(vproj, hproj) of one scan / candidate as the last scan-lane launch left them (tests, inspection)."""
         vp, hp = np.zeros(cols, np.uint32), np.zeros(rows, np.uint32)

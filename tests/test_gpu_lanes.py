@@ -125,6 +125,19 @@ def test_lanes_headline_size(oracle):
         assert abs((best[i] - 200) * 0.05 - cards[i][1]) < 0.5
 
 
+@pytest.mark.parametrize("rows,cols,max_angle,step", [(200, 300, 5, 0.5), (333, 64, 10, 1.0), (1754, 1240, 10, 0.25), (97, 131, 9, 1.5),
+                                                      (640, 1000, 7, 0.5), (3508, 2480, 10, 0.05)])
+def test_device_built_programs_equal_the_host_generator(rows, cols, max_angle, step):
+    """The plan's programs are generated on the device (slane_build.hip); the host generator (slane_plan.cpp, the one
+    tests/test_slane_program.py runs through the CPU interpreter against the oracle) must produce the same buffer,
+    dword for dword: classes, layout, segment words, fetch schedule, commit lists, the null program."""
+    b = projection.Batch(rows, cols, max_angle, step, n_streams=1)
+    b.set_lanes(64)
+    n, diff = b.lanes_check_programs()
+    b.close()
+    assert n > 0 and diff == 0, (n, diff)
+
+
 def test_steep_sweep_is_refused(oracle):
     # +-20 degrees: more than 8 segments per word -> -213, the context stays on the run-merging / gather path
     b = projection.Batch(300, 400, 20, 1.0, n_streams=1)

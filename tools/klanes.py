@@ -26,7 +26,7 @@ best = torch.zeros(n, dtype=torch.int32, device=dev)
 b = projection.Batch(ROWS, COLS, 10, 0.05, n_streams=1)
 t0 = time.perf_counter()
 b.set_lanes(lanes)
-print("plan + scratch for %d scans per launch: %.1f s" % (lanes, time.perf_counter() - t0), flush=True)
+print("plan + scratch for %d scans per launch: %.3f s (programs generated on the device, %.2f GB)" % (lanes, time.perf_counter() - t0, b.lanes_program_bytes() / 1e9), flush=True)
 b.set_timing(True)
 for it in range(passes):
     torch.cuda.synchronize()
