@@ -161,7 +161,7 @@ struct SlanePlan {
 struct SlaneScratch {
     int nsg = 0;  // scan groups of 64 scans a launch may carry
     bool keep_rows = false, rows_dirty = false;  // inspection: leave the row counts in place after a launch
-    DevBuf bits, hrows, vproj, planes, descs, vsd, hsd, best, guard;
+    DevBuf bits, hrows, vproj, planes, descs[3], vsd, hsd, best, guard;  // descs[lg]: workgroups of (16 >> lg) strips x (1 << lg) scan groups
     int create(const SlanePlan &p, int groups);
 };
 int slane_enqueue(const SlanePlan &p, SlaneScratch &s, const uint8_t *d_img, int64_t scan_stride, int64_t step, int nscans,

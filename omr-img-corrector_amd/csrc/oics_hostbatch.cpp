@@ -21,7 +21,9 @@ using namespace omr;
 
 namespace {
 constexpr int HB_CHUNK = 64;    // scans per ring slot / DMA
-constexpr int HB_LAUNCH = 256;  // scans per sweep launch in scan-lane mode (four scan groups: one workgroup row)
+constexpr int HB_LAUNCH = 64;   // scans per sweep launch in scan-lane mode: the pipeline is bound by the copies (10 ms per 64 A4
+                                // scans at 56 GB/s against 6.6 ms of sweep), so what counts is the LAST launch's sweep, which
+                                // nothing overlaps -- the smaller the launch, the shorter that tail
 constexpr int HB_SLOTS = 3;
 
 struct HostBatchDev {
@@ -84,8 +86,8 @@ int omr_host_batch_create(int32_t rows, int32_t cols, uint16_t max_angle, double
         int rc = omr_batch_create(rows, cols, max_angle, step, 1.0, dv, 1, &raw);
         if (rc) return rc;
         d->ctx.reset(raw);
-        // the scan-lane sweep pays for its plan (seconds of host time, gigabytes of programs) from a few launches on
-        if (per_dev >= 2 * HB_CHUNK) {
+        // the scan-lane sweep (its plan is built on the device in tens of milliseconds) from one full wavefront of scans on
+        if (per_dev >= HB_CHUNK) {
             d->launch = std::min(HB_LAUNCH, ((per_dev + HB_CHUNK - 1) / HB_CHUNK) * HB_CHUNK);
             rc = omr_batch_set_lanes(d->ctx.get(), d->launch);
             if (rc == OMR_OK) d->lanes = true;

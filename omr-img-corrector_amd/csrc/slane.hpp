@@ -120,7 +120,7 @@ struct SlaneTask {
     uint32_t nrec;       // records (a multiple of 4)
     uint32_t hpitch;     // bytes between pair rows of the row counts
     int32_t cls;         // 0 / 1 / 2 = 2 / 4 / 8 slots per word
-    int32_t wave;        // the strip's place in its quad (strip & 3): which accumulator rows the wave flushes
+    int32_t wave;        // the pair rows of its scan group's LDS accumulators this wave flushes: first (bits 2:0), number 0 / 1 / 2 (bits 5:4)
     uint64_t planes;     // counter dump of (task, scan group): [word][SL_DUMP][64]
     uint32_t lds_base;   // LDS address of the scan group's row-count accumulators in the workgroup
     uint32_t pad1;
@@ -154,7 +154,7 @@ hipError_t launch_slane_build_emit(const SlaneBuild &b, int ntasks, hipStream_t 
 hipError_t launch_slane_pack(const uint8_t *d_img, int64_t scan_stride, int64_t step, const SlaneGeom &g, int nscans,
                              int black_max, uint32_t *d_bits, hipStream_t s);
 // nsg_used = scan groups that carry scans in this launch, nsg = scan groups the scratch (and its descriptors) is laid out for
-hipError_t launch_slane(const SlaneTask *d_descs, int nsg_used, int nsgp, int A, int NS, int32_t *d_guard, hipStream_t s);
+hipError_t launch_slane(const SlaneTask *d_descs, int nsgq, int nsgp, int A, int NQ, int sgw_log, int32_t *d_guard, hipStream_t s);
 hipError_t launch_slane_vproj(const uint32_t *d_planes, const int32_t *d_tasks, int ntasks, int nsg_used, int nsg, int NS,
                               int cols, int off, int nrec, uint16_t *d_vproj, hipStream_t s);
 hipError_t launch_slane_stddev(const uint16_t *d_vproj, const uint32_t *d_hproj, int A, int cols, int rows, int hpairs_per_cand,

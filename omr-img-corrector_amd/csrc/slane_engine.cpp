@@ -183,45 +183,52 @@ int SlaneScratch::create(const SlanePlan &p, int groups)
     OMR_HIP(vsd.alloc(sizeof(double) * nscp * p.A));
     OMR_HIP(hsd.alloc(sizeof(double) * nscp * p.A));
     OMR_HIP(best.alloc(sizeof(int32_t) * nscp));
-    // ---- one descriptor per (candidate in launch order, place in its workgroups, scan group of the padded table).
+    // ---- one descriptor per (candidate in launch order, place in its workgroups, scan group of the padded table),
+    // for each composition of a workgroup: 4 strips x 4 scan groups (sgw_log 2), 8 x 2 (1), 16 x 1 (0).
     // Places beyond the last strip or the last scan group are null tasks: the empty program, buffer descriptors of
     // size 0 (their fetches read zeros, their row-count adds are dropped), a spare slot for the counter dump.
-    const int NSp = ((g.NS + 3) / 4) * 4, nsgp = ((nsg + 3) / 4) * 4;
     OMR_HIP(planes.alloc(sizeof(uint32_t) * (ntasks * nsg + 1) * SL_K * SL_DUMP * SL_LANES));
-    std::vector<SlaneTask> h((size_t)p.A * NSp * nsgp);
     const uint64_t prog0 = (uint64_t)p.prog.p;
-    for (int ai = 0; ai < p.A; ai++)
-        for (int st = 0; st < NSp; st++) {
-            const size_t ti = (size_t)ai * g.NS + (st < g.NS ? st : 0);  // index into p.tasks (launch order)
-            const int task = p.tasks[ti], a = task / g.NS;
-            const SlaneStrip &S = p.strips[(size_t)task];
-            for (int sg = 0; sg < nsgp; sg++) {
-                const bool real = st < g.NS && sg < nsg;
-                const bool counts = sg < nsg;  // a null strip of a real scan group still flushes that group's row counts
-                SlaneTask &k = h[((size_t)ai * NSp + st) * nsgp + sg];
-                memset(&k, 0, sizeof k);
-                k.seg = prog0 + 4ull * (uint64_t)(real ? S.seg_offset : p.null_seg);
-                k.fet = prog0 + 4ull * (uint64_t)(real ? S.fet_offset : p.null_fet);
-                const uint64_t hb = (uint64_t)hrows.p + (counts ? 4ull * ((uint64_t)a * (p.nrec / 2) * nscp + (uint64_t)sg * SL_LANES) : 0ull);
-                k.hrsrc[0] = (uint32_t)hb;
-                k.hrsrc[1] = (uint32_t)(hb >> 32) & 0xffffu;
-                k.hrsrc[2] = counts ? (uint32_t)((size_t)(p.nrec / 2) * nscp * 4 - (size_t)sg * SL_LANES * 4) : 0u;
-                k.hrsrc[3] = 0x00020000u;
-                k.planes = (uint64_t)planes.p + 4ull * ((real ? ti * nsg + sg : ntasks * nsg) * SL_K * SL_DUMP * SL_LANES);
-                const uint64_t base = (uint64_t)bits.p + (counts ? 4ull * (uint64_t)sg * g.entries * SL_LANES : 0ull);
-                k.rsrc[0] = (uint32_t)base;
-                k.rsrc[1] = (uint32_t)(base >> 32) & 0xffffu;
-                k.rsrc[2] = real ? (uint32_t)(g.entries * SL_LANES * 4) : 0u;
-                k.rsrc[3] = 0x00020000u;
-                k.nrec = (uint32_t)p.nrec;
-                k.hpitch = (uint32_t)(nscp * 4);
-                k.cls = real ? S.cls : 0;
-                k.wave = st & 3;
-                k.lds_base = (uint32_t)((sg & 3) * 2 * 8 * SL_LANES * 4);
+    for (int lg = 0; lg < 3; lg++) {
+        const int sgw = 1 << lg, places = 16 >> lg;
+        const int NSp = ((g.NS + places - 1) / places) * places, nsgp = ((nsg + sgw - 1) / sgw) * sgw;
+        std::vector<SlaneTask> h((size_t)p.A * NSp * nsgp);
+        for (int ai = 0; ai < p.A; ai++)
+            for (int st = 0; st < NSp; st++) {
+                const size_t ti = (size_t)ai * g.NS + (st < g.NS ? st : 0);  // index into p.tasks (launch order)
+                const int task = p.tasks[ti], a = task / g.NS;
+                const SlaneStrip &S = p.strips[(size_t)task];
+                // the eight pair rows of a scan group's LDS buffer, dealt to the strips of the workgroup
+                const int place = st % places;
+                const int first = places == 4 ? 2 * place : place & 7, count = places == 4 ? 2 : place < 8 ? 1 : 0;
+                for (int sg = 0; sg < nsgp; sg++) {
+                    const bool real = st < g.NS && sg < nsg;
+                    const bool counts = sg < nsg;  // a null strip of a real scan group still flushes that group's row counts
+                    SlaneTask &k = h[((size_t)ai * NSp + st) * nsgp + sg];
+                    memset(&k, 0, sizeof k);
+                    k.seg = prog0 + 4ull * (uint64_t)(real ? S.seg_offset : p.null_seg);
+                    k.fet = prog0 + 4ull * (uint64_t)(real ? S.fet_offset : p.null_fet);
+                    const uint64_t hb = (uint64_t)hrows.p + (counts ? 4ull * ((uint64_t)a * (p.nrec / 2) * nscp + (uint64_t)sg * SL_LANES) : 0ull);
+                    k.hrsrc[0] = (uint32_t)hb;
+                    k.hrsrc[1] = (uint32_t)(hb >> 32) & 0xffffu;
+                    k.hrsrc[2] = counts ? (uint32_t)((size_t)(p.nrec / 2) * nscp * 4 - (size_t)sg * SL_LANES * 4) : 0u;
+                    k.hrsrc[3] = 0x00020000u;
+                    k.planes = (uint64_t)planes.p + 4ull * ((real ? ti * nsg + sg : ntasks * nsg) * SL_K * SL_DUMP * SL_LANES);
+                    const uint64_t base = (uint64_t)bits.p + (counts ? 4ull * (uint64_t)sg * g.entries * SL_LANES : 0ull);
+                    k.rsrc[0] = (uint32_t)base;
+                    k.rsrc[1] = (uint32_t)(base >> 32) & 0xffffu;
+                    k.rsrc[2] = real ? (uint32_t)(g.entries * SL_LANES * 4) : 0u;
+                    k.rsrc[3] = 0x00020000u;
+                    k.nrec = (uint32_t)p.nrec;
+                    k.hpitch = (uint32_t)(nscp * 4);
+                    k.cls = real ? S.cls : 0;
+                    k.wave = first | (count << 4);
+                    k.lds_base = (uint32_t)((sg % sgw) * 2 * 8 * SL_LANES * 4);
+                }
             }
-        }
-    OMR_HIP(descs.alloc(sizeof(SlaneTask) * h.size()));
-    OMR_HIP(hipMemcpy(descs.p, h.data(), sizeof(SlaneTask) * h.size(), hipMemcpyHostToDevice));
+        OMR_HIP(descs[lg].alloc(sizeof(SlaneTask) * h.size()));
+        OMR_HIP(hipMemcpy(descs[lg].p, h.data(), sizeof(SlaneTask) * h.size(), hipMemcpyHostToDevice));
+    }
     return OMR_OK;
 }
 
@@ -240,7 +247,11 @@ int slane_enqueue(const SlanePlan &p, SlaneScratch &s, const uint8_t *d_img, int
     }
     OMR_HIP(launch_slane_pack(d_img, scan_stride, step, p.g, nscans, black_max, s.bits.as<uint32_t>(), stream));
     if (ev0) OMR_HIP(hipEventRecord(ev0, stream));
-    OMR_HIP(launch_slane(s.descs.as<SlaneTask>(), used, ((s.nsg + 3) / 4) * 4, p.A, p.g.NS, s.guard.as<int32_t>(), stream));
+    {   // the workgroup's composition: 16 strips x 1 scan group, 8 x 2, or 4 x 4 (the scratch holds a table for each)
+        const int lg = used <= 1 ? 0 : used == 2 ? 1 : 2, sgw = 1 << lg, places = 16 >> lg;
+        OMR_HIP(launch_slane(s.descs[lg].as<SlaneTask>(), (used + sgw - 1) / sgw, ((s.nsg + sgw - 1) / sgw) * sgw, p.A,
+                             (p.g.NS + places - 1) / places, lg, s.guard.as<int32_t>(), stream));
+    }
     if (ev1) OMR_HIP(hipEventRecord(ev1, stream));
     if (post_stream && ev_mid) {
         OMR_HIP(hipEventRecord(ev_mid, stream));

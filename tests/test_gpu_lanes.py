@@ -148,7 +148,7 @@ def test_steep_sweep_is_refused(oracle):
 
 
 def test_host_batch_pageable_and_pinned(oracle):
-    """omr_host_batch: 150 binarised scans from host memory (>= 128 per device: the scan-lane sweep), pageable and
+    """omr_host_batch: 150 binarised scans from host memory (>= 64 per device: the scan-lane sweep), pageable and
     page-locked sources, two runs on one context; every scan's scores equal the oracle's bit for bit."""
     rows, cols, n = 180, 260, 150
     scans = [np.where(s <= 127, 0, 255).astype(np.uint8) for s in make_scans(rows, cols, n, 31)]
