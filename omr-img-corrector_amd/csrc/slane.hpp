@@ -33,7 +33,7 @@
 //                                   pk = sh | idx << 5 | 0x60000 | q << 21 (pk >> 5 is M0 for the indexed v_alignbit:
 //                                   index + SRC0_REL | SRC1_REL; pk itself is its shift operand; pk >> 21 the second
 //                                   shift), the first pk of a word also carries its segment count n << 26 (n >= 1) and bit 31 when n <= 4
-//                S = 2 / 4 / 8 slots per word (class 0 / 1 / 2: 4 / 8 / 16 dwords per row), chosen per strip
+//                S = 2 / 4 / 8 slots per word laid out (4 / 8 / 16 dwords per row), 2 .. 8 executed, chosen per strip
 #pragma once
 #include <stdint.h>
 
@@ -86,13 +86,27 @@ void slane_guard_need(const int32_t *ad, const int32_t *bd, const int32_t *x0, c
 struct SlaneStrip {     // per (candidate, strip)
     int64_t seg_offset; // of the segment stream, in dwords from the program base (a multiple of 64)
     int64_t fet_offset; // of the fetch stream
-    int32_t cls;        // 0 / 1 / 2 = 2 / 4 / 8 segment slots per word; -1 = the strip does not fit this scheme
+    int32_t cls;        // slot class (slane_slots / slane_exec_slots); -1 = the strip does not fit this scheme
     int32_t nseg;       // most segments any of its words needs
 };
 
-inline int slane_slots(int cls) { return 2 << cls; }
-inline int slane_seg_dwords(int cls) { return SL_K * slane_slots(cls); }  // per row
-inline int slane_class(int most) { return most <= 2 ? 0 : most <= 4 ? 1 : most <= 8 ? 2 : -1; }
+// Classes: the segment stream of a strip is LAID OUT with 2, 4 or 8 slots per word (s_load sizes), the wave EXECUTES
+// exactly as many slots as the strip's busiest word needs (a word of at most four segments still skips the rest):
+//   class            0  1  2  3  4  5  6
+//   slots laid out   2  4  8  4  8  8  8
+//   slots executed   2  4  8  3  5  6  7
+#if defined(__HIPCC__)
+#define SL_HD __host__ __device__
+#else
+#define SL_HD
+#endif
+SL_HD inline int slane_slots(int cls) { return cls == 0 ? 2 : (cls == 1 || cls == 3) ? 4 : 8; }
+SL_HD inline int slane_exec_slots(int cls) { return cls <= 2 ? 2 << cls : cls == 3 ? 3 : cls + 1; }
+SL_HD inline int slane_seg_dwords(int cls) { return SL_K * slane_slots(cls); }  // per row
+inline int slane_class(int most)
+{
+    return most <= 2 ? 0 : most == 3 ? 3 : most == 4 ? 1 : most <= 7 ? most - 1 : most == 8 ? 2 : -1;
+}
 inline int slane_records(int rows) { return (SL_PRE + rows + 63) & ~63; }  // the kernel keeps only the rows LEFT: phases are taken modulo 64
 
 // warpAffine's integer tables of one candidate on the host (the expressions of tables_kernel, kernels.hip;
@@ -119,7 +133,7 @@ struct SlaneTask {
     uint32_t rsrc[4];    // buffer descriptor of the scan group's interleaved bit image
     uint32_t nrec;       // records (a multiple of 4)
     uint32_t hpitch;     // bytes between pair rows of the row counts
-    int32_t cls;         // 0 / 1 / 2 = 2 / 4 / 8 slots per word
+    int32_t cls;         // slot class: slots laid out / executed per word (slane_slots, slane_exec_slots)
     int32_t wave;        // the pair rows of its scan group's LDS accumulators this wave flushes: first (bits 2:0), number 0 / 1 / 2 (bits 5:4)
     uint64_t planes;     // counter dump of (task, scan group): [word][SL_DUMP][64]
     uint32_t lds_base;   // LDS address of the scan group's row-count accumulators in the workgroup

@@ -105,7 +105,7 @@ __global__ __launch_bounds__(256) void slane_fill_kernel(SlaneBuild b, int ntask
     if (q >= b.nrec) return;
     const int cls = t < ntasks ? b.cls[t] : 0;
     uint32_t *seg = b.prog + (t < ntasks ? b.seg_off[t] : b.null_seg), *fet = b.prog + (t < ntasks ? b.fet_off[t] : b.null_fet);
-    const int S = 2 << cls, RD = SL_K * S;
+    const int S = slane_slots(cls), RD = SL_K * S;
     const uint32_t white = ((uint32_t)SL_ZERO << 5) | SL_PK_MODE | (1u << SL_NSHIFT) | SL_SHORT, pad = ((uint32_t)SL_ZERO << 5) | SL_PK_MODE;
     for (int k = 0; k < SL_K; k++)
         for (int j = 0; j < S; j++) seg[(int64_t)q * RD + k * S + j] = j == 0 ? white : pad;
@@ -174,7 +174,7 @@ __global__ __launch_bounds__(256) void slane_words_kernel(SlaneBuild b)
     const int32_t *ad = b.adelta + (int64_t)a * g.cols, *bd = b.bdelta + (int64_t)a * g.cols;
     const int2_t xy = b.xy0[(int64_t)a * g.rows + r];
     const int64_t tb = (int64_t)task * g.rowsG;
-    const int S = 2 << b.cls[task], RD = SL_K * S;
+    const int S = slane_slots(b.cls[task]), RD = SL_K * S;
     uint32_t *w = b.prog + b.seg_off[task] + (int64_t)(r + SL_PRE) * RD + k * S;
     uint32_t w0 = 0;
     const int n = sb_word_runs(g, ad, bd, xy.x, xy.y, strip * SL_K + k, [&](int j, int s, int src, int len) {

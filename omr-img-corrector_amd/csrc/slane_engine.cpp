@@ -153,7 +153,7 @@ int SlanePlan::build(const SweepTables &t, bool on_host)
     for (int a = 0; a < A; a++) order[(size_t)a] = a;
     auto weight = [&](int a) {
         int w = 0;
-        for (int st = 0; st < NS; st++) w += 2 << strips[(size_t)a * NS + st].cls;
+        for (int st = 0; st < NS; st++) w += slane_exec_slots(strips[(size_t)a * NS + st].cls);
         return w;
     };
     std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return weight(x) > weight(y); });

@@ -49,17 +49,17 @@ FCOM = (96, 98, 100, 12)       # commit pairs of sets A..D
 AHEAD = 4
 
 
-def word(out, k, sset, S, dreg, tag):
-    """segments of word k (pk dwords in s[sset + k * S ...]) -> VGPR dreg.  Scalar work per segment: one s_lshr writes M0
-    (ring index + mode bits); the second shift amounts of TWO segments come out of one s_lshr_b64 of their SGPR pair
-    (low dword's bits 4:0 = q of the even segment, high dword's = q of the odd one; the junk above bit 4 is ignored by
-    v_alignbit / v_lshlrev)."""
-    G = {2: 2, 4: 4, 8: 4}[S]
+def word(out, k, sset, S, dreg, tag, E=None):
+    """segments of word k (pk dwords in s[sset + k * S ...], S slots laid out, E of them executed) -> VGPR dreg.  Scalar work
+    per segment: one s_lshr writes M0 (ring index + mode bits); the second shift amounts of TWO segments come out of one
+    s_lshr_b64 of their SGPR pair (low dword's bits 4:0 = q of the even segment, high dword's = q of the odd one; the junk
+    above bit 4 is ignored by v_alignbit / v_lshlrev)."""
+    E = E or S
     Q32 = "q32" in ABLATE  # timing probe: one s_lshr_b32 per segment for the second shift instead of one s_lshr_b64 per pair
-    SKIP = "noskip" not in ABLATE  # a word of at most four segments skips the second group of four (measured: 45.1 ms with, 45.9 without)
+    SKIP = "noskip" not in ABLATE  # a word of at most four segments skips the second group (measured: 45.1 ms with, 45.9 without)
     p = lambda j: "s%d" % (sset + k * S + j)
-    for g in range(S // G):
-        js = list(range(g * G, (g + 1) * G))
+    groups = [list(range(0, min(E, 4)))] + ([list(range(4, E))] if E > 4 else [])
+    for g, js in enumerate(groups):
         for n, j in enumerate(js):
             out.append("s_lshr_b32 m0, %s, 5" % p(j))        # ring index + SRC0_REL | SRC1_REL
             out.append("v_alignbit_b32 v%d, v%d, v%d, %s" % (XR[n], RING + 1, RING, p(j)))
@@ -69,17 +69,17 @@ def word(out, k, sset, S, dreg, tag):
                 out.append("s_lshr_b32 s10, %s, 21" % p(j))
                 q = "s10"
             else:
-                if n % 2 == 0:  # the pair (j, j + 1) sits in an even-aligned SGPR pair: sets and slot counts are even
+                if n % 2 == 0:  # the pair (j, j + 1) sits in an even-aligned SGPR pair: sets and laid-out slot counts are even
                     out.append("s_lshr_b64 s[10:11], s[%d:%d], 21" % (sset + k * S + j, sset + k * S + j + 1))
                 q = "s%d" % (10 + (n & 1))
             if g == 0 and n == 0:
                 out.append("v_lshlrev_b32 v%d, %s, v%d" % (dreg, q, XR[n]))
             else:
                 out.append("v_alignbit_b32 v%d, v%d, v%d, %s" % (dreg, XR[n], dreg, q))
-        if g + 1 < S // G and SKIP:
-            out.append("s_bitcmp1_b32 %s, 31" % p(0))        # the generator's flag: at most G segments
+        if g + 1 < len(groups) and SKIP:
+            out.append("s_bitcmp1_b32 %s, 31" % p(0))        # the generator's flag: at most four segments
             out.append("s_cbranch_scc1 %s" % tag)
-    if S > G and SKIP:
+    if len(groups) > 1 and SKIP:
         out.append("%s:" % tag)
 
 
@@ -207,8 +207,8 @@ def rec_loads(out, x, S, row, force=False):
     out.append("s_load_dwordx2 s[%d:%d], s[2:3], %d" % (FCOM[x], FCOM[x] + 1, row * 32 + 16))
 
 
-def body(o, S, L):
-    """the row loop of one slot class"""
+def body(o, S, L, E=None):
+    """the row loop of one slot class: S slots laid out per word, E executed"""
     rec_loads(o, 0, S, 0, True)
     rec_loads(o, 1, S, 1, True)
     if "norec" in ABLATE:
@@ -226,8 +226,8 @@ def body(o, S, L):
         odd = r & 1
         commit_and_fetch(o, r, r)
         d = (ST[0], ST[1]) if not odd else DODD
-        word(o, 0, SEG[r], S, d[0], "L%s_r%dw0" % (L, r))
-        word(o, 1, SEG[r], S, d[1], "L%s_r%dw1" % (L, r))
+        word(o, 0, SEG[r], S, d[0], "L%s_r%dw0" % (L, r), E)
+        word(o, 1, SEG[r], S, d[1], "L%s_r%dw1" % (L, r), E)
         row_count(o, d[0], d[1], odd == 1, r == 3)
         if odd:
             carry_save(o, "L%s_cs%d" % (L, r), r == 3)
@@ -250,10 +250,13 @@ def kernel():
     o.append("s_waitcnt lgkmcnt(0)")
     o.append("s_or_b32 s9, s9, s10")
     o += ["s_set_gpr_idx_on s10, gpr_idx(SRC0)", "s_mov_b32 m0, 0"]  # index mode on for good; M0 = 0: nothing indexed
-    o += ["s_cmp_eq_u32 s11, 0", "s_cbranch_scc1 L%s_c0" % U, "s_cmp_eq_u32 s11, 1", "s_cbranch_scc1 L%s_c1" % U]
-    for cls, S in ((2, 8), (1, 4), (0, 2)):
+    # slot classes (slane.hpp): laid out / executed = 2/2, 4/4, 8/8, 4/3, 8/5, 8/6, 8/7
+    CLASSES = ((0, 2, 2), (1, 4, 4), (2, 8, 8), (3, 4, 3), (4, 8, 5), (5, 8, 6), (6, 8, 7))
+    for cls, S, E in CLASSES[:-1]:
+        o += ["s_cmp_eq_u32 s11, %d" % cls, "s_cbranch_scc1 L%s_c%d" % (U, cls)]
+    for cls, S, E in reversed(CLASSES):
         o.append("L%s_c%d:" % (U, cls))
-        body(o, S, "%s_c%d" % (U, cls))
+        body(o, S, "%s_c%d" % (U, cls), E)
         if cls:
             o.append("s_branch L%s_dump" % U)
     # ---- dump the 34 counter registers: [word][p0..p11, c0..c4][lane]
