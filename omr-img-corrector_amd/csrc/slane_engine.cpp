@@ -1,5 +1,6 @@
 // slane_engine.cpp -- host side of the scan-lane sweep: the plan (every strip's program, generated on the device by
 // slane_build.hip, or on the host's cores by slane_plan.cpp -- the reference implementation -- and uploaded), the per-launch scratch and the enqueue (slane.hpp).
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -184,7 +185,9 @@ int SlaneScratch::create(const SlanePlan &p, int groups)
     OMR_HIP(hsd.alloc(sizeof(double) * nscp * p.A));
     OMR_HIP(best.alloc(sizeof(int32_t) * nscp));
     // ---- one descriptor per (candidate in launch order, place in its workgroups, scan group of the padded table),
-    // for each composition of a workgroup: 4 strips x 4 scan groups (sgw_log 2), 8 x 2 (1), 16 x 1 (0).
+    // for each composition of a workgroup: 4 strips x 4 scan groups (sgw_log 2), 8 x 2 (1), 16 x 1 (0).  (2 x 8 for
+    // launches of 512 scans was built and measured: 41.2 ms against 40.8 -- eight-way sharing of a program through the
+    // scalar cache buys nothing over four-way.)
     // Places beyond the last strip or the last scan group are null tasks: the empty program, buffer descriptors of
     // size 0 (their fetches read zeros, their row-count adds are dropped), a spare slot for the counter dump.
     OMR_HIP(planes.alloc(sizeof(uint32_t) * (ntasks * nsg + 1) * SL_K * SL_DUMP * SL_LANES));
@@ -200,7 +203,7 @@ int SlaneScratch::create(const SlanePlan &p, int groups)
                 const SlaneStrip &S = p.strips[(size_t)task];
                 // the eight pair rows of a scan group's LDS buffer, dealt to the strips of the workgroup
                 const int place = st % places;
-                const int first = places == 4 ? 2 * place : place & 7, count = places == 4 ? 2 : place < 8 ? 1 : 0;
+                const int first = places <= 4 ? (8 / places) * place : place & 7, count = places <= 4 ? 8 / places : place < 8 ? 1 : 0;
                 for (int sg = 0; sg < nsgp; sg++) {
                     const bool real = st < g.NS && sg < nsg;
                     const bool counts = sg < nsg;  // a null strip of a real scan group still flushes that group's row counts
@@ -247,7 +250,7 @@ int slane_enqueue(const SlanePlan &p, SlaneScratch &s, const uint8_t *d_img, int
     }
     OMR_HIP(launch_slane_pack(d_img, scan_stride, step, p.g, nscans, black_max, s.bits.as<uint32_t>(), stream));
     if (ev0) OMR_HIP(hipEventRecord(ev0, stream));
-    {   // the workgroup's composition: 16 strips x 1 scan group, 8 x 2, or 4 x 4 (the scratch holds a table for each)
+    {   // the workgroup's composition: 16 strips x 1 scan group, 8 x 2 or 4 x 4 (the scratch holds a table for each)
         const int lg = used <= 1 ? 0 : used == 2 ? 1 : 2, sgw = 1 << lg, places = 16 >> lg;
         OMR_HIP(launch_slane(s.descs[lg].as<SlaneTask>(), (used + sgw - 1) / sgw, ((s.nsg + sgw - 1) / sgw) * sgw, p.A,
                              (p.g.NS + places - 1) / places, lg, s.guard.as<int32_t>(), stream));

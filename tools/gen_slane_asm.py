@@ -20,7 +20,7 @@ workgroup's other strips in LDS; one global atomic per pair row and 16 rows) -> 
 
 Register map (fixed; the statement clobbers s0-s13, s16-s101, v1-v127, so lane * 4 arrives in v0):
   s[0:1] segment stream  s[2:3] fetch stream  s[4:7] bit-image descriptor  s8 rows left (a multiple of 64 at the start:
-  row phases are taken from -s8)  s9 pair rows the wave flushes (first in bits 2:0, number in bits 5:4) | LDS base of the scan group's accumulators (a multiple of 4096)
+  row phases are taken from -s8)  s9 pair rows the wave flushes (first in bits 2:0, number in bits 6:4) | LDS base of the scan group's accumulators (a multiple of 4096)
   s[10:11] second shifts of a segment pair / scratch  s[14:15] the task (input)
   segment sets A-D: s[16:31] s[32:47] s[48:63] s[64:79]   fetch offsets A-D: s[80:83] s[84:87] s[88:91] s[92:95]
   commit pairs A-D: s[96:97] s[98:99] s[100:101] s[12:13]
@@ -118,15 +118,16 @@ def row_count(out, d0, d1, odd, second):
 
 def flush(out, L):
     """after rows 12..15 of a block of 16: the workgroup meets, then the wave reads the pair rows of its scan group's LDS
-    buffer that the task assigns to it (s9: first pair row in bits 2:0, their number -- 0, 1 or 2 -- in bits 5:4: a
-    workgroup is 4 strips x 4 scan groups, 8 x 2 or 16 x 1, and the eight pair rows of a scan group's buffer are dealt to
-    its strips), clears them and adds them to the candidate's row counts in memory.  Segment set C is dead here: it takes
-    the row-count descriptor, the record count and the pitch (s[48:53]) and the scratch (s54-s57)."""
+    buffer that the task assigns to it (s9: first pair row in bits 2:0, their number -- 0, 1, 2 or 4 -- in bits 6:4: a
+    workgroup is 4 strips x 4 scan groups, 8 x 2 or 16 x 1, and the eight pair rows of a scan group's buffer are
+    dealt to its strips), clears them and adds them to the candidate's row counts in memory, one pair row per turn of a
+    short loop.  Segment set C is dead here: it takes the row-count descriptor, the record count and the pitch (s[48:53])
+    and the scratch (s54-s57)."""
     out += ["s_sub_u32 s10, 0, s8", "s_and_b32 s10, s10, 12", "s_cmp_lg_u32 s10, 12", "s_cbranch_scc1 %s_nofl" % L]
     if "noatomic" not in ABLATE:
         out += ["s_load_dwordx4 s[48:51], %[desc], 16", "s_load_dwordx2 s[52:53], %[desc], 48",
                 "s_waitcnt lgkmcnt(0)", "s_barrier",
-                "s_bfe_u32 s57, s9, 0x20004",                              # pair rows this wave sends on
+                "s_bfe_u32 s57, s9, 0x30004",                              # pair rows this wave sends on
                 "s_cmp_eq_u32 s57, 0", "s_cbranch_scc1 %s_nofl" % L,
                 "s_sub_u32 s54, s52, s8",                                  # row index of the turn (12 mod 16)
                 "s_and_b32 s55, s54, 16", "s_lshl_b32 s55, s55, 7",        # buffer (bit 4 of the row index) * 2048
@@ -137,19 +138,14 @@ def flush(out, L):
                 "s_lshr_b32 s54, s54, 4", "s_lshl_b32 s54, s54, 3",        # first pair row of the block
                 "s_and_b32 s56, s9, 7", "s_add_u32 s54, s54, s56",         # + the wave's first pair row
                 "s_mul_i32 s54, s54, s53",                                 # * pitch
-                "s_cmp_eq_u32 s57, 1", "s_cbranch_scc1 %s_one" % L,
-                "ds_read_b32 v%d, v%d" % (CARRY[0][0], CNT2), "ds_read_b32 v%d, v%d offset:256" % (CARRY[0][1], CNT2),
-                "ds_write_b32 v%d, v%d" % (CNT2, CARRY[1][0]), "ds_write_b32 v%d, v%d offset:256" % (CNT2, CARRY[1][0]),
-                "s_waitcnt lgkmcnt(0)",
-                "buffer_atomic_add v%d, %%[lane4], s[48:51], s54 offen" % CARRY[0][0],
-                "s_add_u32 s54, s54, s53",
-                "buffer_atomic_add v%d, %%[lane4], s[48:51], s54 offen" % CARRY[0][1],
-                "s_branch %s_nofl" % L,
-                "%s_one:" % L,
+                "%s_fl:" % L,
                 "ds_read_b32 v%d, v%d" % (CARRY[0][0], CNT2),
                 "ds_write_b32 v%d, v%d" % (CNT2, CARRY[1][0]),
                 "s_waitcnt lgkmcnt(0)",
-                "buffer_atomic_add v%d, %%[lane4], s[48:51], s54 offen" % CARRY[0][0]]
+                "buffer_atomic_add v%d, %%[lane4], s[48:51], s54 offen" % CARRY[0][0],
+                "v_add_u32 v%d, 256, v%d" % (CNT2, CNT2),
+                "s_add_u32 s54, s54, s53",
+                "s_sub_u32 s57, s57, 1", "s_cmp_lg_u32 s57, 0", "s_cbranch_scc1 %s_fl" % L]
     out.append("%s_nofl:" % L)
 
 
