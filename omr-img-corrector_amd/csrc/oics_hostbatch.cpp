@@ -2,8 +2,8 @@
 // a context that owns, per device, the sweep plan, a pinned ring and two device stages, so that the copy of one launch's
 // scans overlaps the sweep of the previous one and nothing is allocated inside a run.
 //
-//   caller's scans (pageable: copier threads -> pinned ring slot of 64 scans; or already pinned: straight from the
-//   caller's memory) --async DMA on a copy stream--> device stage (one launch = up to 256 scans, two stages)
+//   caller's scans (pageable: copier threads -> pinned ring slot of 16 scans; or already pinned: straight from the
+//   caller's memory) --async DMA on a copy stream--> device stage (one launch = 64 scans, two stages)
 //   --omr_batch_run_device (scan-lane sweep when the candidates fit it, else the run-merging path)--> results, one
 //   download at the end.  Scan i goes to device i % n_devices; the only "collective" is the host-side gather.
 #include <string.h>
@@ -20,7 +20,9 @@
 using namespace omr;
 
 namespace {
-constexpr int HB_CHUNK = 64;    // scans per ring slot / DMA
+constexpr int HB_CHUNK = 16;    // scans per ring slot / DMA (139 MB at A4: DMAs of that size run at the link's rate; three slots are
+                                // 0.4 GB of pinned memory to allocate, a quarter of what 64-scan slots cost a one-off call)
+constexpr int HB_LANES_MIN = 64; // scans per device from which the scan-lane sweep is used (one full wavefront of scans)
 constexpr int HB_LAUNCH = 64;   // scans per sweep launch in scan-lane mode: the pipeline is bound by the copies (10 ms per 64 A4
                                 // scans at 56 GB/s against 6.6 ms of sweep), so what counts is the LAST launch's sweep, which
                                 // nothing overlaps -- the smaller the launch, the shorter that tail
@@ -87,8 +89,8 @@ int omr_host_batch_create(int32_t rows, int32_t cols, uint16_t max_angle, double
         if (rc) return rc;
         d->ctx.reset(raw);
         // the scan-lane sweep (its plan is built on the device in tens of milliseconds) from one full wavefront of scans on
-        if (per_dev >= HB_CHUNK) {
-            d->launch = std::min(HB_LAUNCH, ((per_dev + HB_CHUNK - 1) / HB_CHUNK) * HB_CHUNK);
+        if (per_dev >= HB_LANES_MIN) {
+            d->launch = HB_LAUNCH;
             rc = omr_batch_set_lanes(d->ctx.get(), d->launch);
             if (rc == OMR_OK) d->lanes = true;
             else if (rc != OMR_ERR_NOTIMPL) return rc;

@@ -2,6 +2,7 @@
 scores"; the reference times image-in-memory to result, packages/core/src/main.rs:68-95): omr_host_batch_run on `scans`
 binarised A4 scans, plan / pinned ring / device stages created OUTSIDE the timed region, once from pageable memory
 (copier threads -> pinned ring -> DMA) and once from page-locked memory (DMA straight from the caller's buffers).
+Also the one-off call (omr_sweep_batch: context created and released inside the call).
 Never bench.py's `value` -- that is HBM-resident by contract; bench.py reports these figures as e2e_host_*.
 Usage: python tools/bench_host.py [scans, default 512] [repeats, default 3]"""
 import json
@@ -50,6 +51,18 @@ def measure(n, repeats=3, cards=None):
         out[name + "_h2d_GBps"] = n * rows * cols / best_t / 1e9
         out[name + "_seconds"] = best_t
     hb.close()
+    # the one-off call: omr_sweep_batch creates the context (plan generated on the device, pinned ring, stages), runs the
+    # batch and releases everything -- what a caller pays who does not keep a context
+    projection.sweep_batch(pageable[:64], 10, 0.05, n_devices=1)  # (first use of the library's per-process state)
+    best_t = None
+    for _ in range(2):
+        t0 = time.perf_counter()
+        best, _, _, _ = projection.sweep_batch(pageable, 10, 0.05, n_devices=1)
+        dt = time.perf_counter() - t0
+        best_t = dt if best_t is None else min(best_t, dt)
+    assert (best == ref).all()
+    out["one_off_sweep_batch_images_per_s"] = n / best_t
+    out["one_off_sweep_batch_seconds"] = best_t
     return out
 
 
