@@ -161,6 +161,7 @@ struct SlanePlan {
 struct SlaneScratch {
     int nsg = 0;  // scan groups of 64 scans a launch may carry
     bool keep_rows = false, rows_dirty = false;  // inspection: leave the row counts in place after a launch
+    size_t rows_bytes = 0;                       // of hrows: the row counts and, behind them, the totals [candidate][scan]
     DevBuf bits, hrows, vproj, planes, descs[3], vsd, hsd, best, guard;  // descs[lg]: workgroups of (16 >> lg) strips x (1 << lg) scan groups
     int create(const SlanePlan &p, int groups);
 };

@@ -170,7 +170,7 @@ hipError_t launch_slane_pack(const uint8_t *d_img, int64_t scan_stride, int64_t 
 // nsg_used = scan groups that carry scans in this launch, nsg = scan groups the scratch (and its descriptors) is laid out for
 hipError_t launch_slane(const SlaneTask *d_descs, int nsgq, int nsgp, int A, int NQ, int sgw_log, int32_t *d_guard, hipStream_t s);
 hipError_t launch_slane_vproj(const uint32_t *d_planes, const int32_t *d_tasks, int ntasks, int nsg_used, int nsg, int NS,
-                              int cols, int off, int nrec, uint16_t *d_vproj, hipStream_t s);
-hipError_t launch_slane_stddev(const uint16_t *d_vproj, const uint32_t *d_hproj, int A, int cols, int rows, int hpairs_per_cand,
+                              int cols, int off, int nrec, uint16_t *d_vproj, uint32_t *d_total, hipStream_t s);
+hipError_t launch_slane_stddev(const uint16_t *d_vproj, const uint32_t *d_hproj, const uint32_t *d_total, int A, int cols, int rows, int hpairs_per_cand,
                                int hrow0, int nsg_used, int nsg, int nscans, double *d_v_sd, double *d_h_sd, hipStream_t s);
 }  // namespace omr

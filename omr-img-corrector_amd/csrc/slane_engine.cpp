@@ -176,8 +176,11 @@ int SlaneScratch::create(const SlanePlan &p, int groups)
     const size_t bits_b = sizeof(uint32_t) * (size_t)nsg * g.entries * SL_LANES;
     OMR_HIP(bits.alloc(bits_b));
     OMR_HIP(hipMemset(bits.p, 0, bits_b));  // entry 0 and the guard columns stay zero for good
-    OMR_HIP(hrows.alloc(sizeof(uint32_t) * (size_t)p.A * (p.nrec / 2) * nscp));  // two records per dword
-    OMR_HIP(hipMemset(hrows.p, 0, sizeof(uint32_t) * (size_t)p.A * (p.nrec / 2) * nscp));  // every launch leaves them zero again
+    // row counts, two records per dword, and behind them the black-pixel totals [candidate][scan] (added up by the
+    // column-count kernel): both are accumulated with atomics, so every launch leaves them zero again
+    rows_bytes = sizeof(uint32_t) * ((size_t)p.A * (p.nrec / 2) * nscp + (size_t)p.A * nscp);
+    OMR_HIP(hrows.alloc(rows_bytes));
+    OMR_HIP(hipMemset(hrows.p, 0, rows_bytes));
     OMR_HIP(guard.alloc(sizeof(int32_t)));
     OMR_HIP(hipMemset(guard.p, 0, sizeof(int32_t)));
     OMR_HIP(vproj.alloc(sizeof(uint16_t) * (size_t)p.A * g.cols * nscp));  // column counts <= rows <= 65535
@@ -245,7 +248,7 @@ int slane_enqueue(const SlanePlan &p, SlaneScratch &s, const uint8_t *d_img, int
     const int used = (nscans + SL_LANES - 1) / SL_LANES;  // scan groups that hold scans; the descriptors are laid out for s.nsg
     const size_t nscp = (size_t)s.nsg * SL_LANES;
     if (s.rows_dirty) {  // the previous launch was asked to keep its row counts (omr_batch_lanes_keep)
-        OMR_HIP(hipMemsetAsync(s.hrows.p, 0, sizeof(uint32_t) * (size_t)p.A * (p.nrec / 2) * nscp, stream));
+        OMR_HIP(hipMemsetAsync(s.hrows.p, 0, s.rows_bytes, stream));
         s.rows_dirty = false;
     }
     OMR_HIP(launch_slane_pack(d_img, scan_stride, step, p.g, nscans, black_max, s.bits.as<uint32_t>(), stream));
@@ -262,15 +265,16 @@ int slane_enqueue(const SlanePlan &p, SlaneScratch &s, const uint8_t *d_img, int
         stream = post_stream;
     }
     OMR_HIP(launch_slane_vproj(s.planes.as<uint32_t>(), p.d_tasks.as<int32_t>(), (int)p.tasks.size(), used, s.nsg, p.g.NS, p.g.cols,
-                               p.g.off, p.nrec, s.vproj.as<uint16_t>(), stream));
+                               p.g.off, p.nrec, s.vproj.as<uint16_t>(), s.hrows.as<uint32_t>() + (size_t)p.A * (p.nrec / 2) * nscp, stream));
     double *vs = d_v_sd ? d_v_sd : s.vsd.as<double>(), *hs = d_h_sd ? d_h_sd : s.hsd.as<double>();
-    OMR_HIP(launch_slane_stddev(s.vproj.as<uint16_t>(), s.hrows.as<uint32_t>(), p.A, p.g.cols, p.g.rows, p.nrec / 2, SL_PRE, used, s.nsg,
+    OMR_HIP(launch_slane_stddev(s.vproj.as<uint16_t>(), s.hrows.as<uint32_t>(), s.hrows.as<uint32_t>() + (size_t)p.A * (p.nrec / 2) * nscp,
+                                p.A, p.g.cols, p.g.rows, p.nrec / 2, SL_PRE, used, s.nsg,
                                 nscans, vs, hs, stream));
     if (d_best) OMR_HIP(launch_argmax_path1(vs, hs, p.A, d_best, stream, nscans));
     // the row counts are accumulated with atomics: cleared here, behind their only reader and off the sweep's stream
     // (the caller orders the next launch on this scratch set behind this stream's work)
     if (s.keep_rows) s.rows_dirty = true;
-    else OMR_HIP(hipMemsetAsync(s.hrows.p, 0, sizeof(uint32_t) * (size_t)p.A * (p.nrec / 2) * nscp, stream));
+    else OMR_HIP(hipMemsetAsync(s.hrows.p, 0, s.rows_bytes, stream));
     return OMR_OK;
 }
 
