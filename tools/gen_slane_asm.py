@@ -1,5 +1,5 @@
 """Generates omr-img-corrector_amd/csrc/slane_asm.inc: the scan-lane sweep's wave program as
-gfx950 assembly text; ONE asm statement that dispatches on the strip's segment-slot class (S = 2 / 4 / 8 per word).
+gfx950 assembly text; ONE asm statement that dispatches on the strip's segment-slot class (2 / 4 / 8 slots per word laid out, 2 .. 8 executed: seven loop bodies).
 
 Why assembly: the wave keeps its source words in a ring of 64 VGPRs addressed through the gfx9 VGPR index mode (M0),
 its segment descriptors live in SGPRs filled by s_load, and the column counters are a carry-save tree in fixed
@@ -234,7 +234,7 @@ def body(o, S, L, E=None):
 
 
 def kernel():
-    """ONE statement: descriptor, dispatch on the slot class, the three row loops, the counter dump.  (Three statements
+    """ONE statement: descriptor, dispatch on the slot class, the seven row loops, the counter dump.  (Three statements
     behind a C++ branch keep the class live across them, and with nearly every register clobbered that costs a 129th
     VGPR -- a whole wave per SIMD.)"""
     o = []
