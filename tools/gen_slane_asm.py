@@ -31,6 +31,7 @@ Register map (fixed; the statement clobbers s0-s13, s16-s101, v1-v127, so lane *
 Usage: python tools/gen_slane_asm.py   (writes the .inc; the build only reads it)"""
 import os
 
+TURN = int(os.environ.get("SLANE_TURN", "8"))  # rows per turn of the loop (4 or 8): the loop's own scalar work is paid once per turn
 ABLATE = os.environ.get("SLANE_ABLATE", "").split(",")  # timing probes only (results are wrong except noskip): norec, noatomic, nofetch, noskip
 RING = 60
 T0 = 44
@@ -113,7 +114,7 @@ def row_count(out, d0, d1, odd, second):
     out.append("v_bcnt_u32_b32 v%d, v%d, v%d" % (CNT2, d1, CNT2))
     out.append("v_lshl_or_b32 v%d, v%d, 16, v%d" % (CNT, CNT2, CNT))
     if "noatomic" not in ABLATE:
-        out.append("ds_add_u32 v%d, v%d offset:%d" % (LADDR, CNT, 256 if second else 0))
+        out.append("ds_add_u32 v%d, v%d offset:%d" % (LADDR, CNT, 256 * second))  # second: the pair's place in the turn
 
 
 def flush(out, L):
@@ -123,7 +124,8 @@ def flush(out, L):
     dealt to its strips), clears them and adds them to the candidate's row counts in memory, one pair row per turn of a
     short loop.  Segment set C is dead here: it takes the row-count descriptor, the record count and the pitch (s[48:53])
     and the scratch (s54-s57)."""
-    out += ["s_sub_u32 s10, 0, s8", "s_and_b32 s10, s10, 12", "s_cmp_lg_u32 s10, 12", "s_cbranch_scc1 %s_nofl" % L]
+    ph = 16 - TURN  # first row (mod 16) of the turn that ends a block of 16
+    out += ["s_sub_u32 s10, 0, s8", "s_and_b32 s10, s10, %d" % ph, "s_cmp_lg_u32 s10, %d" % ph, "s_cbranch_scc1 %s_nofl" % L]
     if "noatomic" not in ABLATE:
         out += ["s_load_dwordx4 s[48:51], %[desc], 16", "s_load_dwordx2 s[52:53], %[desc], 48",
                 "s_waitcnt lgkmcnt(0)", "s_barrier",
@@ -157,7 +159,7 @@ def xor3(out, d, a, b, c):
     out.append("v_bitop3_b32 v%d, v%d, v%d, v%d bitop3:0x96" % (d, a, b, c))
 
 
-def carry_save(out, L, second):
+def carry_save(out, L, second, grp=0):
     """odd row of a pair: (even row's word in c0, this row's word in DODD) -> the carry-save tree.  First pair of the turn:
     bit 1 of the row index is clear, the carry is parked in c1; second pair: c1 is consumed and bits 2.. of the row index
     (= -rows left, modulo 64) say how far the carry travels."""
@@ -172,7 +174,7 @@ def carry_save(out, L, second):
         maj(out, CARRY[k][1], P[k] + 1, ST[k] + 1, CARRY[k][0])
         xor3(out, P[k] + 1, P[k] + 1, ST[k] + 1, CARRY[k][0])
     cur = 1
-    out.append("s_sub_u32 s11, 0, s8")
+    out.append("s_sub_u32 s11, %d, s8" % (4 * grp))  # row index of this group of four rows (s8 = rows left at the turn's start)
     for lv in range(2, NST):
         out.append("s_bitcmp1_b32 s11, %d" % lv)
         out.append("s_cbranch_scc1 %s_add%d" % (L, lv))
@@ -214,23 +216,23 @@ def body(o, S, L, E=None):
     # LDS address of this turn's two pair slots: buffer = bit 4 of the row index, slot = bits 3:1
     o += ["s_sub_u32 s10, 0, s8", "s_bfe_u32 s10, s10, 0x40001", "s_lshl_b32 s10, s10, 8", "s_and_b32 s11, s9, 0xfffff000",
           "s_add_u32 s10, s10, s11", "v_add_u32 v%d, s10, %%[lane4]" % LADDR]
-    for r in range(4):
+    for r in range(TURN):
         if r % 2 == 0:  # a batch of two rows: everything requested two rows ago is here; request the next two rows
             o.append("s_waitcnt lgkmcnt(0)")
             rec_loads(o, (r + 2) % 4, S, r + 2)
             rec_loads(o, (r + 3) % 4, S, r + 3)
         odd = r & 1
-        commit_and_fetch(o, r, r)
+        commit_and_fetch(o, r % 4, r % 4)
         d = (ST[0], ST[1]) if not odd else DODD
-        word(o, 0, SEG[r], S, d[0], "L%s_r%dw0" % (L, r), E)
-        word(o, 1, SEG[r], S, d[1], "L%s_r%dw1" % (L, r), E)
-        row_count(o, d[0], d[1], odd == 1, r == 3)
+        word(o, 0, SEG[r % 4], S, d[0], "L%s_r%dw0" % (L, r), E)
+        word(o, 1, SEG[r % 4], S, d[1], "L%s_r%dw1" % (L, r), E)
+        row_count(o, d[0], d[1], odd == 1, r // 2)
         if odd:
-            carry_save(o, "L%s_cs%d" % (L, r), r == 3)
+            carry_save(o, "L%s_cs%d" % (L, r), (r & 2) != 0, r // 4)
     flush(o, "L%s" % L)
-    o += ["s_add_u32 s0, s0, %d" % (4 * 2 * S * 4), "s_addc_u32 s1, s1, 0",
-          "s_add_u32 s2, s2, 128", "s_addc_u32 s3, s3, 0",
-          "s_sub_u32 s8, s8, 4", "s_cmp_lg_u32 s8, 0", "s_cbranch_scc1 L%s_loop" % L]
+    o += ["s_add_u32 s0, s0, %d" % (TURN * 2 * S * 4), "s_addc_u32 s1, s1, 0",
+          "s_add_u32 s2, s2, %d" % (TURN * 32), "s_addc_u32 s3, s3, 0",
+          "s_sub_u32 s8, s8, %d" % TURN, "s_cmp_lg_u32 s8, 0", "s_cbranch_scc1 L%s_loop" % L]
 
 
 def kernel():
