@@ -94,7 +94,8 @@ def commit_and_fetch(out, x, tset):
                              "s_and_b32 m0, s%d, 0xffff" % c1, "s_lshr_b32 m0, s%d, 16" % c1)):
         out.append(ins)                                          # ring register | DST_REL
         out.append("v_mov_b32 v%d, v%d" % (RING, t + f))
-    out.append("s_mov_b32 m0, 0")
+    # (M0 is left as it is: the loads below are not vector-ALU instructions -- the index mode does not touch them -- and the
+    # next vector-ALU instruction is a word's first indexed v_alignbit, right behind its own M0 write)
     for f in range(4):
         if "nofetch" not in ABLATE:
             out.append("buffer_load_dword v%d, %%[lane4], s[4:7], s%d offen" % (t + f, FOFF[x] + f))
