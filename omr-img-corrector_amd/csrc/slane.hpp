@@ -56,6 +56,7 @@ constexpr int SL_QSHIFT = 21, SL_NSHIFT = 26;           // pk fields: second shi
 constexpr uint32_t SL_SHORT = 0x80000000u;              // first pk of a word: at most four segments
 constexpr int SL_GX = 4;                                // least zero guard, word columns on either side
 constexpr int SL_LANES = 64;
+constexpr int SL_BLOCK = 64;                            // rows between two meetings of a workgroup (row counts leave its LDS)
 constexpr int SL_DUMP = 17;                             // registers a wave dumps per word: planes p0..p11, carries c0..c4
 
 struct SlaneGeom {

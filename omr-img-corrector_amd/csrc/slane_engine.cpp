@@ -204,9 +204,10 @@ int SlaneScratch::create(const SlanePlan &p, int groups)
                 const size_t ti = (size_t)ai * g.NS + (st < g.NS ? st : 0);  // index into p.tasks (launch order)
                 const int task = p.tasks[ti], a = task / g.NS;
                 const SlaneStrip &S = p.strips[(size_t)task];
-                // the eight pair rows of a scan group's LDS buffer, dealt to the strips of the workgroup
                 const int place = st % places;
-                const int first = places <= 4 ? (8 / places) * place : place & 7, count = places <= 4 ? 8 / places : place < 8 ? 1 : 0;
+                // the SL_BLOCK / 2 pair rows of a scan group's LDS buffer, dealt to the strips of the workgroup
+                constexpr int PR = SL_BLOCK / 2;
+                const int first = places <= PR ? (PR / places) * place : place % PR, count = places <= PR ? PR / places : place < PR ? 1 : 0;
                 for (int sg = 0; sg < nsgp; sg++) {
                     const bool real = st < g.NS && sg < nsg;
                     const bool counts = sg < nsg;  // a null strip of a real scan group still flushes that group's row counts
@@ -228,8 +229,8 @@ int SlaneScratch::create(const SlanePlan &p, int groups)
                     k.nrec = (uint32_t)p.nrec;
                     k.hpitch = (uint32_t)(nscp * 4);
                     k.cls = real ? S.cls : 0;
-                    k.wave = first | (count << 4);
-                    k.lds_base = (uint32_t)((sg % sgw) * 2 * 8 * SL_LANES * 4);
+                    k.wave = first | (count << 8);
+                    k.lds_base = (uint32_t)((sg % sgw) * 2 * (SL_BLOCK / 2) * SL_LANES * 4);
                 }
             }
         OMR_HIP(descs[lg].alloc(sizeof(SlaneTask) * h.size()));

@@ -20,7 +20,7 @@ workgroup's other strips in LDS; one global atomic per pair row and 16 rows) -> 
 
 Register map (fixed; the statement clobbers s0-s13, s16-s101, v1-v127, so lane * 4 arrives in v0):
   s[0:1] segment stream  s[2:3] fetch stream  s[4:7] bit-image descriptor  s8 rows left (a multiple of 64 at the start:
-  row phases are taken from -s8)  s9 pair rows the wave flushes (first in bits 2:0, number in bits 6:4) | LDS base of the scan group's accumulators (a multiple of 4096)
+  row phases are taken from -s8)  s9 pair rows the wave flushes (first in bits 4:0, number in bits 11:8) | LDS base of the scan group's accumulators (a multiple of 4096)
   s[10:11] second shifts of a segment pair / scratch  s[14:15] the task (input)
   segment sets A-D: s[16:31] s[32:47] s[48:63] s[64:79]   fetch offsets A-D: s[80:83] s[84:87] s[88:91] s[92:95]
   commit pairs A-D: s[96:97] s[98:99] s[100:101] s[12:13]
@@ -31,6 +31,8 @@ Register map (fixed; the statement clobbers s0-s13, s16-s101, v1-v127, so lane *
 Usage: python tools/gen_slane_asm.py   (writes the .inc; the build only reads it)"""
 import os
 
+BLOCK = int(os.environ.get("SLANE_BLOCK", "64"))  # rows between two meetings of the workgroup (16, 32 or 64): its LDS row-count buffers hold BLOCK / 2 pair rows
+LB = {16: 4, 32: 5, 64: 6}[BLOCK]
 TURN = int(os.environ.get("SLANE_TURN", "8"))  # rows per turn of the loop (4 or 8): the loop's own scalar work is paid once per turn
 ABLATE = os.environ.get("SLANE_ABLATE", "").split(",")  # timing probes only (results are wrong except noskip): norec, noatomic, nofetch, noskip
 RING = 60
@@ -119,27 +121,29 @@ def row_count(out, d0, d1, odd, second):
 
 
 def flush(out, L):
-    """after rows 12..15 of a block of 16: the workgroup meets, then the wave reads the pair rows of its scan group's LDS
-    buffer that the task assigns to it (s9: first pair row in bits 2:0, their number -- 0, 1, 2 or 4 -- in bits 6:4: a
-    workgroup is 4 strips x 4 scan groups, 8 x 2 or 16 x 1, and the eight pair rows of a scan group's buffer are
-    dealt to its strips), clears them and adds them to the candidate's row counts in memory, one pair row per turn of a
+    """after the last rows of a block of BLOCK rows: the workgroup meets, then the wave reads the pair rows of its scan
+    group's LDS buffer that the task assigns to it (s9: first pair row in bits 4:0, their number in bits
+    11:8: a workgroup is 4 strips x 4 scan groups, 8 x 2 or 16 x 1, and the BLOCK / 2 pair rows of a scan group's buffer
+    are dealt to its strips), clears them and adds them to the candidate's row counts in memory, one pair row per turn of a
     short loop.  Segment set C is dead here: it takes the row-count descriptor, the record count and the pitch (s[48:53])
     and the scratch (s54-s57)."""
-    ph = 16 - TURN  # first row (mod 16) of the turn that ends a block of 16
+    ph = BLOCK - TURN  # first row (mod BLOCK) of the turn that ends a block
     out += ["s_sub_u32 s10, 0, s8", "s_and_b32 s10, s10, %d" % ph, "s_cmp_lg_u32 s10, %d" % ph, "s_cbranch_scc1 %s_nofl" % L]
     if "noatomic" not in ABLATE:
         out += ["s_load_dwordx4 s[48:51], %[desc], 16", "s_load_dwordx2 s[52:53], %[desc], 48",
                 "s_waitcnt lgkmcnt(0)", "s_barrier",
-                "s_bfe_u32 s57, s9, 0x30004",                              # pair rows this wave sends on
+                "s_bfe_u32 s57, s9, 0x40008",                              # pair rows this wave sends on (bits 11:8)
                 "s_cmp_eq_u32 s57, 0", "s_cbranch_scc1 %s_nofl" % L,
                 "s_sub_u32 s54, s52, s8",                                  # row index of the turn (12 mod 16)
-                "s_and_b32 s55, s54, 16", "s_lshl_b32 s55, s55, 7",        # buffer (bit 4 of the row index) * 2048
+                # the block's buffer: that bit of -s8, as the adds computed it (the number of records is a multiple of 64, not
+                # of 128: -s8 and the row index agree modulo 64 only), * BLOCK / 2 * 256 bytes
+                "s_sub_u32 s55, 0, s8", "s_and_b32 s55, s55, %d" % BLOCK, "s_lshl_b32 s55, s55, 7",
                 "s_and_b32 s56, s9, 0xfffff000", "s_add_u32 s55, s55, s56",  # + this scan group's accumulators
-                "s_and_b32 s56, s9, 7", "s_lshl_b32 s56, s56, 8", "s_add_u32 s55, s55, s56",  # + first pair row * 256 bytes
+                "s_and_b32 s56, s9, 31", "s_lshl_b32 s56, s56, 8", "s_add_u32 s55, s55, s56",  # + first pair row * 256 bytes
                 "v_add_u32 v%d, s55, %%[lane4]" % CNT2,
                 "v_mov_b32 v%d, 0" % CARRY[1][0],
-                "s_lshr_b32 s54, s54, 4", "s_lshl_b32 s54, s54, 3",        # first pair row of the block
-                "s_and_b32 s56, s9, 7", "s_add_u32 s54, s54, s56",         # + the wave's first pair row
+                "s_lshr_b32 s54, s54, %d" % LB, "s_lshl_b32 s54, s54, %d" % (LB - 1),  # first pair row of the block
+                "s_and_b32 s56, s9, 31", "s_add_u32 s54, s54, s56",        # + the wave's first pair row
                 "s_mul_i32 s54, s54, s53",                                 # * pitch
                 "%s_fl:" % L,
                 "ds_read_b32 v%d, v%d" % (CARRY[0][0], CNT2),
@@ -214,8 +218,8 @@ def body(o, S, L, E=None):
         rec_loads(o, 2, S, 2, True)
         rec_loads(o, 3, S, 3, True)
     o.append("L%s_loop:" % L)
-    # LDS address of this turn's two pair slots: buffer = bit 4 of the row index, slot = bits 3:1
-    o += ["s_sub_u32 s10, 0, s8", "s_bfe_u32 s10, s10, 0x40001", "s_lshl_b32 s10, s10, 8", "s_and_b32 s11, s9, 0xfffff000",
+    # LDS address of this turn's pair slots: buffer = bit log2(BLOCK) of the row index, slot = the bits below it down to 1
+    o += ["s_sub_u32 s10, 0, s8", "s_bfe_u32 s10, s10, 0x%x" % ((LB << 16) | 1), "s_lshl_b32 s10, s10, 8", "s_and_b32 s11, s9, 0xfffff000",
           "s_add_u32 s10, s10, s11", "v_add_u32 v%d, s10, %%[lane4]" % LADDR]
     for r in range(TURN):
         if r % 2 == 0:  # a batch of two rows: everything requested two rows ago is here; request the next two rows
@@ -281,6 +285,7 @@ out = ["// GENERATED by tools/gen_slane_asm.py -- do not edit; see that file for
 body_txt = "\\n\\t\"\n    \"".join(kernel())
 out.append("#define SLANE_ASM \\\n    \"%s\\n\\t\"\n" % body_txt.replace("\n", " \\\n"))
 out.append("#define SLANE_ASM_CLOBBERS %s\n" % ", ".join(CLOB))
+out.append("#define SLANE_ASM_BLOCK %d  // rows between two meetings of the workgroup\n" % BLOCK)
 path = os.environ.get("SLANE_ASM_OUT") or os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
                                                        "omr-img-corrector_amd", "csrc", "slane_asm.inc")
 open(path, "w").write("".join(out))
