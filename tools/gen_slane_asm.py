@@ -33,7 +33,7 @@ import os
 
 BLOCK = int(os.environ.get("SLANE_BLOCK", "64"))  # rows between two meetings of the workgroup (16, 32 or 64): its LDS row-count buffers hold BLOCK / 2 pair rows
 LB = {16: 4, 32: 5, 64: 6}[BLOCK]
-TURN = int(os.environ.get("SLANE_TURN", "8"))  # rows per turn of the loop (4 or 8): the loop's own scalar work is paid once per turn
+TURN = int(os.environ.get("SLANE_TURN", "16"))  # rows per turn of the loop (4, 8 or 16): the loop's own scalar work is paid once per turn
 ABLATE = os.environ.get("SLANE_ABLATE", "").split(",")  # timing probes only (results are wrong except noskip): norec, noatomic, nofetch, noskip
 RING = 60
 T0 = 44
