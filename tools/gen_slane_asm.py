@@ -179,8 +179,24 @@ def carry_save(out, L, second, grp=0):
         maj(out, CARRY[k][1], P[k] + 1, ST[k] + 1, CARRY[k][0])
         xor3(out, P[k] + 1, P[k] + 1, ST[k] + 1, CARRY[k][0])
     cur = 1
-    out.append("s_sub_u32 s11, %d, s8" % (4 * grp))  # row index of this group of four rows (s8 = rows left at the turn's start)
+    # bits 2.. of the row index say how far the carry travels: the bits below log2(TURN) are known here (grp = this group of
+    # four rows within the turn), the others are read from -s8 (the turn's first row, modulo 64)
+    known = {4: 0, 8: 1, 16: 2}[TURN]
+    sub_done = False
     for lv in range(2, NST):
+        if lv - 2 < known:
+            if not (grp >> (lv - 2)) & 1:  # the carry is parked at this level: done, nothing to decide at run time
+                for k in range(2):
+                    out.append("v_mov_b32 v%d, v%d" % (ST[k] + lv, CARRY[k][cur]))
+                return
+            for k in range(2):
+                maj(out, CARRY[k][cur ^ 1], P[k] + lv, ST[k] + lv, CARRY[k][cur])
+                xor3(out, P[k] + lv, P[k] + lv, ST[k] + lv, CARRY[k][cur])
+            cur ^= 1
+            continue
+        if not sub_done:
+            out.append("s_sub_u32 s11, 0, s8")
+            sub_done = True
         out.append("s_bitcmp1_b32 s11, %d" % lv)
         out.append("s_cbranch_scc1 %s_add%d" % (L, lv))
         for k in range(2):
