@@ -215,7 +215,7 @@ int omr_slane_strip_program(int32_t rows, int32_t cols, const double *fwd_M, int
 /* Switch a batch context to the scan-lane sweep: every launch then carries up to max_scans_per_launch scans (whole
  * groups of 64, at most 4096), 64 scans per wavefront; results are bit-identical to the run-merging path.  The
  * programs of all (candidate, strip) pairs are generated on the device, once (about 45 ms and 4.7 GB of HBM for
- * 2480x3508 with 400 candidates).  A launch of up to 64 / 128 / 256 scans takes about 6.5 / 11.6 / 21 ms at that size:
+ * 2480x3508 with 400 candidates).  A launch of up to 64 / 128 / 256 scans takes about 5.9 / 10.4 / 19 ms at that size:
  * size launches in multiples of 64.  0 switches back.  OMR_ERR_NOTIMPL, context unchanged, when a candidate does not
  * fit the scheme (beyond about +-10 degrees at unit scale, or more than 4078 rows). */
 int omr_batch_set_lanes(omr_batch_ctx *ctx, int32_t max_scans_per_launch);
