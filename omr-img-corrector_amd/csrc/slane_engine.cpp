@@ -158,6 +158,18 @@ int SlanePlan::build(const SweepTables &t, bool on_host)
         return w;
     };
     std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return weight(x) > weight(y); });
+    {   // ... and the 32 candidates that share an XCD (a unit of slane_kernel's launch order) turn the same way: +theta and
+        // -theta weigh the same but read source columns up to 2 rows tan(theta) apart, so a mixed chunk shares half as much
+        // in that XCD's L2.  Blocks of 32 are taken in turn from the clockwise and the counter-clockwise candidates.
+        std::vector<int> side[2], merged;
+        for (int a : order) side[t.host_minv[6 * (size_t)a + 1] < 0.0 ? 1 : 0].push_back(a);
+        size_t at[2] = {0, 0};
+        while (at[0] < side[0].size() || at[1] < side[1].size()) {
+            int pick = at[0] >= side[0].size() ? 1 : at[1] >= side[1].size() ? 0 : (weight(side[0][at[0]]) >= weight(side[1][at[1]]) ? 0 : 1);
+            for (int k = 0; k < 32 && at[pick] < side[pick].size(); k++) merged.push_back(side[pick][at[pick]++]);
+        }
+        order.swap(merged);
+    }
     tasks.clear();
     for (int a : order)
         for (int st = 0; st < NS; st++) tasks.push_back(a * NS + st);
