@@ -16,7 +16,7 @@ a segment is ONE dword (slane.hpp) -- no masks, a word is assembled by funnel sh
     D = X << q  (first segment)   |   D = v_alignbit(X, D, q)  (the others: X's low q bits enter at the top)
 Per row:  wait until the loads issued four rows ago have landed (counted: vector loads return in order) -> commit them
 into the ring (v_mov with DST_REL) -> issue this row's four loads -> two words -> row count (pairs of rows meet the
-workgroup's other strips in LDS; one global atomic per pair row and 16 rows) -> (odd rows) carry-save column counters.
+workgroup's other strips in LDS; one global atomic per pair row and block of BLOCK rows) -> (odd rows) carry-save column counters.
 
 Register map (fixed; the statement clobbers s0-s13, s16-s101, v1-v127, so lane * 4 arrives in v0):
   s[0:1] segment stream  s[2:3] fetch stream  s[4:7] bit-image descriptor  s8 rows left (a multiple of 64 at the start:
@@ -106,7 +106,7 @@ def commit_and_fetch(out, x, tset):
 def row_count(out, d0, d1, odd, second):
     """Row counts leave the wave as PAIRS: even row in the low half of a dword, odd row in the high half (a count is at
     most 64 per wave and 2480 per row, so neither half can overflow).  The four waves of a scan group in the workgroup --
-    four adjacent strips -- add their pairs in LDS (ds_add_u32); every 16 rows the workgroup meets and each wave sends
+    four adjacent strips -- add their pairs in LDS (ds_add_u32); every BLOCK rows the workgroup meets and each wave sends
     two of the eight accumulated pair rows on with ONE global atomic per pair row (flush()).  With one global atomic
     per wave and row the kernel issued 1.8e9 L2 atomic requests per launch: 25 ms."""
     if not odd:
