@@ -424,7 +424,7 @@ def main():
     lanes_mode = False
     if args.lanes > 0:
         try:
-            batch.set_lanes(min(B, args.lanes))  # builds every strip's program on the host's cores, uploads them once
+            batch.set_lanes(min(B, args.lanes))  # the programs of every strip are generated on the device, once
             lanes_mode = True
         except oics.OmrError as e:
             if e.code != -213:
