@@ -157,6 +157,9 @@ struct SlanePlan {
     // OMR_ERR_NOTIMPL when a candidate does not fit the scheme.  on_host: slane_plan.cpp's generator (the reference
     // implementation, 16 host threads + upload) instead of slane_build.hip's
     int build(const SweepTables &t, bool on_host = false);
+    void layout();                                 // seg_offset / fet_offset of every strip, the null program, prog_dwords
+    int generate_on_device(const SweepTables &t);  // classes + programs by slane_build.hip
+    int generate_on_host(const SweepTables &t);    // ... by slane_plan.cpp on the host's threads, then one upload
 };
 struct SlaneScratch {
     int nsg = 0;  // scan groups of 64 scans a launch may carry

@@ -19,97 +19,89 @@ static int host_threads()
     return (int)std::max(1u, std::min(hw ? hw : 4u, 16u));
 }
 
-int SlanePlan::build(const SweepTables &t, bool on_host)
+static const char *kNoFit = "a candidate does not fit the scan-lane scheme (more than 8 segments per word, more than 4 word "
+                            "columns per source row, or a ring schedule that does not fit 16 source rows)";
+
+// the streams' places in the program buffer, from the strips' classes
+void SlanePlan::layout()
+{
+    int64_t off = 0;
+    for (auto &S : strips) {
+        S.seg_offset = off;
+        off += ((int64_t)nrec * slane_seg_dwords(S.cls) + 63) & ~63ll;
+        S.fet_offset = off;
+        off += ((int64_t)nrec * SL_FREC + 63) & ~63ll;
+    }
+    // the null program (class 0: nothing to fetch, empty words) for the places of a workgroup beyond the last strip
+    null_seg = off;
+    off += ((int64_t)nrec * slane_seg_dwords(0) + 63) & ~63ll;
+    null_fet = off;
+    off += ((int64_t)nrec * SL_FREC + 63) & ~63ll;
+    prog_dwords = off + 256;  // the kernel reads one record past a stream's last one
+}
+
+// the device generator (slane_build.hip): scan -> classes and layout on the host -> emit
+int SlanePlan::generate_on_device(const SweepTables &t)
+{
+    const size_t ntasks = (size_t)A * g.NS, nrow = ntasks * (size_t)g.rowsG;
+    DevBuf cmin, cmax, first, last, most, bad, used, freg, d_seg, d_fet, d_cls;
+    OMR_HIP(cmin.alloc(4 * nrow));
+    OMR_HIP(cmax.alloc(4 * nrow));
+    OMR_HIP(first.alloc(4 * nrow));
+    OMR_HIP(last.alloc(4 * nrow));
+    OMR_HIP(most.alloc(4 * ntasks));
+    OMR_HIP(bad.alloc(4));
+    OMR_HIP(hipMemset(most.p, 0, 4 * ntasks));
+    OMR_HIP(hipMemset(bad.p, 0, 4));
+    SlaneBuild b{};
+    b.g = g;
+    b.nrec = nrec;
+    b.adelta = t.adelta.as<int32_t>();
+    b.bdelta = t.bdelta.as<int32_t>();
+    b.xy0 = t.xy0.as<int2_t>();
+    b.cmin = cmin.as<int32_t>(), b.cmax = cmax.as<int32_t>(), b.first = first.as<int32_t>(), b.last = last.as<int32_t>();
+    b.most = most.as<int32_t>(), b.bad = bad.as<int32_t>();
+    OMR_HIP(launch_slane_build_scan(b, (int)ntasks, nullptr));
+    std::vector<int32_t> hm(ntasks);
+    OMR_HIP(hipMemcpy(hm.data(), most.p, 4 * ntasks, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < ntasks; i++) {
+        strips[i].nseg = hm[i] > 8 ? -1 : hm[i];
+        strips[i].cls = hm[i] > 8 ? -1 : slane_class(hm[i]);
+        if (strips[i].cls < 0) return fail(OMR_ERR_NOTIMPL, "%s", kNoFit);
+    }
+    layout();
+    std::vector<int64_t> hs(ntasks), hf(ntasks);
+    std::vector<int32_t> hc(ntasks);
+    for (size_t i = 0; i < ntasks; i++) hs[i] = strips[i].seg_offset, hf[i] = strips[i].fet_offset, hc[i] = strips[i].cls;
+    OMR_HIP(d_seg.alloc(8 * ntasks));
+    OMR_HIP(d_fet.alloc(8 * ntasks));
+    OMR_HIP(d_cls.alloc(4 * ntasks));
+    OMR_HIP(hipMemcpy(d_seg.p, hs.data(), 8 * ntasks, hipMemcpyHostToDevice));
+    OMR_HIP(hipMemcpy(d_fet.p, hf.data(), 8 * ntasks, hipMemcpyHostToDevice));
+    OMR_HIP(hipMemcpy(d_cls.p, hc.data(), 4 * ntasks, hipMemcpyHostToDevice));
+    OMR_HIP(used.alloc(ntasks * (size_t)nrec));
+    OMR_HIP(freg.alloc(ntasks * (size_t)nrec * SL_FETCH));
+    OMR_HIP(hipMemset(used.p, 0, ntasks * (size_t)nrec));
+    OMR_HIP(hipMemset(freg.p, SL_DUMMY, ntasks * (size_t)nrec * SL_FETCH));
+    OMR_HIP(prog.alloc(sizeof(uint32_t) * (size_t)prog_dwords));
+    OMR_HIP(hipMemset(prog.p, 0, sizeof(uint32_t) * (size_t)prog_dwords));
+    b.used = used.as<uint8_t>(), b.freg = freg.as<uint8_t>();
+    b.prog = prog.as<uint32_t>();
+    b.seg_off = d_seg.as<int64_t>(), b.fet_off = d_fet.as<int64_t>(), b.cls = d_cls.as<int32_t>();
+    b.null_seg = null_seg, b.null_fet = null_fet;
+    OMR_HIP(launch_slane_build_emit(b, (int)ntasks, nullptr));
+    int32_t hb = 0;
+    OMR_HIP(hipMemcpy(&hb, bad.p, 4, hipMemcpyDeviceToHost));  // (synchronises: the scratch is released on return)
+    if (hb) return fail(OMR_ERR_NOTIMPL, "%s", kNoFit);
+    return OMR_OK;
+}
+
+// the host generator (slane_plan.cpp, the reference implementation): pass 1, the class of every strip (most segments per
+// word); pass 2, the streams; candidates dealt to the host's threads; one upload
+int SlanePlan::generate_on_host(const SweepTables &t)
 {
     const SweepDims &d = t.dims;
-    if (d.rows + SL_PRE + 1 >= 4096) return fail(OMR_ERR_NOTIMPL, "scan-lane sweep: more than 4078 rows (12 counter planes)");
-    if (d.cols > 65535) return fail(OMR_ERR_NOTIMPL, "scan-lane sweep: more than 65535 columns (row counts travel as u16)");
-    // the zero guard around the bit images: what the steepest candidate reaches outside the image
-    int gx = 0, gy = 0;
-    {
-        std::vector<int32_t> ad, bd, x0, y0;
-        for (int a = 0; a < d.A; a++) {
-            int cx, cy;
-            slane_host_tables(&t.host_minv[6 * (size_t)a], d.rows, d.cols, ad, bd, x0, y0);
-            slane_guard_need(ad.data(), bd.data(), x0.data(), y0.data(), d.rows, d.cols, &cx, &cy);
-            gx = std::max(gx, cx), gy = std::max(gy, cy);
-        }
-    }
-    g.set(d.rows, d.cols, gx, gy);
-    A = d.A;
-    nrec = slane_records(d.rows);
     const int NS = g.NS, T = host_threads();
-    strips.assign((size_t)A * NS, SlaneStrip{0, 0, -1, 0});
-    auto layout = [&]() {  // the streams' places in the program buffer, from the strips' classes
-        int64_t off = 0;
-        for (auto &S : strips) {
-            S.seg_offset = off;
-            off += ((int64_t)nrec * slane_seg_dwords(S.cls) + 63) & ~63ll;
-            S.fet_offset = off;
-            off += ((int64_t)nrec * SL_FREC + 63) & ~63ll;
-        }
-        // the null program (class 0: nothing to fetch, empty words) for the places of a workgroup beyond the last strip
-        null_seg = off;
-        off += ((int64_t)nrec * slane_seg_dwords(0) + 63) & ~63ll;
-        null_fet = off;
-        off += ((int64_t)nrec * SL_FREC + 63) & ~63ll;
-        prog_dwords = off + 256;  // the kernel reads one record past a stream's last one
-    };
-    const char *nofit = "a candidate does not fit the scan-lane scheme (more than 8 segments per word, more than 4 word columns per source row, or a ring schedule that does not fit 16 source rows)";
-    if (!on_host) {
-        // ---- the device generator (slane_build.hip): scan -> classes and layout on the host -> emit
-        const size_t ntasks = (size_t)A * NS, nrow = ntasks * (size_t)g.rowsG;
-        DevBuf cmin, cmax, first, last, most, bad, used, freg, d_seg, d_fet, d_cls;
-        OMR_HIP(cmin.alloc(4 * nrow));
-        OMR_HIP(cmax.alloc(4 * nrow));
-        OMR_HIP(first.alloc(4 * nrow));
-        OMR_HIP(last.alloc(4 * nrow));
-        OMR_HIP(most.alloc(4 * ntasks));
-        OMR_HIP(bad.alloc(4));
-        OMR_HIP(hipMemset(most.p, 0, 4 * ntasks));
-        OMR_HIP(hipMemset(bad.p, 0, 4));
-        SlaneBuild b{};
-        b.g = g;
-        b.nrec = nrec;
-        b.adelta = t.adelta.as<int32_t>();
-        b.bdelta = t.bdelta.as<int32_t>();
-        b.xy0 = t.xy0.as<int2_t>();
-        b.cmin = cmin.as<int32_t>(), b.cmax = cmax.as<int32_t>(), b.first = first.as<int32_t>(), b.last = last.as<int32_t>();
-        b.most = most.as<int32_t>(), b.bad = bad.as<int32_t>();
-        OMR_HIP(launch_slane_build_scan(b, (int)ntasks, nullptr));
-        std::vector<int32_t> hm(ntasks);
-        OMR_HIP(hipMemcpy(hm.data(), most.p, 4 * ntasks, hipMemcpyDeviceToHost));
-        for (size_t i = 0; i < ntasks; i++) {
-            strips[i].nseg = hm[i] > 8 ? -1 : hm[i];
-            strips[i].cls = hm[i] > 8 ? -1 : slane_class(hm[i]);
-            if (strips[i].cls < 0) return fail(OMR_ERR_NOTIMPL, "%s", nofit);
-        }
-        layout();
-        std::vector<int64_t> hs(ntasks), hf(ntasks);
-        std::vector<int32_t> hc(ntasks);
-        for (size_t i = 0; i < ntasks; i++) hs[i] = strips[i].seg_offset, hf[i] = strips[i].fet_offset, hc[i] = strips[i].cls;
-        OMR_HIP(d_seg.alloc(8 * ntasks));
-        OMR_HIP(d_fet.alloc(8 * ntasks));
-        OMR_HIP(d_cls.alloc(4 * ntasks));
-        OMR_HIP(hipMemcpy(d_seg.p, hs.data(), 8 * ntasks, hipMemcpyHostToDevice));
-        OMR_HIP(hipMemcpy(d_fet.p, hf.data(), 8 * ntasks, hipMemcpyHostToDevice));
-        OMR_HIP(hipMemcpy(d_cls.p, hc.data(), 4 * ntasks, hipMemcpyHostToDevice));
-        OMR_HIP(used.alloc(ntasks * (size_t)nrec));
-        OMR_HIP(freg.alloc(ntasks * (size_t)nrec * SL_FETCH));
-        OMR_HIP(hipMemset(used.p, 0, ntasks * (size_t)nrec));
-        OMR_HIP(hipMemset(freg.p, SL_DUMMY, ntasks * (size_t)nrec * SL_FETCH));
-        OMR_HIP(prog.alloc(sizeof(uint32_t) * (size_t)prog_dwords));
-        OMR_HIP(hipMemset(prog.p, 0, sizeof(uint32_t) * (size_t)prog_dwords));
-        b.used = used.as<uint8_t>(), b.freg = freg.as<uint8_t>();
-        b.prog = prog.as<uint32_t>();
-        b.seg_off = d_seg.as<int64_t>(), b.fet_off = d_fet.as<int64_t>(), b.cls = d_cls.as<int32_t>();
-        b.null_seg = null_seg, b.null_fet = null_fet;
-        OMR_HIP(launch_slane_build_emit(b, (int)ntasks, nullptr));
-        int32_t hb = 0;
-        OMR_HIP(hipMemcpy(&hb, bad.p, 4, hipMemcpyDeviceToHost));  // (synchronises: the scratch is released on return)
-        if (hb) return fail(OMR_ERR_NOTIMPL, "%s", nofit);
-    } else {
-    // ---- the host generator: pass 1, the class of every strip (most segments per word), candidates dealt to the host's threads
     std::atomic<int> next{0};
     std::atomic<int> bad{0};
     auto pass = [&](bool emit, uint32_t *host_prog) {
@@ -138,15 +130,39 @@ int SlanePlan::build(const SweepTables &t, bool on_host)
         for (auto &th : pool) th.join();
     };
     pass(false, nullptr);
-    if (bad.load()) return fail(OMR_ERR_NOTIMPL, "%s", nofit);
+    if (bad.load()) return fail(OMR_ERR_NOTIMPL, "%s", kNoFit);
     layout();
     std::vector<uint32_t> host((size_t)prog_dwords, 0u);
     pass(true, host.data());
     slane_null_program(nrec, 0, host.data() + null_seg, host.data() + null_fet);
-    if (bad.load()) return fail(OMR_ERR_NOTIMPL, "%s", nofit);
+    if (bad.load()) return fail(OMR_ERR_NOTIMPL, "%s", kNoFit);
     OMR_HIP(prog.alloc(sizeof(uint32_t) * (size_t)prog_dwords));
     OMR_HIP(hipMemcpy(prog.p, host.data(), sizeof(uint32_t) * (size_t)prog_dwords, hipMemcpyHostToDevice));
+    return OMR_OK;
+}
+
+int SlanePlan::build(const SweepTables &t, bool on_host)
+{
+    const SweepDims &d = t.dims;
+    if (d.rows + SL_PRE + 1 >= 4096) return fail(OMR_ERR_NOTIMPL, "scan-lane sweep: more than 4078 rows (12 counter planes)");
+    if (d.cols > 65535) return fail(OMR_ERR_NOTIMPL, "scan-lane sweep: more than 65535 columns (row counts travel as u16)");
+    // the zero guard around the bit images: what the steepest candidate reaches outside the image
+    int gx = 0, gy = 0;
+    {
+        std::vector<int32_t> ad, bd, x0, y0;
+        for (int a = 0; a < d.A; a++) {
+            int cx, cy;
+            slane_host_tables(&t.host_minv[6 * (size_t)a], d.rows, d.cols, ad, bd, x0, y0);
+            slane_guard_need(ad.data(), bd.data(), x0.data(), y0.data(), d.rows, d.cols, &cx, &cy);
+            gx = std::max(gx, cx), gy = std::max(gy, cy);
+        }
     }
+    g.set(d.rows, d.cols, gx, gy);
+    A = d.A;
+    nrec = slane_records(d.rows);
+    const int NS = g.NS;
+    strips.assign((size_t)A * NS, SlaneStrip{0, 0, -1, 0});
+    if (int rc = on_host ? generate_on_host(t) : generate_on_device(t)) return rc;
     // ---- tasks: candidate-major, all strips of a candidate together (they share the candidate's row counts, see
     // slane_kernel); the candidates with the most segments per word (the steepest angles) go first, so that the
     // launch does not end on its longest tasks
