@@ -45,7 +45,8 @@ CARRY = ((37, 38), (39, 40))   # per word: tA, tB
 P = (1, 18)                    # planes p0..p11 of word k
 ST = (13, 30)                  # pending carries c0..c4 of word k
 NST = 5
-NDUMP = 34
+NDUMP = 24                     # registers dumped: the 12 planes of either word (the parked carries are spent: the number of
+                               # rows is a multiple of 64)
 SEG = (16, 32, 48, 64)         # segment sets A..D
 FOFF = (80, 84, 88, 92)        # fetch offsets of sets A..D
 FCOM = (96, 98, 100, 12)       # commit pairs of sets A..D
@@ -278,7 +279,7 @@ def kernel():
         body(o, S, "%s_c%d" % (U, cls), E)
         if cls:
             o.append("s_branch L%s_dump" % U)
-    # ---- dump the 34 counter registers: [word][p0..p11, c0..c4][lane]
+    # ---- dump the 24 plane registers: [word][p0..p11][lane]
     o.append("L%s_dump:" % U)
     o.append("s_set_gpr_idx_off")
     # the last turn has requested two records past the end into sets A, B: they must have landed before s[16:17] takes the
@@ -289,7 +290,7 @@ def kernel():
     for i in range(NDUMP):
         if i and i % 16 == 0:
             o += ["s_add_u32 s16, s16, 4096", "s_addc_u32 s17, s17, 0"]
-        o.append("global_store_dword %%[lane4], v%d, s[16:17] offset:%d" % (1 + i, (i % 16) * 256))
+        o.append("global_store_dword %%[lane4], v%d, s[16:17] offset:%d" % (P[i // 12] + i % 12, (i % 16) * 256))
     o.append("s_waitcnt vmcnt(0)")
     return o
 
