@@ -217,7 +217,7 @@ int omr_slane_strip_program(int32_t rows, int32_t cols, const double *fwd_M, int
  * programs of all (candidate, strip) pairs are generated on the device, once (about 45 ms and 4.7 GB of HBM for
  * 2480x3508 with 400 candidates).  A launch of up to 64 / 128 / 256 scans takes about 5.9 / 10.4 / 19 ms at that size:
  * size launches in multiples of 64.  0 switches back.  OMR_ERR_NOTIMPL, context unchanged, when a candidate does not
- * fit the scheme (beyond about +-10 degrees at unit scale, or more than 4078 rows). */
+ * fit the scheme (beyond about +-10 degrees at unit scale, or more than 8166 rows). */
 int omr_batch_set_lanes(omr_batch_ctx *ctx, int32_t max_scans_per_launch);
 /* Bytes of programs the context's scan-lane plan holds in HBM, its (candidate, strip) tasks, scans per launch
  * (0 = the context is on the run-merging path).  Pointers may be NULL. */

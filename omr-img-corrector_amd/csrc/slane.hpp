@@ -57,8 +57,9 @@ constexpr uint32_t SL_SHORT = 0x80000000u;              // first pk of a word: a
 constexpr int SL_GX = 4;                                // least zero guard, word columns on either side
 constexpr int SL_LANES = 64;
 constexpr int SL_BLOCK = 64;                            // rows between two meetings of a workgroup (row counts leave its LDS)
-constexpr int SL_DUMP = 12;                             // registers a wave dumps per word: planes p0..p11 (the parked carries of the
+constexpr int SL_DUMP = 13;                             // registers a wave dumps per word: planes p0..p12 (the parked carries of the
                                                         // carry-save tree are spent at the end: the records are a multiple of 64)
+constexpr int SL_MAX_RECORDS = 1 << SL_DUMP;            // a column count must fit the planes
 
 struct SlaneGeom {
     int rows = 0, cols = 0;  // image
@@ -137,7 +138,7 @@ struct SlaneTask {
     uint32_t hpitch;     // bytes between pair rows of the row counts
     int32_t cls;         // slot class: slots laid out / executed per word (slane_slots, slane_exec_slots)
     int32_t wave;        // the pair rows of its scan group's LDS accumulators this wave flushes: first (bits 2:0), number 0 / 1 / 2 (bits 5:4)
-    uint64_t planes;     // counter dump of (task, scan group): [word][SL_DUMP = 12 planes][64]
+    uint64_t planes;     // counter dump of (task, scan group): [word][SL_DUMP planes][64]
     uint32_t lds_base;   // LDS address of the scan group's row-count accumulators in the workgroup
     uint32_t pad1;
     uint64_t pad2[6];

@@ -144,7 +144,7 @@ int SlanePlan::generate_on_host(const SweepTables &t)
 int SlanePlan::build(const SweepTables &t, bool on_host)
 {
     const SweepDims &d = t.dims;
-    if (d.rows + SL_PRE + 1 >= 4096) return fail(OMR_ERR_NOTIMPL, "scan-lane sweep: more than 4078 rows (12 counter planes)");
+    if (d.rows + SL_PRE + 1 >= SL_MAX_RECORDS) return fail(OMR_ERR_NOTIMPL, "scan-lane sweep: more than %d rows (%d counter planes)", SL_MAX_RECORDS - SL_PRE - 2, SL_DUMP);
     if (d.cols > 65535) return fail(OMR_ERR_NOTIMPL, "scan-lane sweep: more than 65535 columns (row counts travel as u16)");
     // the zero guard around the bit images: what the steepest candidate reaches outside the image
     int gx = 0, gy = 0;

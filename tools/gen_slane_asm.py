@@ -24,10 +24,11 @@ Register map (fixed; the statement clobbers s0-s13, s16-s101, v1-v127, so lane *
   s[10:11] second shifts of a segment pair / scratch  s[14:15] the task (input)
   segment sets A-D: s[16:31] s[32:47] s[48:63] s[64:79]   fetch offsets A-D: s[80:83] s[84:87] s[88:91] s[92:95]
   commit pairs A-D: s[96:97] s[98:99] s[100:101] s[12:13]
-  v[1:17] / v[18:34] column counters of word 0 / 1: planes p0..p11, pending carries c0..c4
-  v35 LDS address of the turn's row-count slots  v36 odd row's count / fourth aligned window  v37-v40 carries
-  v41 row count  v42 / v43 odd row's words  v[44:59] four landing sets of four entries  v[60:123] ring
-  v124 zero (ring register 64: white runs)  v[125:127] aligned windows (v125 = ring register 65: dummy commits)
+  v[1:18] / v[19:36] column counters of word 0 / 1: planes p0..p12, pending carries c0..c4
+  v37 LDS address of the turn's row-count slots  v38 odd row's count / fourth aligned window  v39 row count
+  v40 / v41 odd row's words  v42 a carry  v43 free  v[44:59] four landing sets of four entries  v[60:123] ring
+  v124 zero (ring register 64: white runs)  v[125:127] aligned windows, and the carries of the carry-save step between
+  words (v125 = ring register 65: dummy commits)
 Usage: python tools/gen_slane_asm.py   (writes the .inc; the build only reads it)"""
 import os
 
@@ -37,15 +38,16 @@ TURN = int(os.environ.get("SLANE_TURN", "16"))  # rows per turn of the loop (4, 
 ABLATE = os.environ.get("SLANE_ABLATE", "").split(",")  # timing probes only (results are wrong except noskip): norec, noatomic, nofetch, noskip
 RING = 60
 T0 = 44
-XR = (125, 126, 127, 36)       # aligned windows of a group of four segments
-DODD = (42, 43)
-CNT, CNT2 = 41, 36
-LADDR = 35
-CARRY = ((37, 38), (39, 40))   # per word: tA, tB
-P = (1, 18)                    # planes p0..p11 of word k
-ST = (13, 30)                  # pending carries c0..c4 of word k
+NPL = 13                       # counter planes per word: column counts up to 8191
+XR = (125, 126, 127, 38)       # aligned windows of a group of four segments (live inside word() only)
+DODD = (40, 41)
+CNT, CNT2 = 39, 38
+LADDR = 37
+CARRY = ((125, 126), (127, 42))  # per word: tA, tB -- live inside carry_save() and flush() only, where no aligned window is
+P = (1, 19)                    # planes p0..p12 of word k
+ST = (14, 32)                  # pending carries c0..c4 of word k
 NST = 5
-NDUMP = 24                     # registers dumped: the 12 planes of either word (the parked carries are spent: the number of
+NDUMP = 2 * NPL                # registers dumped: the planes of either word (the parked carries are spent: the number of
                                # rows is a multiple of 64)
 SEG = (16, 32, 48, 64)         # segment sets A..D
 FOFF = (80, 84, 88, 92)        # fetch offsets of sets A..D
@@ -210,7 +212,7 @@ def carry_save(out, L, second, grp=0):
         cur ^= 1
     for k in range(2):  # the carry out of the last level ripples into the remaining planes (once per 2^NST rows)
         c = cur
-        for lv in range(NST, 12):
+        for lv in range(NST, NPL):
             out.append("v_and_b32 v%d, v%d, v%d" % (CARRY[k][c ^ 1], P[k] + lv, CARRY[k][c]))
             out.append("v_xor_b32 v%d, v%d, v%d" % (P[k] + lv, P[k] + lv, CARRY[k][c]))
             c ^= 1
@@ -279,7 +281,7 @@ def kernel():
         body(o, S, "%s_c%d" % (U, cls), E)
         if cls:
             o.append("s_branch L%s_dump" % U)
-    # ---- dump the 24 plane registers: [word][p0..p11][lane]
+    # ---- dump the plane registers: [word][p0..p12][lane]
     o.append("L%s_dump:" % U)
     o.append("s_set_gpr_idx_off")
     # the last turn has requested two records past the end into sets A, B: they must have landed before s[16:17] takes the
@@ -290,7 +292,7 @@ def kernel():
     for i in range(NDUMP):
         if i and i % 16 == 0:
             o += ["s_add_u32 s16, s16, 4096", "s_addc_u32 s17, s17, 0"]
-        o.append("global_store_dword %%[lane4], v%d, s[16:17] offset:%d" % (P[i // 12] + i % 12, (i % 16) * 256))
+        o.append("global_store_dword %%[lane4], v%d, s[16:17] offset:%d" % (P[i // NPL] + i % NPL, (i % 16) * 256))
     o.append("s_waitcnt vmcnt(0)")
     return o
 

@@ -1,6 +1,6 @@
 """Scan-lane sweep timing (development aid): `n` A4 scans resident in HBM (8 distinct seeded cards), omr_batch_set_lanes,
 HIP-event time of the sweep kernel per launch and the wall-clock rate of the whole batch (pack, sweep, column counts,
-std-dev, arg-max).  Usage: python tools/klanes.py [scans, default 512] [scans per launch, default = scans] [passes]"""
+std-dev, arg-max).  Usage: python tools/klanes.py [scans, default 512] [scans per launch, default = scans] [passes] [rows cols, default A4 at 300 dpi]"""
 import os
 import sys
 import time
@@ -16,7 +16,7 @@ from oics import projection, synth
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 lanes = int(sys.argv[2]) if len(sys.argv) > 2 else n
 passes = int(sys.argv[3]) if len(sys.argv) > 3 else 3
-ROWS, COLS = 3508, 2480
+ROWS, COLS = (int(sys.argv[4]), int(sys.argv[5])) if len(sys.argv) > 5 else (3508, 2480)
 cards = [synth.make_card(ROWS, COLS, 3 + i) for i in range(8)]
 dev = torch.device("cuda:0")
 buf = torch.empty((n, ROWS, COLS), dtype=torch.uint8, device=dev)
