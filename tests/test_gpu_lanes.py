@@ -79,6 +79,35 @@ def test_lanes_match_the_oracle(oracle, rows, cols, max_angle, step, n):
         assert best[i] == oracle.argmax_path1(evs, ehs)[0]
 
 
+def test_lanes_row_pitch_scan_stride_and_threshold(oracle):
+    """Scans that sit in a larger buffer: rows 13 bytes apart from packed (an unaligned pitch: the pack's byte path),
+    scans a guard band apart, grey values with another threshold than 127."""
+    rows, cols, n, pitch, gap = 140, 211, 70, 224, 777
+    rng = np.random.Generator(np.random.PCG64(5))
+    scans = [rng.integers(0, 256, (rows, cols)).astype(np.uint8) for _ in range(n)]
+    stride = rows * pitch + gap
+    dev = torch.device("cuda:0")
+    host = np.full(n * stride, 7, np.uint8)
+    for i, s in enumerate(scans):
+        host[i * stride:i * stride + rows * pitch].reshape(rows, pitch)[:, :cols] = s
+    buf = torch.from_numpy(host).to(dev)
+    N, A = oracle.candidate_count(6, 1.0)
+    best = torch.zeros(n, dtype=torch.int32, device=dev)
+    vs = torch.zeros((n, A), dtype=torch.float64, device=dev)
+    hs = torch.zeros((n, A), dtype=torch.float64, device=dev)
+    b = projection.Batch(rows, cols, 6, 1.0, n_streams=1)
+    b.set_lanes(128)
+    b.run_device(buf.data_ptr(), stride, pitch, n, 90, best.data_ptr(), vs.data_ptr(), hs.data_ptr())
+    b.sync()
+    b.close()
+    best, vs, hs = best.cpu().numpy(), vs.cpu().numpy(), hs.cpu().numpy()
+    for i in (0, 1, 63, 64, 69):
+        binimg = np.where(scans[i] <= 90, 0, 255).astype(np.uint8)
+        _, _, evs, ehs = oracle.sweep(binimg, 6, 1.0)
+        assert (vs[i].view(np.uint64) == evs.view(np.uint64)).all() and (hs[i].view(np.uint64) == ehs.view(np.uint64)).all()
+        assert best[i] == oracle.argmax_path1(evs, ehs)[0]
+
+
 def test_lanes_in_several_launches(oracle):
     # 200 scans through launches of 64: the scratch sets alternate, the last launch is a partial group
     rows, cols = 150, 220
