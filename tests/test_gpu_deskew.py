@@ -119,3 +119,45 @@ def test_call_pool_is_bounded_across_short_lived_threads():
     live2, idle2, pinned2 = stats()
     assert live2 <= live0 + 24 and idle2 == live2 and idle2 <= 32
     assert pinned2 <= 512 << 20
+
+
+@pytest.mark.parametrize("interp", [NEAREST, LINEAR])
+def test_batch_deskew_behind_the_scan_lane_sweep(oracle, interp):
+    """The configuration bench.py times: the context switched to the scan-lane sweep (omr_batch_set_lanes), 70 scans in
+    one launch (a full scan group and a partial one), winners read on the device by the warp.  Every sampled scan
+    against the oracle's rotate_mat; the winners against the angle-only entry point."""
+    import torch
+    rows, cols, max_angle, step, n = 300, 404, 8, 0.5, 70
+    rng = np.random.Generator(np.random.PCG64(17))
+    skews = rng.uniform(-7.5, 7.5, n)
+    cards = np.stack([synth.make_card(rows, cols, 300 + i, skew=float(s))[0] for i, s in enumerate(skews)])
+    dev = torch.device("cuda:0")
+    scans = torch.from_numpy(cards).to(dev)
+    b = projection.Batch(rows, cols, max_angle, step, device=0, n_streams=1)
+    b.set_lanes(128)
+    dr, dc = b.deskew_canvas()
+    out = torch.full((n, dr, dc), 7, dtype=torch.uint8, device=dev)
+    size = torch.zeros((n, 2), dtype=torch.int32, device=dev)
+    best = torch.full((n,), -1, dtype=torch.int32, device=dev)
+    b.deskew_device(scans.data_ptr(), rows * cols, cols, n, 127, interp, 255, out.data_ptr(), dr * dc, dc, size.data_ptr(),
+                    best.data_ptr())
+    b.sync()
+    best2 = torch.full((n,), -1, dtype=torch.int32, device=dev)
+    b.run_device(scans.data_ptr(), rows * cols, cols, n, 127, best2.data_ptr())
+    b.sync()
+    N = b.N
+    b.close()
+    best, out, size = best.cpu().numpy(), out.cpu().numpy(), size.cpu().numpy()
+    assert (best == best2.cpu().numpy()).all()
+    for i in (0, 1, 31, 63, 64, 69):
+        angle = (int(best[i]) - N) * step
+        assert abs(angle - skews[i]) <= step, (i, angle, skews[i])
+        exp = oracle.rotate_mat(cards[i], angle, 1.0, interp, (255, 255, 255, 0), 1)
+        er, ec = exp.shape
+        assert tuple(size[i]) == (er, ec)
+        got = out[i, :er, :ec]
+        if interp == NEAREST:
+            assert (got == exp).all(), i
+        else:
+            assert np.abs(got.astype(np.int16) - exp.astype(np.int16)).max() <= 1, i
+        assert (out[i, er:, :] == 7).all() and (out[i, :, ec:] == 7).all()
