@@ -310,7 +310,7 @@ def e2e_host(cards, B, repeats=3):
     create_s = time.perf_counter() - t0
     _, spl, lane = hb.info()
     out = {"what": "omr_host_batch_run: %d binarised scans from host memory to best angles on the host, 1 GPU; context "
-                   "(plan, pinned ring of 3 x 64 scans, 2 device stages) created outside the timed region; best of %d runs"
+                   "(plan, pinned ring of 3 x 16 scans, 2 device stages of one 64-scan launch) created outside the timed region; best of %d runs"
                    % (B, repeats),
            "scans_per_launch": spl, "scan_lane": lane, "context_creation_s": create_s}
     ref = None
