@@ -103,6 +103,23 @@ __global__ __launch_bounds__(256) void deskew_warp_kernel(const DeskewPass p)
     const bool staged = dwords && bwb > 0 && bh > 0 && (int64_t)bwb * bh <= DW_LDS && bx0 > -30000 && bx1 < 30000 &&
                         by0 > -30000 && by1 < 30000;
     const uint32_t border4 = (uint32_t)p.border * 0x01010101u;
+    // A tile whose box lies wholly outside the scan (the corners of a CONTAIN canvas: up to a fifth of it at 10 degrees) is
+    // the border value: every tap of every sample is outside, NEAREST takes it as it is and the bilinear weights of four
+    // equal taps sum to 2^15.  Workgroup-uniform: the four corners bound every sample of the tile.
+    if (bx1 < 0 || by1 < 0 || bx0 >= p.scols || by0 >= p.srows) {
+        if (x0 >= dcols) return;
+        const bool whole4 = x0 + 4 <= dcols && ((p.dstep | p.out_stride | (int64_t)(uintptr_t)p.dst) & 3) == 0;
+#pragma unroll
+        for (int k = 0; k < DW_TH / 8; k++) {
+            uint8_t *D = dst + (int64_t)min(yq + 8 * k, ty1) * p.dstep + x0;
+            if (whole4) {
+                *(uint32_t *)D = border4;
+            } else {
+                for (int j = 0; j < 4 && x0 + j < dcols; j++) D[j] = (uint8_t)p.border;
+            }
+        }
+        return;
+    }
     if (staged) {
         // the box as dwords, thread t takes dwords t, t + 256, ..: ALL loads are issued before the first LDS write, and
         // every one of them unconditionally (a dword outside the image reads the scan's first dword and is replaced by
