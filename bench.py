@@ -22,8 +22,9 @@ Prints ONE JSON line (rank 0) with the contract's fields plus `roofline` and `cp
 roofline: the sweep kernel never moves SURVEY 8(d)'s algorithmic bytes through HBM (the scan is a
 1-bit/px image staged in LDS, 32 px per lane-operation), so that figure is kept as the labelled side
 value `algorithmic_GBps`, NOT as the fraction.  `bound` names the resource the kernel's own counters
-show closest to its peak (VALU issue or the LDS array), `achieved`/`peak`/`frac` are that resource's
-measured rate against its peak (<= 1), and `traffic` / `hbm_frac` are the HBM bytes per launch from
+show closest to its peak (VALU issue, SCALAR issue, the LDS array or HBM), `achieved`/`peak`/`frac` are that
+resource's measured rate against its peak (<= 1), `wait_frac` is the share of wave cycles spent in s_waitcnt,
+and `traffic` / `hbm_frac` are the HBM bytes per launch from
 rocprofv3 FETCH_SIZE / WRITE_SIZE passes of this very run (child processes started before the parent
 touches the GPU), or -- if rocprofv3 cannot run -- the figure from profiles/ with its source named.
 """
@@ -230,6 +231,12 @@ def dry_run(args):
 
 
 # ------------------------------------------------------------------------------------------------
+def card_order(B, D):
+    """card of scan i: (i + 7 * (i // 64)) % D -- the 64 lanes of every scan group carry different cards than the same
+    lanes of the other groups"""
+    return [(i + 7 * (i // 64)) % D for i in range(B)]
+
+
 def _one_card(seed):
     from oics import synth
     return synth.make_card(ROWS, COLS, seed)
@@ -248,27 +255,32 @@ def make_cards(n, seed0):
     return np.stack([r[0] for r in res]), [r[1] for r in res]
 
 
-def cpu_baseline(gray, gpu_vs, gpu_hs, budget_s):
+def cpu_baseline(checks, budget_s):
     """The oracle ("port" of the reference CPU path, oracle/oracle.c) timed on this box's host
     cores on a bounded sample of the same workload: whole 400-candidate sweeps of one scan,
     angle-parallel over all cores, repeated until about 2/3 of `budget_s` seconds are spent; then
     16-candidate slices on one thread for the rest.  Also the run's parity check: every candidate's
-    scores must equal the GPU's bit for bit."""
+    scores must equal the GPU's bit for bit -- `checks` = [(scan index, gray card, GPU v_sd, GPU h_sd)]: the timed
+    sweeps go round the list, so scans of BOTH quads of scan groups of the launch are compared (index 0 and one >= 256)."""
     from oracle import oracle as orc
     orc.build()
-    b = orc.threshold_binary(gray)
+    bins = [orc.threshold_binary(g) for _, g, _, _ in checks]
+    b = bins[0]
     Ms = orc.rotation_matrices(ROWS, COLS, MAX_ANGLE, STEP)
     A = Ms.shape[0]
     cores = min(os.cpu_count() or 1, 64)
     orc.sweep_matrices(b, Ms[:2], threads=1, want_proj=False, fast=True)  # warm-up
-    sweeps, t_all, ok = 0, 0.0, True
-    while sweeps < 1 or t_all < budget_s * 2.0 / 3.0:
+    sweeps, t_all, ok, compared = 0, 0.0, True, []
+    while sweeps < len(checks) or t_all < budget_s * 2.0 / 3.0:
+        k = sweeps % len(checks)
         t0 = time.perf_counter()
-        _, _, vs, hs = orc.sweep_matrices(b, Ms, threads=cores, want_proj=False, fast=True)
+        _, _, vs, hs = orc.sweep_matrices(bins[k], Ms, threads=cores, want_proj=False, fast=True)
         t_all += time.perf_counter() - t0
         sweeps += 1
-        ok = ok and bool((vs.view(np.uint64) == gpu_vs.view(np.uint64)).all()
-                         and (hs.view(np.uint64) == gpu_hs.view(np.uint64)).all())
+        ok = ok and bool((vs.view(np.uint64) == checks[k][2].view(np.uint64)).all()
+                         and (hs.view(np.uint64) == checks[k][3].view(np.uint64)).all())
+        if checks[k][0] not in compared:
+            compared.append(checks[k][0])
     n1, t_1 = 0, 0.0
     while n1 < 16 or (t_1 < budget_s / 3.0 and n1 + 16 <= A):
         t0 = time.perf_counter()
@@ -287,10 +299,11 @@ def cpu_baseline(gray, gpu_vs, gpu_hs, budget_s):
         "single_thread_sample": "%d candidates, 1 thread, %.1f s (threads=1 is what every reference caller passes)"
                                 % (n1, t_1),
         "parity_vs_gpu": ok,
+        "parity_scans": compared,
     }
 
 
-def e2e_host(cards, B, repeats=3):
+def e2e_host(cards, B, order, repeats=3):
     """SURVEY.md 8(d)'s end-to-end figure (the reference times image-in-memory to result, packages/core/src/main.rs:68-95):
     the same B scans, binarised, starting in HOST memory, through omr_host_batch_run -- H2D of every 8.7 MB scan and D2H
     of the results inside the timed region; plan, pinned ring and device stages created outside it.  Two variants:
@@ -299,7 +312,7 @@ def e2e_host(cards, B, repeats=3):
     from oics import projection
     D = cards.shape[0]
     binc = [np.where(cards[i] > 127, 255, 0).astype(np.uint8) for i in range(D)]
-    pageable = [binc[i % D].copy() for i in range(B)]
+    pageable = [binc[order[i]].copy() for i in range(B)]
     pinned_t = torch.empty((B, ROWS, COLS), dtype=torch.uint8).pin_memory()
     pinned_np = pinned_t.numpy()
     for i in range(B):
@@ -377,7 +390,7 @@ def main():
 
     # ---- everything that must happen before this process touches the GPU
     B = args.scans
-    D = max(1, min(args.distinct, B))  # distinct cards; scan i of the batch is card i % D
+    D = max(1, min(args.distinct, B))  # distinct cards; scan i of the batch is card order[i]
     if args.cards:
         cards = np.load(args.cards)
         D = cards.shape[0]
@@ -414,9 +427,10 @@ def main():
     xdev = torch.device("cpu") if args.share_gpus else dev  # where the (tiny) exchanged tensors live
 
     N, A = projection.candidate_count(MAX_ANGLE, STEP)
-    scans = torch.from_numpy(cards).to(dev)
-    if B != D:  # the batch: B scans, each its own buffer in HBM (repeats of the D cards)
-        scans = scans.repeat((B + D - 1) // D, 1, 1)[:B].contiguous()
+    # the batch: B scans, each its own buffer in HBM (repeats of the D cards).  Every scan group of 64 holds the cards in
+    # another lane order (round-4 verdict, item 1d): identical groups would hide a launch that mixed up groups or lanes
+    order = card_order(B, D)
+    scans = torch.from_numpy(cards).to(dev)[torch.tensor(order, device=dev)].contiguous()
     best = torch.full((B,), -1, dtype=torch.int32, device=dev)
     vs = torch.zeros((B, A), dtype=torch.float64, device=dev)
     hs = torch.zeros((B, A), dtype=torch.float64, device=dev)
@@ -512,7 +526,7 @@ def main():
     out = None
     if rank == 0:
         detected = [(int(k) - N) * STEP for k in best.cpu().tolist()]
-        acc_ok = all(abs(d - thetas[i % D]) < 0.5 for i, d in enumerate(detected))  # lib.rs:103-113
+        acc_ok = all(abs(d - thetas[order[i]]) < 0.5 for i, d in enumerate(detected))  # lib.rs:103-113
         out = base_record(args, world, value, elapsed, B, A, G, D, "scan-lane" if lanes_mode else "run-merging")
         if deskew:
             out["deskew_images_per_s"] = deskew["linear"]
@@ -521,20 +535,24 @@ def main():
                              "linear_images_per_s": deskew["linear"], "nearest_images_per_s": deskew["nearest"],
                              "linear_over_value": deskew["linear"] / value, "nearest_over_value": deskew["nearest"] / value,
                              "warp_hbm_bytes_per_scan": float(ROWS * COLS) + deskew["canvas_bytes_per_scan_mean"]}
-        roof = {"kernel": "omr::slane_kernel (scan-lane rotate+project: 64 scans per wavefront, geometry as wave-uniform "
-                          "programs, both projections per launch)" if lanes_mode
-                          else "omr::runs_kernel (run-merging rotate+project, both projections per launch)"
-                          if n_runs > 0 else "omr::sweep_lds_kernel (gather rotate+project)",
-                "kernel_ms": kernel_ms, "scans_per_launch": G, "launches_per_group": launches,
-                "sweep_stage_ms_per_scan": stage_ms / G, "kernel_ms_per_8_scans": kernel_ms * 8.0 / G,
-                "launch_groups_timed": k_n,
-                "candidates_run_merged": 0 if lanes_mode else n_runs, "candidates_gathered": 0 if lanes_mode else n_gather,
-                "candidates_scan_lane": A if lanes_mode else 0,
-                "algorithmic_bytes_per_launch": algo_bytes, "algorithmic_bytes_per_scan": algo_bytes_scan,
-                "algorithmic_GBps": algo_bytes / kernel_s / 1e9,
-                "algorithmic_note": "SURVEY 8(d) bytes (u8 image streamed once per candidate) / kernel time: a labelled "
-                                    "side figure, not a roofline fraction -- the kernel reads a 1-bit/px image, 32 px per "
-                                    "lane-operation"}
+        kname = "omr::slane_kernel" if lanes_mode else "omr::runs_kernel" if n_runs > 0 else "omr::sweep_lds_kernel"
+        # headline keys FIRST (the driver's parsed copy keeps the first ~20 keys of this object); strings, raw counters
+        # and side figures go under "detail"
+        roof = {"kernel": kname, "kernel_ms": kernel_ms, "bound": None, "frac": None, "achieved": None, "peak": None,
+                "unit": None, "traffic": None, "hbm_frac": None, "valu_frac": None, "scalar_frac": None, "lds_frac": None,
+                "wait_frac": None, "scans_per_launch": G, "kernel_ms_per_8_scans": kernel_ms * 8.0 / G,
+                "algorithmic_GBps": algo_bytes / kernel_s / 1e9, "compulsory_bytes_per_launch": None}
+        det = {"kernel_what": "scan-lane rotate+project: 64 scans per wavefront, geometry as wave-uniform programs, both "
+                              "projections per launch" if lanes_mode
+                              else "run-merging rotate+project, both projections per launch" if n_runs > 0 else "gather rotate+project",
+               "launches_per_group": launches, "sweep_stage_ms_per_scan": stage_ms / G, "launch_groups_timed": k_n,
+               "candidates_run_merged": 0 if lanes_mode else n_runs, "candidates_gathered": 0 if lanes_mode else n_gather,
+               "candidates_scan_lane": A if lanes_mode else 0,
+               "algorithmic_bytes_per_launch": algo_bytes, "algorithmic_bytes_per_scan": algo_bytes_scan,
+               "algorithmic_note": "SURVEY 8(d) bytes (u8 image streamed once per candidate) / kernel time: a labelled "
+                                   "side figure, not a roofline fraction -- the kernel reads a 1-bit/px image, 32 px per "
+                                   "lane-operation"}
+        roof["detail"] = det
         traffic, source = None, None
         sq = None
         if pmc_res and "passes" in pmc_res:
@@ -547,14 +565,14 @@ def main():
                     traffic = pmc.hbm_bytes(f_kb, w_kb)
                     source = ("measured in this run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE child passes "
                               "(3 steps each), mean per launch, (2 x FETCH_SIZE + WRITE_SIZE) x 1024 B")
-                    roof["hbm_counters_KB"] = {"FETCH_SIZE": f_kb, "WRITE_SIZE": w_kb}
+                    det["hbm_counters_KB"] = {"FETCH_SIZE": f_kb, "WRITE_SIZE": w_kb}
             if "per_launch" in ps.get("sq", {}):
                 sq = ps["sq"]
             errs = {k: v["error"] for k, v in ps.items() if "error" in v}
             if errs:
-                roof["pmc_errors"] = errs
+                det["pmc_errors"] = errs
         elif pmc_res:
-            roof["pmc_errors"] = pmc_res
+            det["pmc_errors"] = pmc_res
         if traffic is None:
             tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
             if os.path.exists(tpath):
@@ -565,18 +583,24 @@ def main():
                 except Exception:  # noqa: BLE001
                     traffic = None
         roof["traffic"] = traffic
-        roof["traffic_source"] = source
+        det["traffic_source"] = source
         if traffic is not None:
-            roof["hbm_measured_GBps"] = traffic / kernel_s / 1e9
+            det["hbm_measured_GBps"] = traffic / kernel_s / 1e9
             roof["hbm_frac"] = traffic / kernel_s / 1e9 / HBM_PEAK_GBPS
             if lanes_mode:
-                # what one launch has to move at least: every strip's program once, the interleaved bit images once, the
-                # row counts (u16 pairs, read-modify-write) and the counter dumps once
+                # what one launch has to move at least: every strip's program once PER QUAD OF SCAN GROUPS (a workgroup
+                # sweeps four scan groups with one copy of the program; a launch of 512 scans reads the plan twice), the
+                # interleaved bit images once, the row counts (u16 pairs, read-modify-write) and the counter dumps once
                 nw = (COLS + 31) // 32
-                roof["compulsory_bytes_per_launch"] = float(batch.lanes_program_bytes()) + float(G) * (
+                used = (G + 63) // 64
+                plan_reads = 1 if used <= 2 else (used + 3) // 4
+                det["plan_bytes"] = float(batch.lanes_program_bytes())
+                det["plan_reads_per_launch"] = plan_reads
+                roof["compulsory_bytes_per_launch"] = float(batch.lanes_program_bytes()) * plan_reads + float(G) * (
                     ROWS * nw * 4 + A * ROWS * 2 * 2 + A * nw * 17 * 4)
             else:
                 roof["compulsory_bytes_per_launch"] = float(G) * (ROWS * ((COLS + 127) // 128 * 16) + A * (ROWS + COLS) * 4)
+            det["traffic_over_compulsory"] = traffic / roof["compulsory_bytes_per_launch"]
         if sq is not None:
             c = sq["per_launch"]
             t_prof = sq["kernel_us_profiled"] * 1e-6  # the counters belong to the profiled launch: use ITS duration
@@ -584,29 +608,40 @@ def main():
             valu_peak = N_SIMD * CLOCK_GHZ * 1e9 / VALU_ISSUE_CYCLES  # hardware constant: 2 cycles per wave64 op
             lds_rate = c["SQ_LDS_IDX_ACTIVE"] / t_prof          # LDS-array cycles / s, summed over CUs
             lds_peak = N_CU * CLOCK_GHZ * 1e9
+            # the scalar unit: one per CU, one SALU / SMEM instruction per cycle (SQ_ACTIVE_INST_SCA / SQ_BUSY_CU_CYCLES gives
+            # the same fraction within 2 %, profiles/r04_pmc_sweep.md)
+            sca_rate = (c["SQ_INSTS_SALU"] + c.get("SQ_INSTS_SMEM", 0.0)) / t_prof
+            sca_peak = N_CU * CLOCK_GHZ * 1e9
             mix = VALU_LANE_MIX_CYCLES if lanes_mode else VALU_MIX_CYCLES
-            roof.update(valu_issue_frac_at_2_cycles=valu_rate / valu_peak,
-                        valu_issue_frac_at_mix=valu_rate / (N_SIMD * CLOCK_GHZ * 1e9 / mix),
-                        valu_mix_cycles=mix,
-                        lds_busy_frac=lds_rate / lds_peak,
-                        lds_conflict_frac=c["SQ_LDS_BANK_CONFLICT"] / max(1.0, c["SQ_LDS_IDX_ACTIVE"]),
-                        sq_counters_per_launch=c, kernel_us_under_profiler=sq["kernel_us_profiled"],
-                        valu_insts_per_dst_word=c["SQ_INSTS_VALU"] * 64.0 / (G * A * ROWS * ((COLS + 31) // 32)),
-                        peaks="frac / peak / bound are priced against hardware constants only (round-3 advice): VALU = %d SIMDs "
-                              "x %.1f GHz / 2 cycles per wave64 op; LDS = %d CUs x %.1f GHz array cycles; HBM = %.0f GB/s "
-                              "(MI355X_MICROARCH.md).  valu_issue_frac_at_mix prices the same instruction count at the issue "
-                              "cost of THIS kernel's opcodes (%.2f cycles: v_alignbit / v_and_or / v_bitop3 / v_bcnt are "
-                              "4-cycle VOP3 forms, profiles/r02_valu_issue.md) -- a side figure"
-                              % (N_SIMD, CLOCK_GHZ, N_CU, CLOCK_GHZ, HBM_PEAK_GBPS, mix))
-            cands = [("valu", roof["valu_issue_frac_at_2_cycles"], valu_rate / 1e9, valu_peak / 1e9, "G wave-instr/s"),
-                     ("lds", roof["lds_busy_frac"], lds_rate / 1e9, lds_peak / 1e9, "G LDS-array cycles/s")]
+            roof.update(valu_frac=valu_rate / valu_peak, scalar_frac=sca_rate / sca_peak, lds_frac=lds_rate / lds_peak,
+                        wait_frac=c["SQ_WAIT_ANY"] / max(1.0, c["SQ_WAVE_CYCLES"]) if "SQ_WAIT_ANY" in c else None)
+            det.update(valu_issue_frac_at_2_cycles=valu_rate / valu_peak,
+                       valu_issue_frac_at_mix=valu_rate / (N_SIMD * CLOCK_GHZ * 1e9 / mix),
+                       valu_mix_cycles=mix,
+                       scalar_frac_of_busy_cu_cycles=(c["SQ_INSTS_SALU"] + c.get("SQ_INSTS_SMEM", 0.0)) / max(1.0, c.get("SQ_BUSY_CU_CYCLES", 0.0)),
+                       lds_conflict_frac=c["SQ_LDS_BANK_CONFLICT"] / max(1.0, c["SQ_LDS_IDX_ACTIVE"]),
+                       sq_counters_per_launch=c, kernel_us_under_profiler=sq["kernel_us_profiled"],
+                       valu_insts_per_dst_word=c["SQ_INSTS_VALU"] * 64.0 / (G * A * ROWS * ((COLS + 31) // 32)),
+                       scalar_insts_per_dst_word=(c["SQ_INSTS_SALU"] + c.get("SQ_INSTS_SMEM", 0.0)) * 64.0 / (G * A * ROWS * ((COLS + 31) // 32)),
+                       peaks="frac / peak / bound are priced against hardware constants only (round-3 advice): VALU = %d SIMDs "
+                             "x %.1f GHz / 2 cycles per wave64 op; SCALAR = %d CUs x %.1f GHz, one SALU / SMEM instruction per "
+                             "cycle and CU; LDS = %d CUs x %.1f GHz array cycles; HBM = %.0f GB/s (MI355X_MICROARCH.md).  "
+                             "`bound` names the LARGEST of these busy fractions; wait_frac = SQ_WAIT_ANY / SQ_WAVE_CYCLES says "
+                             "how much of the waves' time is spent in s_waitcnt: when no fraction is near 1 the kernel is "
+                             "issue- and latency-bound, not saturated.  valu_issue_frac_at_mix prices the same instruction "
+                             "count at the issue cost of THIS kernel's opcodes (%.2f cycles: v_alignbit / v_bitop3 / v_bcnt "
+                             "are 4-cycle VOP3 forms, profiles/r02_valu_issue.md) -- a side figure"
+                             % (N_SIMD, CLOCK_GHZ, N_CU, CLOCK_GHZ, N_CU, CLOCK_GHZ, HBM_PEAK_GBPS, mix))
+            cands = [("valu", roof["valu_frac"], valu_rate / 1e9, valu_peak / 1e9, "G wave-instr/s"),
+                     ("scalar", roof["scalar_frac"], sca_rate / 1e9, sca_peak / 1e9, "G scalar-instr/s"),
+                     ("lds", roof["lds_frac"], lds_rate / 1e9, lds_peak / 1e9, "G LDS-array cycles/s")]
             if traffic is not None:
-                cands.append(("hbm", roof["hbm_frac"], roof["hbm_measured_GBps"], HBM_PEAK_GBPS, "GB/s"))
-            b = max(cands, key=lambda t: t[1])
-            roof.update(bound=b[0], frac=b[1], achieved=b[2], peak=b[3], unit=b[4])
+                cands.append(("hbm", roof["hbm_frac"], det["hbm_measured_GBps"], HBM_PEAK_GBPS, "GB/s"))
+            bnd = max(cands, key=lambda t: t[1])
+            roof.update(bound=bnd[0], frac=bnd[1], achieved=bnd[2], peak=bnd[3], unit=bnd[4])
         elif traffic is not None:
             # no SQ counters: fall back to the measured HBM fraction (<= 1 by construction)
-            roof.update(bound="hbm", achieved=roof["hbm_measured_GBps"], peak=HBM_PEAK_GBPS, unit="GB/s",
+            roof.update(bound="hbm", achieved=det["hbm_measured_GBps"], peak=HBM_PEAK_GBPS, unit="GB/s",
                         frac=roof["hbm_frac"])
         else:
             roof.update(bound="hbm", achieved=None, peak=HBM_PEAK_GBPS, unit="GB/s", frac=None)
@@ -616,13 +651,16 @@ def main():
         out["accuracy_ok"] = acc_ok
         out["gathered_results"] = int(all_best.numel())
         if not args.no_cpu_baseline and world == 1:  # reported at N = 1 only
-            out["cpu_baseline"] = cpu_baseline(cards[0], vs[0].cpu().numpy(), hs[0].cpu().numpy(), args.cpu_seconds)
+            # scan 0 (first quad of scan groups of the launch) and one scan of the last scan group
+            picks = sorted({0, B - 1 - (B - 1) % 64 + min(44, (B - 1) % 64)})
+            out["cpu_baseline"] = cpu_baseline([(i, cards[order[i]], vs[i].cpu().numpy(), hs[i].cpu().numpy()) for i in picks],
+                                               args.cpu_seconds)
     batch.close()
     if rank == 0 and world == 1 and not args.no_e2e:
         del scans, vs, hs
         torch.cuda.empty_cache()
         try:
-            e2e, e2e_best = e2e_host(cards, B)
+            e2e, e2e_best = e2e_host(cards, B, order)
             # the detected angles must be the HBM-resident run's (same cards, thresholded on the host instead of in the pack)
             e2e["agrees_with_resident_run"] = bool((e2e_best == np.array(all_best.cpu().tolist()[:B], np.int32)).all())
             out["e2e_host"] = e2e
@@ -646,6 +684,18 @@ def main():
         shutil.rmtree(tmpdir, ignore_errors=True)
     if rank == 0:
         print(json.dumps(out))
+        # the bench fails on its own checks (round-4 verdict, weak 10): no `value` with exit code 0 from a kernel that
+        # misses the reference's criterion (lib.rs:103-113) or differs from the oracle
+        problems = []
+        if not out.get("accuracy_ok", True):
+            problems.append("accuracy_ok is false (a detected angle is >= 0.5 deg from the injected one)")
+        if "cpu_baseline" in out and not out["cpu_baseline"].get("parity_vs_gpu", True):
+            problems.append("cpu_baseline.parity_vs_gpu is false (GPU scores differ from the oracle's)")
+        e2 = out.get("e2e_host", {})
+        if e2 and "error" not in e2 and not (e2.get("agrees_with_resident_run", True) and e2.get("pinned_agrees", True)):
+            problems.append("e2e_host results differ from the HBM-resident run")
+        if problems:
+            raise SystemExit("bench.py: " + "; ".join(problems))
 
 
 if __name__ == "__main__":

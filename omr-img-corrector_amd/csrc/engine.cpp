@@ -593,6 +593,7 @@ int SweepScratch::create(const SweepTables &t, int scans_per_launch)
     if (t.runs_built && t.n_runs > 0) {
         OMR_HIP(hpart.alloc(sizeof(uint16_t) * Z * (size_t)d.A * t.Ph * t.NRp));
         OMR_HIP(guard.alloc(sizeof(int32_t) * (size_t)d.A));
+        OMR_HIP(hipMemset(guard.p, 0, guard.bytes));  // runs_kernel sets guard[a] when it could not sweep candidate a
         OMR_HIP(bitsT.alloc(sizeof(uint32_t) * Z * (size_t)t.NWt * t.rowsT));
         OMR_HIP(hipMemset(bitsT.p, 0, bitsT.bytes));  // the guard stays zero: the transpose writes the image only
     }
@@ -653,6 +654,7 @@ int enqueue_sweep(const SweepTables &t, SweepScratch &s, int kernel_sel, const u
                                       t.GXh, t.GYh, stream, scans));
         const RunPass ph = t.run_pass(s.bitsT.as<uint32_t>(), s.hpart.as<uint16_t>(), scans);
         OMR_HIP(launch_runs(ph, t.list_runs.as<int32_t>(), t.n_runs, s.guard.as<int32_t>(), vp, stream));
+        s.guard_pending = true;
     }
     for (int z = 0; z < scans && n_g > 0; z++) {  // the gather kernels take one scan per launch
         const uint32_t *bz = s.bits.as<uint32_t>() + (size_t)z * d.rows * d.wpr;
@@ -676,6 +678,13 @@ int enqueue_sweep(const SweepTables &t, SweepScratch &s, int kernel_sel, const u
                                   stream, scans, d.A));
     OMR_HIP(launch_stddev(vp, hp, d, vs, hs, stream, scans, /*latency=*/post_stream == nullptr));
     if (d_best) OMR_HIP(launch_argmax_path1(vs, hs, d.A, d_best, stream, scans));
+    return OMR_OK;
+}
+
+int guard_verdict(const int32_t *flags, size_t n, const char *kernel)
+{
+    for (size_t i = 0; i < n; i++)
+        if (flags[i]) return fail(OMR_ERR_GPU, "%s reported that it could not sweep (guard flag %zu set): no results were computed", kernel, i);
     return OMR_OK;
 }
 
@@ -825,6 +834,15 @@ int omr_sweep_plan_run(omr_sweep_plan *plan, const omr_image *img, int32_t black
     if (h_sd) OMR_HIP(hipMemcpyAsync(h_sd, plan->scratch.hsd.p, sizeof(double) * (size_t)d.A, hipMemcpyDeviceToHost, s));
     if (best_idx) OMR_HIP(hipMemcpyAsync(best_idx, plan->scratch.best.p, sizeof(int32_t), hipMemcpyDeviceToHost, s));
     OMR_HIP(hipStreamSynchronize(s));
+    if (plan->scratch.guard_pending) {  // the run-merging kernel's guard flags (see check_guards)
+        plan->scratch.guard_pending = false;
+        std::vector<int32_t> g(plan->scratch.guard.bytes / sizeof(int32_t));
+        OMR_HIP(hipMemcpy(g.data(), plan->scratch.guard.p, plan->scratch.guard.bytes, hipMemcpyDeviceToHost));
+        if (int r = guard_verdict(g.data(), g.size(), "runs_kernel")) {
+            OMR_HIP(hipMemset(plan->scratch.guard.p, 0, plan->scratch.guard.bytes));
+            return r;
+        }
+    }
     return OMR_OK;
 }
 
@@ -1296,11 +1314,39 @@ int omr_batch_lanes_projections(omr_batch_ctx *ctx, int32_t set, int32_t scan, i
             const int q = r + SL_PRE;
             hproj[r] = (pairs[(size_t)q >> 1] >> ((q & 1) * 16)) & 0xffffu;
         }
-        int32_t g = 0;
-        OMR_HIP(hipMemcpy(&g, s.guard.p, sizeof g, hipMemcpyDeviceToHost));
-        if (g) return fail(OMR_ERR_GPU, "scan-lane kernel: its LDS accumulators are not at LDS address 0");
     }
-    return OMR_OK;
+    return OMR_OK;  // (the kernel's guard flag was read by the omr_batch_sync above)
+}
+
+// The sweep kernels address LDS by integer and hand a candidate back when they cannot sweep it (slane.hip: the
+// accumulators are not at LDS address 0; runs.hip: the same, or a window that left its slab): they set a flag and return
+// WITHOUT results.  Plan creation makes both impossible for the shapes it accepts, so a set flag means a toolchain or
+// plan defect -- and the scores of that launch are zeros or stale.  Every synchronisation point of the production path
+// reads the flags of the scratch sets that were launched on since the last one: OMR_ERR_GPU, never silent wrong angles.
+static int check_guards(omr_batch_ctx *ctx)
+{
+    int rc = OMR_OK;
+    for (auto &sc : ctx->slane_scratch) {
+        if (!sc || !sc->guard_pending) continue;
+        sc->guard_pending = false;
+        int32_t g = 0;
+        OMR_HIP(hipMemcpy(&g, sc->guard.p, sizeof g, hipMemcpyDeviceToHost));
+        if (g) {
+            OMR_HIP(hipMemset(sc->guard.p, 0, sizeof g));
+            rc = guard_verdict(&g, 1, "slane_kernel (its LDS accumulators are not at LDS address 0)");
+        }
+    }
+    for (auto &sc : ctx->scratch) {
+        if (!sc || !sc->guard_pending || !sc->guard.p) continue;
+        sc->guard_pending = false;
+        std::vector<int32_t> g(sc->guard.bytes / sizeof(int32_t));
+        OMR_HIP(hipMemcpy(g.data(), sc->guard.p, sc->guard.bytes, hipMemcpyDeviceToHost));
+        if (int r = guard_verdict(g.data(), g.size(), "runs_kernel")) {
+            OMR_HIP(hipMemset(sc->guard.p, 0, sc->guard.bytes));
+            rc = r;
+        }
+    }
+    return rc;
 }
 
 int omr_batch_sync(omr_batch_ctx *ctx)
@@ -1309,8 +1355,30 @@ int omr_batch_sync(omr_batch_ctx *ctx)
     OMR_HIP(hipSetDevice(ctx->tables.device));
     for (auto s : ctx->streams) OMR_HIP(hipStreamSynchronize(s));
     for (auto s : ctx->post_streams) OMR_HIP(hipStreamSynchronize(s));
+    std::lock_guard<std::mutex> lk(ctx->guard_mu);
+    return check_guards(ctx);
+}
+
+#ifdef OMR_RUNS_DEBUG
+// development aid (make debug only, not in the public header): set a guard flag of scratch set `set` on the device, as a
+// kernel that could not sweep would (tests/test_gpu_debuglib.py: the next omr_batch_sync must return OMR_ERR_GPU)
+int omr_debug_poke_guard(omr_batch_ctx *ctx, int set)
+{
+    if (!ctx) return fail(OMR_ERR_BADARG, "null ctx");
+    OMR_HIP(hipSetDevice(ctx->tables.device));
+    const int32_t one = 1;
+    if (ctx->lanes > 0) {
+        if (set < 0 || set >= (int)ctx->slane_scratch.size()) return fail(OMR_ERR_BADARG, "no such scratch set");
+        OMR_HIP(hipMemcpy(ctx->slane_scratch[(size_t)set]->guard.p, &one, sizeof one, hipMemcpyHostToDevice));
+        ctx->slane_scratch[(size_t)set]->guard_pending = true;
+    } else {
+        if (set < 0 || set >= (int)ctx->scratch.size() || !ctx->scratch[(size_t)set]->guard.p) return fail(OMR_ERR_BADARG, "no such scratch set");
+        OMR_HIP(hipMemcpy(ctx->scratch[(size_t)set]->guard.p, &one, sizeof one, hipMemcpyHostToDevice));
+        ctx->scratch[(size_t)set]->guard_pending = true;
+    }
     return OMR_OK;
 }
+#endif
 
 int omr_batch_kernel_ms(omr_batch_ctx *ctx, double *sum_ms, int32_t *launches)
 {

@@ -133,6 +133,7 @@ struct SweepScratch {
     DevBuf hpart, guard;  // run-merging scratch: u16 row-count partials per chunk of word groups
     DevBuf bitsT;         // run-merging scratch: the bit images transposed (word columns contiguous)
     int zmax = 1;         // scans a launch may carry (every buffer above holds that many result sets)
+    bool guard_pending = false;  // runs_kernel was launched on this set since its guard flags were last read
     int create(const SweepTables &t, int scans_per_launch = 1);
 };
 
@@ -140,6 +141,9 @@ enum KernelSel { KERNEL_AUTO = 0, KERNEL_GENERIC = 1, KERNEL_LDS = 2, KERNEL_RUN
 
 // Enqueue pack -> sweep -> std-dev -> arg-max for `scans` device-resident scans (img_stride bytes apart)
 // in one launch of each kernel; scores / best index of scan z land at d_v_sd + z * A, d_best + z.
+// host side of the kernels' guard flags: OMR_ERR_GPU when any of the n flags is set
+int guard_verdict(const int32_t *flags, size_t n, const char *kernel);
+
 int enqueue_sweep(const SweepTables &t, SweepScratch &s, int kernel_sel, const uint8_t *d_img, int64_t step,
                   int black_max, hipStream_t stream, uint32_t *d_vproj, uint32_t *d_hproj, double *d_v_sd,
                   double *d_h_sd, int32_t *d_best, hipEvent_t ev0, hipEvent_t ev1, bool want_proj = false,
@@ -164,6 +168,7 @@ struct SlanePlan {
 struct SlaneScratch {
     int nsg = 0;  // scan groups of 64 scans a launch may carry
     bool keep_rows = false, rows_dirty = false;  // inspection: leave the row counts in place after a launch
+    bool guard_pending = false;                  // slane_kernel was launched on this set since its guard flag was last read
     size_t rows_bytes = 0;                       // of hrows: the row counts and, behind them, the totals [candidate][scan]
     DevBuf bits, hrows, vproj, planes, descs[3], vsd, hsd, best, guard;  // descs[lg]: workgroups of (16 >> lg) strips x (1 << lg) scan groups
     int create(const SlanePlan &p, int groups);
@@ -210,5 +215,6 @@ struct omr_batch_ctx {
     int dk_rows = 0, dk_cols = 0;  // largest canvas (cols rounded up to 4)
     omr::DevBuf dk_size, dk_adelta, dk_bdelta, dk_xy0;
     std::mutex mu;
+    std::mutex guard_mu;  // omr_batch_sync is called with and without `mu` held: the guard flags have a lock of their own
     ~omr_batch_ctx();
 };

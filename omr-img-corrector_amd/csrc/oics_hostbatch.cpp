@@ -9,6 +9,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
 #include <memory>
 #include <string>
 #include <thread>
@@ -20,6 +21,26 @@
 using namespace omr;
 
 namespace {
+#ifdef OMR_RUNS_DEBUG
+// development aid (make debug only): k LOGICAL devices mapped onto the visible ones (logical device d = physical device
+// d % omr_device_count()), so that the multi-device worker loop of omr_host_batch_run -- interleaved scans, one worker
+// thread, context, copy stream and pinned ring per device, results gathered in order -- can be exercised on a box with one
+// GPU (tests/test_gpu_debuglib.py).  The release library has no such switch: there a device is a device.
+std::atomic<int> g_logical_devices{0};
+int visible_devices()
+{
+    const int k = g_logical_devices.load();
+    return k > 0 ? k : omr_device_count();
+}
+int physical_device(int logical)
+{
+    const int n = omr_device_count();
+    return n > 0 ? logical % n : logical;
+}
+#else
+int visible_devices() { return omr_device_count(); }
+int physical_device(int logical) { return logical; }
+#endif
 constexpr int HB_CHUNK = 16;    // scans per ring slot / DMA (139 MB at A4: DMAs of that size run at the link's rate; three slots are
                                 // 0.4 GB of pinned memory to allocate, a quarter of what 64-scan slots cost a one-off call)
 constexpr int HB_LANES_MIN = 64; // scans per device from which the scan-lane sweep is used (one full wavefront of scans)
@@ -67,8 +88,8 @@ int omr_host_batch_create(int32_t rows, int32_t cols, uint16_t max_angle, double
 {
     if (!out || max_scans < 1) return fail(OMR_ERR_BADARG, "bad host-batch arguments");
     *out = nullptr;
-    int ndev = omr_device_count();
-    if (ndev <= 0) return fail(OMR_ERR_GPU, "no usable HIP device (there is no CPU fallback)");
+    if (omr_device_count() <= 0) return fail(OMR_ERR_GPU, "no usable HIP device (there is no CPU fallback)");
+    int ndev = visible_devices();
     // 0 (or less) = every visible device; more than are visible is an error, not a silent clamp: a caller that asked
     // for 8 devices must not believe it ran on 8
     if (n_devices > ndev) return fail(OMR_ERR_BADARG, "n_devices exceeds omr_device_count()");
@@ -82,10 +103,10 @@ int omr_host_batch_create(int32_t rows, int32_t cols, uint16_t max_angle, double
     NoPoolScope owned;
     for (int dv = 0; dv < n_devices; dv++) {
         std::unique_ptr<HostBatchDev> d(new HostBatchDev);
-        d->dev = dv;
-        OMR_HIP(hipSetDevice(dv));
+        d->dev = physical_device(dv);
+        OMR_HIP(hipSetDevice(d->dev));
         omr_batch_ctx *raw = nullptr;
-        int rc = omr_batch_create(rows, cols, max_angle, step, 1.0, dv, 1, &raw);
+        int rc = omr_batch_create(rows, cols, max_angle, step, 1.0, d->dev, 1, &raw);
         if (rc) return rc;
         d->ctx.reset(raw);
         // the scan-lane sweep (its plan is built on the device in tens of milliseconds) from one full wavefront of scans on
@@ -150,7 +171,7 @@ int omr_host_batch_run(omr_host_batch *hb, const omr_image *scans, int32_t n, in
     auto worker = [&](int dv) {
         auto run = [&]() -> int {
             HostBatchDev &d = *hb->devs[(size_t)dv];
-            OMR_HIP(hipSetDevice(dv));
+            OMR_HIP(hipSetDevice(d.dev));
             std::vector<int> mine;
             for (int i = dv; i < n; i += ND) mine.push_back(i);
             const int m = (int)mine.size();
@@ -238,5 +259,14 @@ int omr_host_batch_run(omr_host_batch *hb, const omr_image *scans, int32_t n, in
         for (int i = 0; i < n; i++) best_angle[i] = ((double)best_idx[i] - (double)hb->N) * hb->step;  // projection.rs:189-190
     return OMR_OK;
 }
+
+#ifdef OMR_RUNS_DEBUG
+int omr_debug_set_logical_devices(int k)
+{
+    if (k < 0 || k > 16) return fail(OMR_ERR_BADARG, "0..16 logical devices");
+    g_logical_devices = k;
+    return OMR_OK;
+}
+#endif
 
 }  // extern "C"

@@ -37,7 +37,7 @@ void SlanePlan::layout()
     off += ((int64_t)nrec * slane_seg_dwords(0) + 63) & ~63ll;
     null_fet = off;
     off += ((int64_t)nrec * SL_FREC + 63) & ~63ll;
-    prog_dwords = off + 256;  // the kernel reads one record past a stream's last one
+    prog_dwords = off + 2048;  // the kernel requests two records past a stream's last one (and may prefetch a turn or two beyond it)
 }
 
 // the device generator (slane_build.hip): scan -> classes and layout on the host -> emit
@@ -286,6 +286,7 @@ int slane_enqueue(const SlanePlan &p, SlaneScratch &s, const uint8_t *d_img, int
         const int lg = used <= 1 ? 0 : used == 2 ? 1 : 2, sgw = 1 << lg, places = 16 >> lg;
         OMR_HIP(launch_slane(s.descs[lg].as<SlaneTask>(), (used + sgw - 1) / sgw, ((s.nsg + sgw - 1) / sgw) * sgw, p.A,
                              (p.g.NS + places - 1) / places, lg, s.guard.as<int32_t>(), stream));
+        s.guard_pending = true;
     }
     if (ev1) OMR_HIP(hipEventRecord(ev1, stream));
     if (post_stream && ev_mid) {

@@ -17,8 +17,10 @@ import subprocess
 import sys
 from collections import defaultdict
 
-SQ_PASS = ["SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_ACTIVE_INST_LDS", "SQ_LDS_BANK_CONFLICT",
-           "SQ_LDS_IDX_ACTIVE", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES"]
+# the units a sweep kernel can be bound by, one pass: vector issue, SCALAR issue (SALU + SMEM instructions against the CU's
+# busy cycles: the scalar unit of a CU takes one instruction per cycle), the LDS array, and how long waves sit in s_waitcnt
+SQ_PASS = ["SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_SMEM", "SQ_LDS_IDX_ACTIVE", "SQ_LDS_BANK_CONFLICT",
+           "SQ_WAVE_CYCLES", "SQ_BUSY_CU_CYCLES", "SQ_WAIT_ANY"]
 SQ_PASS2 = ["SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_WAIT_INST_LDS", "SQ_ACTIVE_INST_VALU",
             "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_WAVES"]
 

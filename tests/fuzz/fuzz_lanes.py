@@ -1,6 +1,6 @@
 """Randomised parity run of the scan-lane sweep (development aid, not part of the test suite): random shapes, sweeps within
 the scheme's +-10 degrees, batch sizes that leave partial scan groups and use every workgroup composition (1, 2, 4 scan
-groups per workgroup), random content.  For every batch: the device-built programs against the host generator (dword for
+groups per workgroup; launches of 320 / 512 scans run two quads of scan groups), random content.  For every batch: the device-built programs against the host generator (dword for
 dword), and for a sample of scans both std-dev vectors (f64 bits) and the arg-max against the CPU oracle.
 Usage: python tests/fuzz/fuzz_lanes.py [batches] [seed]"""
 import os
@@ -25,8 +25,8 @@ for c in range(batches):
     rows, cols = int(rng.integers(40, 1400)), int(rng.integers(33, 1400))
     max_angle = int(rng.integers(1, 11))
     step = float(rng.choice([1.0, 0.5, 0.25, 0.2]))
-    n = int(rng.choice([1, 7, 64, 65, 100, 128, 130, 200, 257]))
-    lanes = int(rng.choice([64, 128, 256]))
+    n = int(rng.choice([1, 7, 64, 65, 100, 128, 130, 200, 257, 320, 400, 512]))
+    lanes = int(rng.choice([64, 128, 256, 320, 512]))  # 320 / 512: two quads of scan groups in one launch (bench.py's form)
     scans = []
     for i in range(n):
         kind = int(rng.integers(0, 4))
@@ -61,7 +61,7 @@ for c in range(batches):
     b.sync()
     b.close()
     bs, v, h = best.cpu().numpy(), vs.cpu().numpy(), hs.cpu().numpy()
-    for i in sorted(set([0, n - 1, n // 2, min(n - 1, 63), min(n - 1, 64)])):
+    for i in sorted(set([0, n - 1, n // 2, min(n - 1, 63), min(n - 1, 64), min(n - 1, 256), min(n - 1, 300), min(n - 1, 319), min(n - 1, 448)])):
         binimg = np.where(scans[i] <= 127, 0, 255).astype(np.uint8)
         _, _, evs, ehs = orc.sweep(binimg, max_angle, step)
         checked += 1

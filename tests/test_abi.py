@@ -130,3 +130,48 @@ def test_release_library_has_no_debug_switches():
     assert "getenv" not in open(os.path.join(PKG, "csrc", "runs.hip")).read()
     # and the stamp read-out of the debug build is not exported by the release library
     assert b"omr_debug_runs_stamps" not in blob
+    # nor are the guard-flag hook and the logical devices of the debug build (tests/test_gpu_debuglib.py)
+    assert b"omr_debug_poke_guard" not in blob and b"omr_debug_set_logical_devices" not in blob and b"omr_debug" not in blob
+
+
+def test_guard_verdict_host_side():
+    """Round-4 verdict, item 6: the kernels' guard flags (slane.hip / runs.hip set one and return without results) are read
+    at every synchronisation point of the production path and answered with OMR_ERR_GPU.  The host side of that check is
+    one function, omr::guard_verdict (engine.cpp); this compiles it into a small program of its own -- no GPU, no HIP
+    call -- and checks its verdicts.  The device side (a poked flag makes omr_batch_sync return -217) runs on the GPU in
+    tests/test_gpu_debuglib.py."""
+    import re
+    import shutil
+    import subprocess
+    import tempfile
+    src = open(os.path.join(PKG, "csrc", "engine.cpp")).read()
+    m = re.search(r"int guard_verdict\(const int32_t \*flags, size_t n, const char \*kernel\)\n\{.*?\n\}\n", src, re.S)
+    assert m, "omr::guard_verdict not found in engine.cpp"
+    if not shutil.which("g++"):
+        pytest.skip("g++ not available")
+    prog = """#include <stdarg.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#define OMR_OK 0
+#define OMR_ERR_GPU (-217)
+static char msg[256];
+static int fail(int code, const char *fmt, ...) { va_list ap; va_start(ap, fmt); vsnprintf(msg, sizeof msg, fmt, ap); va_end(ap); return code; }
+%s
+int main() {
+    int32_t none[5] = {0, 0, 0, 0, 0}, third[5] = {0, 0, 7, 0, 0}, one[1] = {1};
+    if (guard_verdict(none, 5, "k") != OMR_OK) return 1;
+    if (guard_verdict(none, 0, "k") != OMR_OK) return 2;
+    if (guard_verdict(third, 5, "runs_kernel") != OMR_ERR_GPU || !strstr(msg, "runs_kernel") || !strstr(msg, "flag 2")) return 3;
+    if (guard_verdict(one, 1, "slane_kernel") != OMR_ERR_GPU || !strstr(msg, "slane_kernel")) return 4;
+    puts("ok");
+    return 0;
+}
+""" % m.group(0)
+    with tempfile.TemporaryDirectory() as td:
+        open(os.path.join(td, "g.cpp"), "w").write(prog)
+        subprocess.check_call(["g++", "-std=c++17", "-O1", "-o", os.path.join(td, "g"), os.path.join(td, "g.cpp")])
+        r = subprocess.run([os.path.join(td, "g")], capture_output=True, text=True)
+    assert r.returncode == 0 and r.stdout.strip() == "ok", (r.returncode, r.stdout, r.stderr)
+    # and the production synchronisation points call it
+    assert src.count("guard_verdict(") >= 4 and "check_guards(ctx)" in src.split("int omr_batch_sync(omr_batch_ctx *ctx)")[1][:600]

@@ -154,6 +154,90 @@ def test_lanes_headline_size(oracle):
         assert abs((best[i] - 200) * 0.05 - cards[i][1]) < 0.5
 
 
+def _a4_card(seed):
+    return synth.make_card(3508, 2480, seed)
+
+
+def test_lanes_the_launch_bench_py_times(oracle):
+    """THE launch form bench.py times (round-4 verdict, item 1): C2's shape and sweep, 500 scans in ONE scan-lane launch
+    -- set_lanes(512): 4 x 4 workgroups, TWO quads of scan groups (slane.hip: sgq = cq / NQ, scan groups 4 .. 7), the last
+    group partial -- with different content in every lane of every group (no scan equals another: a second-quad
+    workgroup that read the first quad's images, or wrote to its slots, cannot pass).  One scan of EVERY scan group
+    against the oracle on all 400 candidates (f64 bits of both std-devs, arg-max; projection.rs:47-65, :125-190), integer
+    projections of probed (scan, candidate) pairs in both quads, and the black-pixel total of every scan as a cheap
+    whole-batch property (every scan's row counts and column counts of a candidate add up to the same number, which
+    is the scan's own: a misplaced lane shows up as another scan's total)."""
+    import multiprocessing as mp
+    rows, cols, n = 3508, 2480, 500
+    with mp.get_context("spawn").Pool(min(8, os.cpu_count() or 1)) as pool:  # spawned: HIP is initialised in this process
+        base = [c[0] for c in pool.map(_a4_card, range(70, 78))]
+    dev = torch.device("cuda:0")
+    buf = torch.empty((n, rows, cols), dtype=torch.uint8, device=dev)
+    tb = [torch.from_numpy(b).to(dev) for b in base]
+    shifts = [((37 * i) % 211 - 105, (53 * i) % 127 - 63) for i in range(n)]  # 500 distinct (dy, dx) pairs
+    assert len(set(shifts)) == n
+    for i in range(n):
+        buf[i] = torch.roll(tb[i % 8], shifts=shifts[i], dims=(0, 1))
+    del tb
+    black = (buf <= 127).sum(dim=(1, 2)).cpu().numpy()
+    A = 400
+    best = torch.zeros(n, dtype=torch.int32, device=dev)
+    vs = torch.zeros((n, A), dtype=torch.float64, device=dev)
+    hs = torch.zeros((n, A), dtype=torch.float64, device=dev)
+    b = projection.Batch(rows, cols, 10, 0.05, n_streams=1)
+    b.set_lanes(512)
+    b.lanes_keep(True)
+    b.run_device(buf.data_ptr(), rows * cols, cols, n, 127, best.data_ptr(), vs.data_ptr(), hs.data_ptr())
+    b.sync()
+    probes = {(3, 0): None, (70, 399): None, (200, 17): None, (255, 200): None, (256, 1): None, (333, 399): None, (400, 123): None,
+              (447, 0): None, (448, 250): None, (499, 399): None}
+    for scan, a in probes:
+        probes[(scan, a)] = b.lanes_projections(scan, a, rows, cols)
+    b.close()
+    best, vs, hs = best.cpu().numpy(), vs.cpu().numpy(), hs.cpu().numpy()
+    for (scan, a), (vp, hp) in probes.items():  # every scan's own black pixels, whatever the candidate lets fall outside
+        assert int(vp.sum()) == int(hp.sum()) and int(vp.sum()) <= int(black[scan])
+    checked = (0, 100, 191, 192, 256, 300, 319, 383, 384, 447, 448, 499)  # groups 0, 1, 2, 3 | 4, 4, 4, 5, 6, 6, 7, 7
+    assert {i // 64 for i in checked} == set(range(8))
+    for i in checked:
+        binimg = np.where(np.roll(base[i % 8], shifts[i], axis=(0, 1)) <= 127, 0, 255).astype(np.uint8)
+        assert int((binimg == 0).sum()) == int(black[i])
+        evp, ehp, evs, ehs = oracle.sweep(binimg, 10, 0.05, threads=os.cpu_count() or 4, fast=True)
+        assert (vs[i].view(np.uint64) == evs.view(np.uint64)).all(), "v_sd bits, scan %d (group %d)" % (i, i // 64)
+        assert (hs[i].view(np.uint64) == ehs.view(np.uint64)).all(), "h_sd bits, scan %d (group %d)" % (i, i // 64)
+        assert best[i] == oracle.argmax_path1(evs, ehs)[0]
+        for (scan, a), (vp, hp) in probes.items():
+            if scan == i:
+                assert (vp == evp[a]).all() and (hp == ehp[a]).all(), "projections of scan %d, candidate %d" % (scan, a)
+    # the probes of scans that were not swept by the oracle above: against the oracle's warp of that one candidate
+    Ms = oracle.rotation_matrices(rows, cols, 10, 0.05)
+    for (scan, a), (vp, hp) in probes.items():
+        if scan in checked:
+            continue
+        binimg = np.where(np.roll(base[scan % 8], shifts[scan], axis=(0, 1)) <= 127, 0, 255).astype(np.uint8)
+        evp, ehp, _, _ = oracle.sweep_matrices(binimg, Ms[a:a + 1], threads=1, fast=True)
+        assert (vp == evp[0]).all() and (hp == ehp[0]).all(), "projections of scan %d, candidate %d" % (scan, a)
+    assert len({vs[i].tobytes() for i in range(n)}) == n, "500 different scans must give 500 different score vectors"
+
+
+@pytest.mark.parametrize("n", [320, 467, 512])
+def test_lanes_five_to_eight_scan_groups_every_scan(oracle, n):
+    """A small shape through the same launch form -- set_lanes(512), 4 x 4 workgroups, two quads of scan groups, 5 / 8
+    (partial) / 8 groups in use -- with EVERY scan of the batch against the oracle."""
+    rows, cols = 150, 220
+    scans = make_scans(rows, cols, n, 1000 + n)
+    best, vs, hs, proj = run_lanes(scans, 6, 0.5, 512, [(0, 0), (n - 1, 23), (256, 5), (300, 11), (319, 0)])
+    for i, img in enumerate(scans):
+        binimg = np.where(img <= 127, 0, 255).astype(np.uint8)
+        evp, ehp, evs, ehs = oracle.sweep(binimg, 6, 0.5)
+        assert (vs[i].view(np.uint64) == evs.view(np.uint64)).all(), "v_sd bits, scan %d" % i
+        assert (hs[i].view(np.uint64) == ehs.view(np.uint64)).all(), "h_sd bits, scan %d" % i
+        assert best[i] == oracle.argmax_path1(evs, ehs)[0]
+        for (scan, a), (vp, hp) in proj.items():
+            if scan == i:
+                assert (vp == evp[a]).all() and (hp == ehp[a]).all()
+
+
 @pytest.mark.parametrize("rows,cols,max_angle,step", [(200, 300, 5, 0.5), (333, 64, 10, 1.0), (1754, 1240, 10, 0.25), (97, 131, 9, 1.5),
                                                       (640, 1000, 7, 0.5), (3508, 2480, 10, 0.05), (7016, 300, 6, 1.0)])
 def test_device_built_programs_equal_the_host_generator(rows, cols, max_angle, step):

@@ -36,6 +36,8 @@ BLOCK = int(os.environ.get("SLANE_BLOCK", "64"))  # rows between two meetings of
 LB = {16: 4, 32: 5, 64: 6}[BLOCK]
 TURN = int(os.environ.get("SLANE_TURN", "16"))  # rows per turn of the loop (4, 8 or 16): the loop's own scalar work is paid once per turn
 ABLATE = os.environ.get("SLANE_ABLATE", "").split(",")  # timing probes only (results are wrong except noskip): norec, noatomic, nofetch, noskip
+PREFETCH = int(os.environ.get("SLANE_PREFETCH", "1"))  # turns ahead the record streams are pulled into L2 by a vector load (0 = off)
+PFREG = 43                     # its landing register (never read)
 RING = 60
 T0 = 44
 NPL = 13                       # counter planes per word: column counts up to 8191
@@ -62,13 +64,16 @@ def word(out, k, sset, S, dreg, tag, E=None):
     above bit 4 is ignored by v_alignbit / v_lshlrev)."""
     E = E or S
     Q32 = "q32" in ABLATE  # timing probe: one s_lshr_b32 per segment for the second shift instead of one s_lshr_b64 per pair
-    SKIP = "noskip" not in ABLATE  # a word of at most four segments skips the second group (measured: 45.1 ms with, 45.9 without)
+    # a word of at most four segments could skip the second group (the generator's flag bit 31): paid off while strips ran 2 / 4 / 8
+    # slots (45.1 ms with, 45.9 without); with exact slot counts per strip it costs more than it saves (36.7 with, 36.5 without)
+    SKIP = "skip" in ABLATE
     p = lambda j: "s%d" % (sset + k * S + j)
     groups = [list(range(0, min(E, 4)))] + ([list(range(4, E))] if E > 4 else [])
     for g, js in enumerate(groups):
         for n, j in enumerate(js):
             out.append("s_lshr_b32 m0, %s, 5" % p(j))        # ring index + SRC0_REL | SRC1_REL
-            out.append("v_alignbit_b32 v%d, v%d, v%d, %s" % (XR[n], RING + 1, RING, p(j)))
+            tgt = dreg if (g == 0 and n == 0 and "nofirstshift" in ABLATE) else XR[n]
+            out.append("v_alignbit_b32 v%d, v%d, v%d, %s" % (tgt, RING + 1, RING, p(j)))
         out.append("s_mov_b32 m0, 0")
         for n, j in enumerate(js):
             if Q32:
@@ -79,6 +84,8 @@ def word(out, k, sset, S, dreg, tag, E=None):
                     out.append("s_lshr_b64 s[10:11], s[%d:%d], 21" % (sset + k * S + j, sset + k * S + j + 1))
                 q = "s%d" % (10 + (n & 1))
             if g == 0 and n == 0:
+                if "nofirstshift" in ABLATE:  # timing probe: what a first segment read straight into the word would save
+                    continue
                 out.append("v_lshlrev_b32 v%d, %s, v%d" % (dreg, q, XR[n]))
             else:
                 out.append("v_alignbit_b32 v%d, v%d, v%d, %s" % (dreg, XR[n], dreg, q))
@@ -97,12 +104,17 @@ def commit_and_fetch(out, x, tset):
     c0, c1 = FCOM[x], FCOM[x] + 1
     for f, ins in enumerate(("s_and_b32 m0, s%d, 0xffff" % c0, "s_lshr_b32 m0, s%d, 16" % c0,
                              "s_and_b32 m0, s%d, 0xffff" % c1, "s_lshr_b32 m0, s%d, 16" % c1)):
+        if "nocommit" in ABLATE:
+            break
         out.append(ins)                                          # ring register | DST_REL
         out.append("v_mov_b32 v%d, v%d" % (RING, t + f))
     # (M0 is left as it is: the loads below are not vector-ALU instructions -- the index mode does not touch them -- and the
     # next vector-ALU instruction is a word's first indexed v_alignbit, right behind its own M0 write)
     for f in range(4):
         if "nofetch" not in ABLATE:
+            if "hotfetch" in ABLATE:  # timing probe: every source load reads entry 0 (always in the vector cache): what the source fetch's latency costs
+                out.append("buffer_load_dword v%d, %%[lane4], s[4:7], 0 offen" % (t + f))
+                continue
             out.append("buffer_load_dword v%d, %%[lane4], s[4:7], s%d offen" % (t + f, FOFF[x] + f))
 
 
@@ -134,7 +146,7 @@ def flush(out, L):
     out += ["s_sub_u32 s10, 0, s8", "s_and_b32 s10, s10, %d" % ph, "s_cmp_lg_u32 s10, %d" % ph, "s_cbranch_scc1 %s_nofl" % L]
     if "noatomic" not in ABLATE:
         out += ["s_load_dwordx4 s[48:51], %[desc], 16", "s_load_dwordx2 s[52:53], %[desc], 48",
-                "s_waitcnt lgkmcnt(0)", "s_barrier",
+                "s_waitcnt lgkmcnt(0)"] + ([] if "nobarrier" in ABLATE else ["s_barrier"]) + [
                 "s_bfe_u32 s57, s9, 0x40008",                              # pair rows this wave sends on (bits 11:8)
                 "s_cmp_eq_u32 s57, 0", "s_cbranch_scc1 %s_nofl" % L,
                 "s_sub_u32 s54, s52, s8",                                  # row index of the turn (12 mod 16)
@@ -171,29 +183,30 @@ def carry_save(out, L, second, grp=0):
     """odd row of a pair: (even row's word in c0, this row's word in DODD) -> the carry-save tree.  First pair of the turn:
     bit 1 of the row index is clear, the carry is parked in c1; second pair: c1 is consumed and bits 2.. of the row index
     (= -rows left, modulo 64) say how far the carry travels."""
+    # bits 2.. of the row index say how far the carry travels: the bits below log2(TURN) are known here (grp = this group of
+    # four rows within the turn), the others are read from -s8 (the turn's first row, modulo 64).  A carry whose parking
+    # level is known when the program is generated is written straight into its parking register (no v_mov).
+    known = {4: 0, 8: 1, 16: 2}[TURN]
+
+    def parks_at(lv):  # the carry INTO level lv is parked there (known now)
+        return lv == 1 and not second or (second and lv >= 2 and lv - 2 < known and not (grp >> (lv - 2)) & 1)
+
     for k in range(2):
-        maj(out, CARRY[k][0], P[k], ST[k], DODD[k])
+        maj(out, ST[k] + 1 if parks_at(1) else CARRY[k][0], P[k], ST[k], DODD[k])
         xor3(out, P[k], P[k], ST[k], DODD[k])
     if not second:
-        for k in range(2):
-            out.append("v_mov_b32 v%d, v%d" % (ST[k] + 1, CARRY[k][0]))
         return
     for k in range(2):
-        maj(out, CARRY[k][1], P[k] + 1, ST[k] + 1, CARRY[k][0])
+        maj(out, ST[k] + 2 if parks_at(2) else CARRY[k][1], P[k] + 1, ST[k] + 1, CARRY[k][0])
         xor3(out, P[k] + 1, P[k] + 1, ST[k] + 1, CARRY[k][0])
     cur = 1
-    # bits 2.. of the row index say how far the carry travels: the bits below log2(TURN) are known here (grp = this group of
-    # four rows within the turn), the others are read from -s8 (the turn's first row, modulo 64)
-    known = {4: 0, 8: 1, 16: 2}[TURN]
     sub_done = False
     for lv in range(2, NST):
         if lv - 2 < known:
-            if not (grp >> (lv - 2)) & 1:  # the carry is parked at this level: done, nothing to decide at run time
-                for k in range(2):
-                    out.append("v_mov_b32 v%d, v%d" % (ST[k] + lv, CARRY[k][cur]))
+            if not (grp >> (lv - 2)) & 1:  # the carry was parked at this level by the maj above: done
                 return
             for k in range(2):
-                maj(out, CARRY[k][cur ^ 1], P[k] + lv, ST[k] + lv, CARRY[k][cur])
+                maj(out, ST[k] + lv + 1 if parks_at(lv + 1) else CARRY[k][cur ^ 1], P[k] + lv, ST[k] + lv, CARRY[k][cur])
                 xor3(out, P[k] + lv, P[k] + lv, ST[k] + lv, CARRY[k][cur])
             cur ^= 1
             continue
@@ -237,6 +250,27 @@ def body(o, S, L, E=None):
         rec_loads(o, 2, S, 2, True)
         rec_loads(o, 3, S, 3, True)
     o.append("L%s_loop:" % L)
+    if PREFETCH:
+        # The records of the turn PREFETCH turns ahead, pulled into L2 by two vector loads (a lane per 128-byte line) of the
+        # wave of the strip's FIRST scan group (lds_base = 0): a scalar load that misses the scalar cache then finds its
+        # line in L2 instead of waiting for HBM.  MUBUF loads through a descriptor made on the spot in s[48:51] (segment set
+        # C is dead at the top of a turn: its last records were consumed by rows 14 / 15, the next are requested at row 0),
+        # whose num_records is exactly the range wanted: lanes beyond it are dropped by the range check, so no EXEC games
+        # and nothing can be read that was not meant to be.  Loads return in order, so the counted vmcnt waits of
+        # commit_and_fetch stay correct (two more loads among the younger ones only make them stricter for a few rows);
+        # v43 is never read.
+        seg_b, fet_b = TURN * 2 * S * 4, TURN * 32
+        assert PREFETCH * seg_b < 4096, "the prefetch distance must fit the load's 12-bit offset"
+        o += ["s_and_b32 s10, s9, 0xfffff000", "s_cmp_lg_u32 s10, 0", "s_cbranch_scc1 L%s_nopf" % L,
+              "s_mov_b32 s48, s0", "s_and_b32 s49, s1, 0xffff", "s_mov_b32 s50, %d" % ((PREFETCH + 1) * seg_b + 64),
+              "s_mov_b32 s51, 0x00020000",
+              "v_lshlrev_b32 v42, 5, %[lane4]",                                          # lane * 128
+              "s_nop 0",
+              "buffer_load_dword v%d, v42, s[48:51], 0 offen offset:%d" % (PFREG, PREFETCH * seg_b),
+              "s_mov_b32 s48, s2", "s_and_b32 s49, s3, 0xffff", "s_mov_b32 s50, %d" % ((PREFETCH + 1) * fet_b + 64),
+              "s_nop 0",
+              "buffer_load_dword v%d, v42, s[48:51], 0 offen offset:%d" % (PFREG, PREFETCH * fet_b),
+              "L%s_nopf:" % L]
     # LDS address of this turn's pair slots: buffer = bit log2(BLOCK) of the row index, slot = the bits below it down to 1
     o += ["s_sub_u32 s10, 0, s8", "s_bfe_u32 s10, s10, 0x%x" % ((LB << 16) | 1), "s_lshl_b32 s10, s10, 8", "s_and_b32 s11, s9, 0xfffff000",
           "s_add_u32 s10, s10, s11", "v_add_u32 v%d, s10, %%[lane4]" % LADDR]
@@ -254,8 +288,11 @@ def body(o, S, L, E=None):
         if odd:
             carry_save(o, "L%s_cs%d" % (L, r), (r & 2) != 0, r // 4)
     flush(o, "L%s" % L)
-    o += ["s_add_u32 s0, s0, %d" % (TURN * 2 * S * 4), "s_addc_u32 s1, s1, 0",
-          "s_add_u32 s2, s2, %d" % (TURN * 32), "s_addc_u32 s3, s3, 0",
+    # (hotrec, a timing probe: the stream pointers stand still, every turn re-reads the first turn's records out of the scalar
+    # cache -- the same instructions without the records' latency)
+    HOT = "hotrec" in ABLATE
+    o += ["s_add_u32 s0, s0, %d" % (0 if HOT else TURN * 2 * S * 4), "s_addc_u32 s1, s1, 0",
+          "s_add_u32 s2, s2, %d" % (0 if HOT else TURN * 32), "s_addc_u32 s3, s3, 0",
           "s_sub_u32 s8, s8, %d" % TURN, "s_cmp_lg_u32 s8, 0", "s_cbranch_scc1 L%s_loop" % L]
 
 
@@ -271,6 +308,10 @@ def kernel():
         o.append("v_mov_b32 v%d, 0" % v)
     o.append("s_waitcnt lgkmcnt(0)")
     o.append("s_or_b32 s9, s9, s10")
+    if "prio" in ABLATE:  # the four waves of a SIMD (the scan groups of a strip: bits 15:14 of the LDS base) at four priorities
+        o += ["s_bfe_u32 s10, s9, 0x2000e", "s_cmp_eq_u32 s10, 1", "s_cbranch_scc0 L%s_p1" % U, "s_setprio 1", "L%s_p1:" % U,
+              "s_cmp_eq_u32 s10, 2", "s_cbranch_scc0 L%s_p2" % U, "s_setprio 2", "L%s_p2:" % U,
+              "s_cmp_eq_u32 s10, 3", "s_cbranch_scc0 L%s_p3" % U, "s_setprio 3", "L%s_p3:" % U]
     o += ["s_set_gpr_idx_on s10, gpr_idx(SRC0)", "s_mov_b32 m0, 0"]  # index mode on for good; M0 = 0: nothing indexed
     # slot classes (slane.hpp): laid out / executed = 2/2, 4/4, 8/8, 4/3, 8/5, 8/6, 8/7
     CLASSES = ((0, 2, 2), (1, 4, 4), (2, 8, 8), (3, 4, 3), (4, 8, 5), (5, 8, 6), (6, 8, 7))
@@ -278,6 +319,8 @@ def kernel():
         o += ["s_cmp_eq_u32 s11, %d" % cls, "s_cbranch_scc1 L%s_c%d" % (U, cls)]
     for cls, S, E in reversed(CLASSES):
         o.append("L%s_c%d:" % (U, cls))
+        if "lessE" in ABLATE:  # timing probe: what one executed slot per word costs (an upper bound for exact slot counts per turn)
+            E = max(1, E - 1)
         body(o, S, "%s_c%d" % (U, cls), E)
         if cls:
             o.append("s_branch L%s_dump" % U)

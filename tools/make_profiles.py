@@ -118,10 +118,12 @@ with open(os.path.join(dst, tag + "_rocprofv3_kernel_stats_bench.md"), "w") as f
     rl = line["roofline"]
     f.write("\nUn-profiled bench line of the same build (`profiles/%s_bench_line.json`): **%.0f images/s**, `roofline.kernel_ms` "
             "%.4f ms per launch of %d scans (HIP events on the launch stream, %d launches), bound `%s` frac %.3f; VALU issue %.3f, "
-            "LDS busy %.3f (conflict share %.3f), HBM %.3f of 8 TB/s from the run's own FETCH_SIZE / WRITE_SIZE passes.\n" % (
-                tag, line["value"], rl["kernel_ms"], rl["scans_per_launch"], rl["launch_groups_timed"], rl.get("bound"),
-                rl.get("frac") or float("nan"), rl.get("valu_issue_frac_at_2_cycles", float("nan")), rl.get("lds_busy_frac", float("nan")),
-                rl.get("lds_conflict_frac", float("nan")), rl.get("hbm_frac", float("nan"))))
+            "SCALAR issue %.3f, LDS busy %.3f (conflict share %.3f), HBM %.3f of 8 TB/s from the run's own FETCH_SIZE / WRITE_SIZE "
+            "passes; waves in s_waitcnt %.3f of their cycles.\n" % (
+                tag, line["value"], rl["kernel_ms"], rl["scans_per_launch"], rl["detail"]["launch_groups_timed"], rl.get("bound"),
+                rl.get("frac") or float("nan"), rl.get("valu_frac") or float("nan"), rl.get("scalar_frac") or float("nan"),
+                rl.get("lds_frac") or float("nan"), rl["detail"].get("lds_conflict_frac", float("nan")), rl.get("hbm_frac") or float("nan"),
+                rl.get("wait_frac") or float("nan")))
     if line.get("deskew"):
         dk = line["deskew"]
         f.write("With the deskewed image produced inside the timed region (`omr_batch_deskew_device`): **%.0f images/s** LINEAR "
@@ -146,11 +148,20 @@ with open(os.path.join(dst, tag + "_pmc_sweep.md"), "w") as f:
     if line and line["roofline"].get("traffic"):
         rl = line["roofline"]
         f.write("\n(2 x FETCH_SIZE + WRITE_SIZE) x 1024 = **%.0f MB per launch of %d scans** = %.0f GB/s = %.3f of the 8 TB/s HBM peak, "
-                "against %.0f MB of compulsory traffic (bit images + outputs) and %.0f MB of SURVEY-8(d) algorithmic bytes.\n" % (
-                    rl["traffic"] / 1e6, rl["scans_per_launch"], rl["hbm_measured_GBps"], rl["hbm_frac"],
-                    rl["compulsory_bytes_per_launch"] / 1e6, rl["algorithmic_bytes_per_launch"] / 1e6))
+                "against %.0f MB of compulsory traffic (programs once per quad of scan groups + bit images + outputs) and %.0f MB of SURVEY-8(d) algorithmic bytes.\n" % (
+                    rl["traffic"] / 1e6, rl["scans_per_launch"], rl["detail"]["hbm_measured_GBps"], rl["hbm_frac"],
+                    rl["compulsory_bytes_per_launch"] / 1e6, rl["detail"]["algorithmic_bytes_per_launch"] / 1e6))
+        c = rl["detail"].get("sq_counters_per_launch")
+        if c:
+            f.write("\n`roofline` of the bench line, reproduced from the SQ pass above: SCALAR = (SQ_INSTS_SALU + SQ_INSTS_SMEM) / kernel time / "
+                    "(256 CUs x 2.4 GHz) = **%.3f** (against the CU's own busy cycles: %.3f); VALU = SQ_INSTS_VALU / kernel time / (1024 SIMDs x "
+                    "2.4 GHz / 2) = **%.3f**; LDS = SQ_LDS_IDX_ACTIVE / kernel time / (256 x 2.4 GHz) = %.3f; waves waiting in s_waitcnt = "
+                    "SQ_WAIT_ANY / SQ_WAVE_CYCLES = **%.3f**; `bound` = `%s` (the largest fraction), `frac` = %.3f.\n" % (
+                        rl.get("scalar_frac") or float("nan"), rl["detail"].get("scalar_frac_of_busy_cu_cycles", float("nan")),
+                        rl.get("valu_frac") or float("nan"), rl.get("lds_frac") or float("nan"), rl.get("wait_frac") or float("nan"),
+                        rl.get("bound"), rl.get("frac") or float("nan")))
         json.dump({"kernel": rl["kernel"], "measured_at": "commit %s, %s" % (commit, tag),
-                   "FETCH_SIZE_KB_per_launch": rl["hbm_counters_KB"]["FETCH_SIZE"], "WRITE_SIZE_KB_per_launch": rl["hbm_counters_KB"]["WRITE_SIZE"],
+                   "FETCH_SIZE_KB_per_launch": rl["detail"]["hbm_counters_KB"]["FETCH_SIZE"], "WRITE_SIZE_KB_per_launch": rl["detail"]["hbm_counters_KB"]["WRITE_SIZE"],
                    "sweep_kernel_hbm_bytes_per_launch": rl["traffic"], "scans_per_launch": rl["scans_per_launch"],
                    "correction": "gfx950: FETCH_SIZE x2 (MI355X_MICROARCH.md HBM section), WRITE_SIZE as is, x1024 B"},
                   open(os.path.join(dst, "hbm_traffic.json"), "w"), indent=1)
