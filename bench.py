@@ -323,23 +323,32 @@ def e2e_host(cards, B, order, repeats=3):
     create_s = time.perf_counter() - t0
     _, spl, lane = hb.info()
     out = {"what": "omr_host_batch_run: %d binarised scans from host memory to best angles on the host, 1 GPU; context "
-                   "(plan, pinned ring of 3 x 16 scans, 2 device stages of one 64-scan launch) created outside the timed region; best of %d runs"
-                   % (B, repeats),
+                   "(plan, pinned ring of 3 x 16 scans, 2 device stages of one launch) created outside the timed region; best of %d runs; "
+                   "three transfer modes: pageable u8 (copier threads -> pinned ring -> DMA), page-locked u8 (DMA from the caller's memory), "
+                   "packed (the copier threads pack to 1 bit per pixel, 1/8 of the bytes cross the link)" % (B, repeats),
            "scans_per_launch": spl, "scan_lane": lane, "context_creation_s": create_s}
     ref = None
-    for name, src, pin in (("pageable", pageable, False), ("pinned", pinned, True)):
-        hb.run(src[:min(B, spl)], pinned=pin)
+    nw = (COLS + 31) // 32
+    # (name, source, pinned, packed, scans per launch): the u8 modes are bound by the copies -- 64-scan launches keep the
+    # exposed last sweep short; packed transfers (1 bit per pixel made by the copier threads, 1/8 of the bytes uploaded) are
+    # bound by the sweep and the host's packing rate -- 128-scan launches sweep faster per scan
+    for name, src, pin, pk, launch in (("pageable", pageable, False, False, 64), ("pinned", pinned, True, False, 64),
+                                       ("packed", pageable, False, True, 128)):
+        hb.set_launch(min(launch, 64 * ((B + 63) // 64)))
+        hb.run(src[:min(B, launch)], pinned=pin, packed=pk)
         best_t = None
         for _ in range(repeats):
             t0 = time.perf_counter()
-            best, _, _, _ = hb.run(src, pinned=pin)
+            best, _, _, _ = hb.run(src, pinned=pin, packed=pk)
             dt = time.perf_counter() - t0
             best_t = dt if best_t is None else min(best_t, dt)
         if ref is None:
             ref = best
         out[name + "_images_per_s"] = B / best_t
-        out[name + "_h2d_GBps"] = B * ROWS * COLS / best_t / 1e9
+        out[name + "_h2d_GBps"] = B * (ROWS * nw * 4 if pk else ROWS * COLS) / best_t / 1e9
+        out[name + "_scans_per_launch"] = hb.info()[1]
         out[name + "_agrees"] = bool((best == ref).all())
+    out["packed_host_read_GBps"] = B * ROWS * COLS / (B / out["packed_images_per_s"]) / 1e9
     hb.close()
     return out, ref
 
@@ -667,6 +676,8 @@ def main():
             out["e2e_host_images_per_s"] = e2e["pageable_images_per_s"]
             out["e2e_host_pinned_images_per_s"] = e2e["pinned_images_per_s"]
             out["e2e_host_h2d_GBps"] = e2e["pinned_h2d_GBps"]
+            out["e2e_host_packed_images_per_s"] = e2e["packed_images_per_s"]
+            out["e2e_host_packed_h2d_GBps"] = e2e["packed_h2d_GBps"]
         except Exception as e:  # noqa: BLE001  (a side leg must never take the bench line down)
             out["e2e_host"] = {"error": repr(e)}
     if world > 1:
@@ -692,7 +703,7 @@ def main():
         if "cpu_baseline" in out and not out["cpu_baseline"].get("parity_vs_gpu", True):
             problems.append("cpu_baseline.parity_vs_gpu is false (GPU scores differ from the oracle's)")
         e2 = out.get("e2e_host", {})
-        if e2 and "error" not in e2 and not (e2.get("agrees_with_resident_run", True) and e2.get("pinned_agrees", True)):
+        if e2 and "error" not in e2 and not (e2.get("agrees_with_resident_run", True) and e2.get("pinned_agrees", True) and e2.get("packed_agrees", True)):
             problems.append("e2e_host results differ from the HBM-resident run")
         if problems:
             raise SystemExit("bench.py: " + "; ".join(problems))

@@ -245,14 +245,27 @@ int omr_host_batch_create(int32_t rows, int32_t cols, uint16_t max_angle, double
                           int32_t max_scans, omr_host_batch **out);
 void omr_host_batch_destroy(omr_host_batch *hb);
 int omr_host_batch_info(const omr_host_batch *hb, int32_t *n_devices, int32_t *scans_per_launch, int32_t *scan_lane);
-/* scans[i] -> device i % n_devices: host memory -> (pageable: copier threads -> pinned ring; source_is_pinned != 0: DMA
- * straight from the caller's page-locked memory) -> device stage -> sweep; the copy of one launch overlaps the sweep of
- * the previous one.  Pixels == 0 are black (binarised scans, as omr_sweep_batch).  Outputs as omr_sweep_batch. */
-int omr_host_batch_run(omr_host_batch *hb, const omr_image *scans, int32_t n, int32_t source_is_pinned,
+/* scans[i] -> device i % n_devices: host memory -> device stage -> sweep; the transfer of one launch overlaps the sweep of
+ * the previous one.  Pixels == 0 are black (binarised scans, as omr_sweep_batch).  transfer_mode:
+ *   OMR_HOST_PAGEABLE  the context's copier threads move the scans into its pinned ring, DMA from there;
+ *   OMR_HOST_PINNED    the caller's memory is page-locked: DMA straight out of it;
+ *   OMR_HOST_PACKED    the copier threads -- which touch every byte anyway -- turn each binarised scan into 1 bit per pixel
+ *                      on its way into the ring: 1/8 of the bytes cross the link (1.09 MB per A4 scan), a device kernel
+ *                      interleaves the packed rows into the scan-lane image.  Contexts on the run-merging path (fewer than
+ *                      64 scans per device) transfer the bytes as they are.
+ * The three give the same results, bit for bit.  Outputs as omr_sweep_batch. */
+#define OMR_HOST_PAGEABLE 0
+#define OMR_HOST_PINNED 1
+#define OMR_HOST_PACKED 2
+int omr_host_batch_run(omr_host_batch *hb, const omr_image *scans, int32_t n, int32_t transfer_mode,
                        int32_t *best_idx, double *best_angle, double *v_sd_opt, double *h_sd_opt);
+/* Scans per sweep launch (scan-lane contexts: rounded up to a multiple of 64, at most 512; default 64, which suits the
+ * copy-bound u8 modes -- the last launch's sweep is what nothing overlaps; packed transfers are sweep-bound and larger
+ * launches sweep faster per scan).  Re-sizes the device stages and the sweep's scratch. */
+int omr_host_batch_set_launch(omr_host_batch *hb, int32_t scans_per_launch);
 
 /* Host-buffer batch over the visible devices (SURVEY.md 8b `omr_sweep_batch`): scans[i] goes
- * to device i % n_devices (an omr_host_batch made for this one call: plan and ring creation are inside the call);
+ * to device i % n_devices (an omr_host_batch made for this one call: plan and ring creation are inside the call; packed transfers);
  * the only "collective" is the host-side gather of the results.  n_devices <= 0 = every visible device;
  * n_devices > omr_device_count() is OMR_ERR_BADARG (never a silent clamp).
  * best_angle[i] = (best_idx[i] - N) * step (projection.rs:189-190). */

@@ -1135,6 +1135,22 @@ int omr_batch_run_device(omr_batch_ctx *ctx, const uint8_t *d_scans, int64_t sca
     return batch_run(ctx, d_scans, scan_stride, step_bytes, n, black_max, d_best_idx, d_v_sd, d_h_sd, nullptr);
 }
 
+}  // extern "C"
+
+// Scans that are already packed to 1 bit per pixel on the device ([rows][ceil(cols / 32)] dwords each, bit i of word c =
+// pixel 32 c + i is black): the host-memory batch's packed transfer mode (oics_hostbatch.cpp).  Scan-lane contexts only.
+int omr::batch_run_device_bits(omr_batch_ctx *ctx, const uint32_t *d_bits, int64_t scan_stride_bytes, int32_t n,
+                               int32_t *d_best_idx, double *d_v_sd, double *d_h_sd)
+{
+    if (!ctx || !d_bits || n < 0) return fail(OMR_ERR_BADARG, "bad batch arguments");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    if (ctx->lanes <= 0) return fail(OMR_ERR_BADARG, "packed scans need a context in scan-lane mode");
+    OMR_HIP(hipSetDevice(ctx->tables.device));
+    return batch_run(ctx, (const uint8_t *)d_bits, scan_stride_bytes, 0, n, /*black_max: packed*/ -1, d_best_idx, d_v_sd, d_h_sd, nullptr);
+}
+
+extern "C" {
+
 int omr_batch_deskew_canvas(omr_batch_ctx *ctx, int32_t *max_rows, int32_t *max_cols)
 {
     if (!ctx) return fail(OMR_ERR_BADARG, "null ctx");

@@ -150,6 +150,8 @@ int enqueue_sweep(const SweepTables &t, SweepScratch &s, int kernel_sel, const u
                   hipStream_t post_stream = nullptr, hipEvent_t ev_mid = nullptr, int scans = 1, int64_t img_stride = 0);
 
 // ---- scan-lane sweep (slane.hpp): lane = scan, for batches of same-shape scans
+struct SlanePlan;
+struct SlaneScratch;
 struct SlanePlan {
     SlaneGeom g;
     int A = 0, nrec = 0;
@@ -178,6 +180,12 @@ int slane_enqueue(const SlanePlan &p, SlaneScratch &s, const uint8_t *d_img, int
                   int32_t *d_best, hipEvent_t ev0, hipEvent_t ev1);
 
 }  // namespace omr
+
+struct omr_batch_ctx;
+namespace omr {
+int batch_run_device_bits(omr_batch_ctx *ctx, const uint32_t *d_bits, int64_t scan_stride_bytes, int32_t n, int32_t *d_best_idx,
+                          double *d_v_sd, double *d_h_sd);
+}
 
 struct omr_sweep_plan {
     omr::SweepTables tables;

@@ -796,7 +796,7 @@ int omr_sweep_batch(const omr_image *scans, int32_t n, uint16_t max_angle, doubl
     if (rc) return rc;
     omr_host_batch *hb = nullptr;
     if ((rc = omr_host_batch_create(scans[0].rows, scans[0].cols, max_angle, step, n_devices, n, &hb))) return rc;
-    rc = omr_host_batch_run(hb, scans, n, 0, best_idx, best_angle, v_sd_opt, h_sd_opt);
+    rc = omr_host_batch_run(hb, scans, n, OMR_HOST_PACKED, best_idx, best_angle, v_sd_opt, h_sd_opt);
     omr_host_batch_destroy(hb);
     return rc;
 }

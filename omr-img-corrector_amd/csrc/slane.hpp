@@ -170,6 +170,9 @@ hipError_t launch_slane_build_scan(const SlaneBuild &b, int ntasks, hipStream_t 
 hipError_t launch_slane_build_emit(const SlaneBuild &b, int ntasks, hipStream_t s);   // -> prog (needs cls, seg_off, fet_off)
 hipError_t launch_slane_pack(const uint8_t *d_img, int64_t scan_stride, int64_t step, const SlaneGeom &g, int nscans,
                              int black_max, uint32_t *d_bits, hipStream_t s);
+// scans that arrive packed to 1 bit per pixel: [scan][rows][NW] dwords, bit i of word c = pixel 32 c + i is black
+hipError_t launch_slane_pack_bits(const uint32_t *d_packed, int64_t scan_stride_dwords, const SlaneGeom &g, int nscans,
+                                  uint32_t *d_bits, hipStream_t s);
 // nsg_used = scan groups that carry scans in this launch, nsg = scan groups the scratch (and its descriptors) is laid out for
 hipError_t launch_slane(const SlaneTask *d_descs, int nsgq, int nsgp, int A, int NQ, int sgw_log, int32_t *d_guard, hipStream_t s);
 hipError_t launch_slane_vproj(const uint32_t *d_planes, const int32_t *d_tasks, int ntasks, int nsg_used, int nsg, int NS,

@@ -268,19 +268,24 @@ int SlaneScratch::create(const SlanePlan &p, int groups)
 }
 
 // pack -> sweep -> column counts -> std-dev -> arg-max for `nscans` device-resident scans (at most nsg * 64)
+// (black_max < 0: d_img holds scans ALREADY packed to 1 bit per pixel, [rows][NW] dwords each, scan_stride bytes apart)
 int slane_enqueue(const SlanePlan &p, SlaneScratch &s, const uint8_t *d_img, int64_t scan_stride, int64_t step, int nscans,
                   int black_max, hipStream_t stream, hipStream_t post_stream, hipEvent_t ev_mid, double *d_v_sd, double *d_h_sd,
                   int32_t *d_best, hipEvent_t ev0, hipEvent_t ev1)
 {
+    const bool packed = black_max < 0;
     if (!d_img || nscans < 1 || nscans > s.nsg * SL_LANES) return fail(OMR_ERR_BADARG, "scan-lane launch: %d scans, scratch holds %d", nscans, s.nsg * SL_LANES);
-    if (step < p.g.cols) return fail(OMR_ERR_BADARG, "step_bytes %lld < cols %d", (long long)step, p.g.cols);
+    if (!packed && step < p.g.cols) return fail(OMR_ERR_BADARG, "step_bytes %lld < cols %d", (long long)step, p.g.cols);
+    if (packed && ((scan_stride & 3) != 0 || scan_stride < (int64_t)p.g.rows * p.g.NW * 4 || ((uintptr_t)d_img & 3) != 0))
+        return fail(OMR_ERR_BADARG, "packed scans: rows x %d dwords each, 4-byte aligned", p.g.NW);
     const int used = (nscans + SL_LANES - 1) / SL_LANES;  // scan groups that hold scans; the descriptors are laid out for s.nsg
     const size_t nscp = (size_t)s.nsg * SL_LANES;
     if (s.rows_dirty) {  // the previous launch was asked to keep its row counts (omr_batch_lanes_keep)
         OMR_HIP(hipMemsetAsync(s.hrows.p, 0, s.rows_bytes, stream));
         s.rows_dirty = false;
     }
-    OMR_HIP(launch_slane_pack(d_img, scan_stride, step, p.g, nscans, black_max, s.bits.as<uint32_t>(), stream));
+    if (packed) OMR_HIP(launch_slane_pack_bits((const uint32_t *)d_img, scan_stride / 4, p.g, nscans, s.bits.as<uint32_t>(), stream));
+    else OMR_HIP(launch_slane_pack(d_img, scan_stride, step, p.g, nscans, black_max, s.bits.as<uint32_t>(), stream));
     if (ev0) OMR_HIP(hipEventRecord(ev0, stream));
     {   // the workgroup's composition: 16 strips x 1 scan group, 8 x 2 or 4 x 4 (the scratch holds a table for each)
         const int lg = used <= 1 ? 0 : used == 2 ? 1 : 2, sgw = 1 << lg, places = 16 >> lg;

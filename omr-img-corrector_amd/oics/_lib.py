@@ -80,6 +80,7 @@ SYMBOLS = {
     "omr_host_batch_destroy": (None, [C.c_void_p]),
     "omr_host_batch_info": (C.c_int, [C.c_void_p, i32p, i32p, i32p]),
     "omr_host_batch_run": (C.c_int, [C.c_void_p, C.POINTER(OmrImage), C.c_int32, C.c_int32, i32p, f64p, f64p, f64p]),
+    "omr_host_batch_set_launch": (C.c_int, [C.c_void_p, C.c_int32]),
     "omr_sweep_batch": (C.c_int, [C.POINTER(OmrImage), C.c_int32, C.c_uint16, C.c_double, C.c_int32, i32p, f64p, f64p,
                                   f64p]),
     "omr_get_angle_with_projections": (C.c_int, [C.POINTER(OmrImage), C.c_uint16, C.c_double, C.c_double, C.c_size_t,

@@ -227,8 +227,15 @@ class HostBatch:
         check(lib().omr_host_batch_info(self.handle, C.byref(nd), C.byref(spl), C.byref(sl)))
         return nd.value, spl.value, bool(sl.value)
 
-    def run(self, scans, pinned=False, want_sd=False):
-        """scans: list of 2-D u8 arrays (pixels == 0 black).  pinned=True: the arrays live in page-locked memory."""
+    PAGEABLE, PINNED, PACKED = 0, 1, 2  # omr_host_batch_run's transfer modes (include/omrdeskew.h)
+
+    def set_launch(self, scans_per_launch):
+        """scans per sweep launch (scan-lane contexts: multiples of 64; default 64)"""
+        check(lib().omr_host_batch_set_launch(self.handle, int(scans_per_launch)))
+
+    def run(self, scans, pinned=False, want_sd=False, packed=False):
+        """scans: list of 2-D u8 arrays (pixels == 0 black).  pinned=True: the arrays live in page-locked memory;
+        packed=True: the context's copier threads pack them to 1 bit per pixel and 1/8 of the bytes are uploaded."""
         from ._lib import OmrImage
         keep, arr = [], (OmrImage * len(scans))()
         for i, s in enumerate(scans):
@@ -240,7 +247,7 @@ class HostBatch:
         ang = np.zeros(n, np.float64)
         vs = np.zeros((n, self.A)) if want_sd else None
         hs = np.zeros((n, self.A)) if want_sd else None
-        check(lib().omr_host_batch_run(self.handle, arr, n, 1 if pinned else 0, best.ctypes.data_as(i32p),
+        check(lib().omr_host_batch_run(self.handle, arr, n, 2 if packed else 1 if pinned else 0, best.ctypes.data_as(i32p),
                                        ang.ctypes.data_as(f64p), vs.ctypes.data_as(f64p) if want_sd else None,
                                        hs.ctypes.data_as(f64p) if want_sd else None))
         return best, ang, vs, hs

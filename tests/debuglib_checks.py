@@ -96,7 +96,7 @@ for k, m in ((2, n), (3, n), (4, 150), (2, 131)):
     nd, spl, lane = hb.info()
     assert nd == k, (nd, k)
     for rep in range(2):  # twice on one context: rings, stages and events are reused
-        bk, ak, vk, hk = hb.run(sc[:m], want_sd=True)
+        bk, ak, vk, hk = hb.run(sc[:m], want_sd=True, packed=(rep == 1))  # the second run: packed transfers
         assert (bk == b1[:m]).all() and (ak == a1[:m]).all(), "best / angle differ with %d logical devices" % k
         assert (vk.view(np.uint64) == v1[:m].view(np.uint64)).all() and (hk.view(np.uint64) == h1[:m].view(np.uint64)).all()
     hb.close()

@@ -260,10 +260,12 @@ def test_steep_sweep_is_refused(oracle):
     b.close()
 
 
-def test_host_batch_pageable_and_pinned(oracle):
-    """omr_host_batch: 150 binarised scans from host memory (>= 64 per device: the scan-lane sweep), pageable and
-    page-locked sources, two runs on one context; every scan's scores equal the oracle's bit for bit."""
-    rows, cols, n = 180, 260, 150
+def test_host_batch_pageable_pinned_and_packed(oracle):
+    """omr_host_batch: 150 binarised scans from host memory (>= 64 per device: the scan-lane sweep) through the three
+    transfer modes -- pageable (copier threads -> pinned ring), page-locked source, PACKED (the copier threads turn every
+    scan into 1 bit per pixel, 1/8 of the bytes are uploaded, a device kernel interleaves the packed rows) -- on one
+    context, then packed again with launches of 128; every mode gives the same bits and they are the oracle's."""
+    rows, cols, n = 180, 261, 150  # (261 columns: the last word of a packed row is partial, and rows are not whole dwords)
     scans = [np.where(s <= 127, 0, 255).astype(np.uint8) for s in make_scans(rows, cols, n, 31)]
     hb = projection.HostBatch(rows, cols, 6, 0.5, n, n_devices=1)
     nd, spl, lane = hb.info()
@@ -274,13 +276,32 @@ def test_host_batch_pageable_and_pinned(oracle):
     for i in range(n):
         pn[i] = scans[i]
     best2, _, vs2, hs2 = hb.run([pn[i] for i in range(n)], pinned=True, want_sd=True)
-    hb.close()
     assert (best == best2).all() and (vs.view(np.uint64) == vs2.view(np.uint64)).all() and (hs.view(np.uint64) == hs2.view(np.uint64)).all()
+    # packed: scans with a row pitch (views into a wider buffer) as well
+    wide = np.full((n, rows, cols + 19), 7, np.uint8)
+    wide[:, :, :cols] = np.stack(scans)
+    for src in (scans, [wide[i, :, :cols] for i in range(n)]):
+        best3, ang3, vs3, hs3 = hb.run(src, want_sd=True, packed=True)
+        assert (best == best3).all() and (ang == ang3).all()
+        assert (vs.view(np.uint64) == vs3.view(np.uint64)).all() and (hs.view(np.uint64) == hs3.view(np.uint64)).all()
+    hb.set_launch(128)
+    assert hb.info()[1] == 128
+    best4, _, vs4, hs4 = hb.run(scans, want_sd=True, packed=True)
+    best5, _, vs5, _ = hb.run(scans, want_sd=True)  # the u8 path on the re-sized context
+    hb.close()
+    assert (best == best4).all() and (vs.view(np.uint64) == vs4.view(np.uint64)).all() and (hs.view(np.uint64) == hs4.view(np.uint64)).all()
+    assert (best == best5).all() and (vs.view(np.uint64) == vs5.view(np.uint64)).all()
     N, A = oracle.candidate_count(6, 0.5)
     for i in range(0, n, 7):
         _, _, evs, ehs = oracle.sweep(scans[i], 6, 0.5)
         assert (vs[i].view(np.uint64) == evs.view(np.uint64)).all() and (hs[i].view(np.uint64) == ehs.view(np.uint64)).all()
         assert best[i] == oracle.argmax_path1(evs, ehs)[0] and ang[i] == (best[i] - N) * 0.5
+    # a context on the run-merging path (fewer than 64 scans per device) takes the packed mode as a plain transfer
+    hs_ = projection.HostBatch(rows, cols, 6, 0.5, 20, n_devices=1)
+    assert not hs_.info()[2]
+    b6, _, v6, _ = hs_.run(scans[:20], want_sd=True, packed=True)
+    hs_.close()
+    assert (b6 == best[:20]).all() and (v6.view(np.uint64) == vs[:20].view(np.uint64)).all()
 
 
 def test_host_batch_refuses_more_devices_than_visible():

@@ -1,7 +1,8 @@
 """End-to-end rate of batches that start in HOST memory ("wall-clock including H2D of the u8 scan + D2H of
 scores"; the reference times image-in-memory to result, packages/core/src/main.rs:68-95): omr_host_batch_run on `scans`
 binarised A4 scans, plan / pinned ring / device stages created OUTSIDE the timed region, once from pageable memory
-(copier threads -> pinned ring -> DMA) and once from page-locked memory (DMA straight from the caller's buffers).
+(copier threads -> pinned ring -> DMA), once from page-locked memory (DMA straight from the caller's buffers) and with PACKED
+transfers (the copier threads pack to 1 bit per pixel; 1/8 of the bytes cross the link) at launches of 64 / 128 / 256 scans.
 Also the one-off call (omr_sweep_batch: context created and released inside the call).
 Never bench.py's `value` -- that is HBM-resident by contract; bench.py reports these figures as e2e_host_*.
 Usage: python tools/bench_host.py [scans, default 512] [repeats, default 3]"""
@@ -50,6 +51,24 @@ def measure(n, repeats=3, cards=None):
         out[name + "_images_per_s"] = n / best_t
         out[name + "_h2d_GBps"] = n * rows * cols / best_t / 1e9
         out[name + "_seconds"] = best_t
+    # packed transfers (OMR_HOST_PACKED): the copier threads pack every scan to 1 bit per pixel, 1/8 of the bytes are uploaded;
+    # the pipeline is then bound by the sweep, so larger launches pay (omr_host_batch_set_launch)
+    nw = (cols + 31) // 32
+    for launch in (64, 128, 256):
+        if launch > n:
+            break
+        hb.set_launch(launch)
+        hb.run(pageable[:min(n, launch)], packed=True)  # warm-up
+        best_t = None
+        for _ in range(repeats):
+            t0 = time.perf_counter()
+            best, ang, _, _ = hb.run(pageable, packed=True)
+            dt = time.perf_counter() - t0
+            best_t = dt if best_t is None else min(best_t, dt)
+        assert (best == ref).all()
+        out["packed_launch%d_images_per_s" % launch] = n / best_t
+        out["packed_launch%d_h2d_GBps" % launch] = n * rows * nw * 4 / best_t / 1e9
+        out["packed_launch%d_host_read_GBps" % launch] = n * rows * cols / best_t / 1e9
     hb.close()
     # the one-off call: omr_sweep_batch creates the context (plan generated on the device, pinned ring, stages), runs the
     # batch and releases everything -- what a caller pays who does not keep a context
