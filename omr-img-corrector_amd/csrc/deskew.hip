@@ -16,8 +16,12 @@ namespace omr {
 #define DW_TW 128  // destination tile: 128 x 32 pixels per 256-thread workgroup, 4 x 4 pixels per thread
 // tile height: 64 rows for NEAREST (the fixed chain of memory round trips per tile is spread over more pixels),
 // 32 for LINEAR (four taps per pixel: at 64 rows the pixels in flight cost 200 VGPRs)
-#define DW_TH (LINEAR ? 32 : 64)
+#ifndef DW_TH_NN
+#define DW_TH_NN 64
+#define DW_TH_LIN 64
 #define DW_LDS 16384
+#endif
+#define DW_TH (LINEAR ? DW_TH_LIN : DW_TH_NN)
 
 __device__ __forceinline__ int dw_mad24(int a, int b, int c) { return __mul24(a, b) + c; }  // v_mad_i32_i24
 __device__ __forceinline__ uint8_t dw_sat_u8(int v) { return (uint8_t)(v < 0 ? 0 : v > 255 ? 255 : v); }
@@ -44,6 +48,74 @@ __device__ __forceinline__ int dw_tap_global(const uint8_t *__restrict__ src, in
     return dw_sat_u8((v0 * w0 + v1 * w1 + v2 * w2 + v3 * w3 + (1 << 14)) >> 15);
 }
 
+// ---- per-tile records (round 5).  The warp kernel used to be a chain of FOUR dependent memory round trips per tile
+// (winner -> canvas size -> table entries of the corners -> box -> taps) with five workgroups per CU to hide them: 30 / 50
+// lane-cycles per pixel for 9 / 25 operations.  Everything that depends only on (scan, tile) -- the winner, the canvas, the
+// four corner samples and the source box they bound -- is now worked out by one thread per tile in a kernel of its own
+// (deskew_tiles_kernel: 10 000 tiles per 8 A4 scans), and the warp kernel starts from a 32-byte record: record -> {table
+// entries, box} -> taps.
+struct DeskewTile {
+    int32_t a;        // winning candidate; -1 = the tile lies outside this scan's canvas
+    int32_t bb0, by0; // the box: first byte column (a multiple of 4), first row
+    int32_t bwb, bh;  // its row length in bytes (a multiple of 4), its rows; bwb = 0: every tap of the tile is border
+    int32_t a1, b1;   // adelta / bdelta of the tile's last column (columns past it repeat it)
+    int32_t last;     // tx1 | ty1 << 16: the tile's last column and row inside the canvas
+};
+
+template <bool LINEAR>
+__global__ __launch_bounds__(64) void deskew_tiles_kernel(const DeskewPass p, DeskewTile *__restrict__ tiles, int ntx, int nty)
+{
+    const int t = blockIdx.x * 64 + threadIdx.x, z = blockIdx.y;
+    if (t >= ntx * nty) return;
+    const int tyi = t / ntx, txi = t - tyi * ntx;
+    const int a = p.best[z];
+    const int drows = p.wsize[2 * a], dcols = p.wsize[2 * a + 1];
+    if (t == 0 && p.out_size) {
+        p.out_size[2 * z] = drows;
+        p.out_size[2 * z + 1] = dcols;
+    }
+    DeskewTile r;
+    r.a = -1, r.bb0 = r.by0 = r.bwb = r.bh = r.a1 = r.b1 = r.last = 0;
+    const int tx0 = txi * DW_TW, ty0 = tyi * DW_TH;
+    if (tx0 < dcols && ty0 < drows) {
+        const int32_t *__restrict__ AD = p.adelta + (int64_t)a * p.DC, *__restrict__ BD = p.bdelta + (int64_t)a * p.DC;
+        const int2_t *__restrict__ XY = p.xy0 + (int64_t)a * p.DR;
+        const int rd = LINEAR ? 16 : 512;
+        const int tx1 = min(dcols, tx0 + DW_TW) - 1, ty1 = min(drows, ty0 + DW_TH) - 1;
+        const int2_t r0 = XY[ty0], r1 = XY[ty1];
+        const int a0 = AD[tx0], a1 = AD[tx1], b0 = BD[tx0], b1 = BD[tx1];
+        // fixed-point source coordinates of the tile's corner samples.  X0(y) and adelta(x) are both monotone, so the four
+        // corners bound every sample of the tile (one pixel of slack for the rounding of the tables, one more for the
+        // bilinear taps)
+        const int cx[4] = {(r0.x + rd + a0) >> 10, (r0.x + rd + a1) >> 10, (r1.x + rd + a0) >> 10, (r1.x + rd + a1) >> 10};
+        const int cy[4] = {(r0.y + rd + b0) >> 10, (r0.y + rd + b1) >> 10, (r1.y + rd + b0) >> 10, (r1.y + rd + b1) >> 10};
+        const int bx0 = min(min(cx[0], cx[1]), min(cx[2], cx[3])) - 1;
+        const int bx1 = max(max(cx[0], cx[1]), max(cx[2], cx[3])) + 1 + (LINEAR ? 1 : 0);
+        const int by0 = min(min(cy[0], cy[1]), min(cy[2], cy[3])) - 1;
+        const int by1 = max(max(cy[0], cy[1]), max(cy[2], cy[3])) + 1 + (LINEAR ? 1 : 0);
+        const int bb0 = bx0 & ~3, bb1 = (bx1 + 4) & ~3;  // the box in bytes of a source row, widened to whole dwords: [bb0, bb1)
+        const int bwb = bb1 - bb0, bh = by1 - by0 + 1;
+        // (a scan whose rows are not whole aligned dwords -- width, pitch or address not a multiple of 4 -- takes the
+        // unstaged path: the staging loop then has no partial dwords and no branches)
+        const bool dwords = ((p.sstep | p.scan_stride | (int64_t)(uintptr_t)p.src | (int64_t)p.scols) & 3) == 0;
+        const bool staged = dwords && bwb > 0 && bh > 0 && (int64_t)bwb * bh <= DW_LDS && bx0 > -30000 && bx1 < 30000 &&
+                            by0 > -30000 && by1 < 30000;
+        // A tile whose box lies wholly outside the scan (the corners of a CONTAIN canvas: up to a fifth of it at 10 degrees)
+        // is the border value: every tap of every sample is outside, NEAREST takes it as it is and the bilinear weights of
+        // four equal taps sum to 2^15
+        const bool all_border = bx1 < 0 || by1 < 0 || bx0 >= p.scols || by0 >= p.srows;
+        // a box that lies wholly inside the image -- all but the tiles on the scan's edges -- is fetched in 16-byte pieces
+        // (rows padded to a multiple of 16 bytes in LDS; the padding stays inside the image row too): a quarter of the
+        // DMA instructions.  Bit 30 of bh says so.
+        const int bwb16 = (bwb + 15) & ~15;
+        const bool x4 = staged && bb0 >= 0 && by0 >= 0 && by0 + bh <= p.srows && bb0 + bwb16 <= p.scols && (int64_t)bwb16 * bh <= DW_LDS;
+        r.a = a, r.bb0 = bb0, r.by0 = by0;
+        r.bwb = all_border ? 0 : x4 ? bwb16 : staged ? bwb : -1;  // the box's pitch in LDS; -1: taps from global memory
+        r.bh = bh | (x4 ? 1 << 30 : 0), r.a1 = a1, r.b1 = b1, r.last = tx1 | (ty1 << 16);
+    }
+    tiles[(int64_t)z * ntx * nty + t] = r;
+}
+
 // grid = (tiles across the largest canvas, tiles down it, scans of the launch); a tile outside its scan's canvas
 // leaves at once.  (Scans fastest instead -- XCD x warps only scan x, so overlapping boxes meet in one L2 -- halves the
 // HBM fetch, 71.8 -> 34.3 MB per 8 scans = the scans' own bytes, but is no faster: 65 / 114 us against 66 / 105.  The
@@ -53,60 +125,53 @@ __device__ __forceinline__ int dw_tap_global(const uint8_t *__restrict__ src, in
 // 32 KB of LDS per workgroup.)  The source bounding box of a tile (four corner samples; one pixel of slack for the rounding of
 // the fixed-point tables, one more for the bilinear taps) is staged in LDS with row-contiguous dword loads, border
 // value outside the image, so a tap is one LDS byte read with no bounds test.  The kernel is a chain of dependent
-// memory round trips (winner -> canvas size -> table entries of the corners -> box -> taps), so everything that
-// does not depend on the box -- the thread's own column and row table entries -- is requested before the box is.
+// memory round trips (tile record -> {table entries, box} -> taps): everything that depends on (scan, tile) alone was
+// worked out by deskew_tiles_kernel, and the thread's own column and row table entries are requested with the box.
 template <bool LINEAR>
 // (forcing more waves per SIMD was measured and lost: __launch_bounds__(256, 6) spills, 127 / 126 us per 8 A4 scans
 // against 62 / 104 at the compiler's own 100 / 92 VGPRs)
-__global__ __launch_bounds__(256) void deskew_warp_kernel(const DeskewPass p)
+#ifndef DW_MIN_BLOCKS
+#define DW_MIN_BLOCKS 8
+#endif
+__global__ __launch_bounds__(256, DW_MIN_BLOCKS) void deskew_warp_kernel(const DeskewPass p, const DeskewTile *__restrict__ tiles)
 {
     __shared__ __attribute__((aligned(16))) uint8_t box[DW_LDS];
-    const int z = blockIdx.z;
-    const int a = __builtin_amdgcn_readfirstlane(p.best[z]);
-    const int drows = p.wsize[2 * a], dcols = p.wsize[2 * a + 1];
-    const int tx0 = blockIdx.x * DW_TW, ty0 = blockIdx.y * DW_TH;
-    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && p.out_size) {
-        p.out_size[2 * z] = drows;
-        p.out_size[2 * z + 1] = dcols;
+    // grid = (scans, tiles across, tiles down), scans fastest: workgroup ids go round-robin to the 8 XCDs, so XCD x warps the
+    // scans x, x + 8, .. only and the overlapping boxes of a scan's neighbouring tiles meet in ONE L2 (with tiles fastest every
+    // L2 saw every eighth tile of a row and each box was fetched from memory in full: 2 x the scans' bytes)
+    // (p.order = 0: tiles fastest, grid = (tiles across, tiles down, scans); 1: scans fastest; 2: a 1-D grid in which XCD k --
+    // workgroup ids go round-robin to the 8 XCDs -- warps the tile ROWS k, k + 8, .. of every scan, left to right: the
+    // overlapping boxes of a row's neighbouring tiles meet in one L2, and every XCD has the same share of every scan)
+    int z, txi, tyi, ntx, nty;
+    if (p.order == 2) {
+        ntx = p.ntx, nty = p.nty;
+        const int nty8 = (nty + 7) >> 3, xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+        txi = j % ntx;
+        const int q = j / ntx, r = q % nty8;
+        z = q / nty8, tyi = r * 8 + xcd;
+        if (tyi >= nty) return;
+    } else {
+        z = p.order ? blockIdx.x : blockIdx.z, txi = p.order ? blockIdx.y : blockIdx.x, tyi = p.order ? blockIdx.z : blockIdx.y;
+        ntx = p.order ? gridDim.y : gridDim.x, nty = p.order ? gridDim.z : gridDim.y;
     }
-    if (tx0 >= dcols || ty0 >= drows) return;
+    // the tile's record: wave-uniform, fetched by the scalar unit
+    const DeskewTile *__restrict__ tr = tiles + ((int64_t)z * nty + tyi) * ntx + txi;
+    const int a = tr->a;
+    if (a < 0) return;  // outside this scan's canvas
+    const int bb0 = tr->bb0, by0 = tr->by0, bwb_rec = tr->bwb, bh_rec = tr->bh, a1 = tr->a1, b1 = tr->b1, last = tr->last;
+    const int bh = bh_rec & 0xffff;
+    const bool x4 = (bh_rec >> 30) & 1;  // the box is wholly inside the image: 16-byte pieces
+    const int tx0 = txi * DW_TW, ty0 = tyi * DW_TH;
+    const int tx1 = last & 0xffff, ty1 = last >> 16;
+    const int dcols = tx1 + 1, drows = ty1 + 1;  // as far as this tile can tell: enough for every test below
     const uint8_t *__restrict__ src = p.src + (int64_t)z * p.scan_stride;
     uint8_t *__restrict__ dst = p.dst + (int64_t)z * p.out_stride;
     const int32_t *__restrict__ AD = p.adelta + (int64_t)a * p.DC, *__restrict__ BD = p.bdelta + (int64_t)a * p.DC;
     const int2_t *__restrict__ XY = p.xy0 + (int64_t)a * p.DR;
     const int rd = LINEAR ? 16 : 512;
-    const int tx1 = min(dcols, tx0 + DW_TW) - 1, ty1 = min(drows, ty0 + DW_TH) - 1;
-    // ---- requests that need nothing but the tile position: the corners' and this thread's table entries
-    const int2_t r0 = XY[ty0], r1 = XY[ty1];
-    const int a0 = AD[tx0], a1 = AD[tx1], b0 = BD[tx0], b1 = BD[tx1];
     const int lx = (threadIdx.x & 31) * 4, x0 = tx0 + lx, yq = ty0 + (threadIdx.x >> 5);
-    const int xl = min(x0, p.DC - 4);  // DC is a multiple of 4 and the tables are 16-byte aligned
-    const int4 ad = *(const int4 *)(AD + xl), bd = *(const int4 *)(BD + xl);
-    // (rows past the tile's last one repeat it and columns past its last one repeat that column below: every sample a
-    // thread computes then lies inside the tile's box, stored or not, and a tap needs no bounds test)
-    int2_t rows[DW_TH / 8];
-#pragma unroll
-    for (int k = 0; k < DW_TH / 8; k++) rows[k] = XY[min(yq + 8 * k, ty1)];
-    // ---- the box: fixed-point source coordinates of the tile's corner samples (wave-uniform).  X0(y) and
-    // adelta(x) are both monotone, so the four corners bound every sample of the tile.
-    const int cx[4] = {(r0.x + rd + a0) >> 10, (r0.x + rd + a1) >> 10, (r1.x + rd + a0) >> 10, (r1.x + rd + a1) >> 10};
-    const int cy[4] = {(r0.y + rd + b0) >> 10, (r0.y + rd + b1) >> 10, (r1.y + rd + b0) >> 10, (r1.y + rd + b1) >> 10};
-    const int bx0 = min(min(cx[0], cx[1]), min(cx[2], cx[3])) - 1;
-    const int bx1 = max(max(cx[0], cx[1]), max(cx[2], cx[3])) + 1 + (LINEAR ? 1 : 0);
-    const int by0 = min(min(cy[0], cy[1]), min(cy[2], cy[3])) - 1;
-    const int by1 = max(max(cy[0], cy[1]), max(cy[2], cy[3])) + 1 + (LINEAR ? 1 : 0);
-    const int bb0 = bx0 & ~3, bb1 = (bx1 + 4) & ~3;  // the box in bytes of a source row, widened to whole dwords: [bb0, bb1)
-    const int bwb = bb1 - bb0, bh = by1 - by0 + 1;
-    // (a scan whose rows are not whole aligned dwords -- width, pitch or address not a multiple of 4 -- takes the
-    // unstaged path below: the staging loop then has no partial dwords and no branches)
-    const bool dwords = ((p.sstep | p.scan_stride | (int64_t)(uintptr_t)p.src | (int64_t)p.scols) & 3) == 0;
-    const bool staged = dwords && bwb > 0 && bh > 0 && (int64_t)bwb * bh <= DW_LDS && bx0 > -30000 && bx1 < 30000 &&
-                        by0 > -30000 && by1 < 30000;
     const uint32_t border4 = (uint32_t)p.border * 0x01010101u;
-    // A tile whose box lies wholly outside the scan (the corners of a CONTAIN canvas: up to a fifth of it at 10 degrees) is
-    // the border value: every tap of every sample is outside, NEAREST takes it as it is and the bilinear weights of four
-    // equal taps sum to 2^15.  Workgroup-uniform: the four corners bound every sample of the tile.
-    if (bx1 < 0 || by1 < 0 || bx0 >= p.scols || by0 >= p.srows) {
+    if (bwb_rec == 0) {  // every tap of the tile is border (workgroup-uniform)
         if (x0 >= dcols) return;
         const bool whole4 = x0 + 4 <= dcols && ((p.dstep | p.out_stride | (int64_t)(uintptr_t)p.dst) & 3) == 0;
 #pragma unroll
@@ -120,38 +185,97 @@ __global__ __launch_bounds__(256) void deskew_warp_kernel(const DeskewPass p)
         }
         return;
     }
+    const bool staged = bwb_rec > 0;
+    const int bwb = staged ? bwb_rec : 4;
+    // ---- the thread's own column and row table entries: requested together with the box, they depend on the record only
+    const int xl = min(x0, p.DC - 4);  // DC is a multiple of 4 and the tables are 16-byte aligned
+    const int4 ad = *(const int4 *)(AD + xl), bd = *(const int4 *)(BD + xl);
+    // (rows past the tile's last one repeat it and columns past its last one repeat that column below: every sample a
+    // thread computes then lies inside the tile's box, stored or not, and a tap needs no bounds test)
+    // the tile's row table entries travel through LDS (thread t brings row ty0 + t): one load per thread instead of DW_TH / 8,
+    // and no registers hold them while the box is in flight
+    __shared__ int2_t rowtab[DW_TH];
+    static_assert(DW_TH_NN <= 256 && DW_TH_LIN <= 256, "one thread per row of the tile brings its table entry");
+    if (threadIdx.x < DW_TH) rowtab[threadIdx.x] = XY[min(ty0 + (int)threadIdx.x, ty1)];
     if (staged) {
-        // the box as dwords, thread t takes dwords t, t + 256, ..: ALL loads are issued before the first LDS write, and
-        // every one of them unconditionally (a dword outside the image reads the scan's first dword and is replaced by
-        // the border value afterwards) -- a load inside a divergent branch is waited for before the next is issued, a
-        // memory round trip per dword.  (row, dword in row) of a thread's next piece follows from the previous one
-        // without a division.  (Skipping the pieces a small box does not need -- a 128 x 32 tile at 5 degrees needs 7 of the
-        // 16 -- by a scalar branch per piece was measured in the bench: 5.4 k deskewed images/s against 10.1 k; the branches
-        // serialise the loads just like divergent ones.)
+        // the box as dwords, thread t takes dwords t, t + 256, ..: LDS-DMA (`buffer_load_dword ... lds`: the 64 lanes of a
+        // wave-instruction write 64 consecutive dwords of the box, each from its own offset into the scan) -- no registers
+        // hold the box on its way (round 4 kept 16 dwords and 16 flags per thread across the round trip: 91 VGPRs, five
+        // workgroups per CU), no ds_write instructions, and every load of the tile is in flight at once.  The scan is a raw
+        // buffer: an offset outside it (a box that pokes out above or below the image; dwords past the box's end) lands as
+        // zeros.  A box that is not wholly inside the image is patched afterwards (workgroup-uniform branch, tiles on the
+        // scan's edges only): dwords outside the image become the border value -- those read through the row pitch into the
+        // neighbouring row included.  (row, dword in row) of a thread's next piece follows from the previous one without a
+        // division; ONE branch on the (workgroup-uniform) size of the box selects among three straight-line versions.
         constexpr int NP = DW_LDS / 4 / 256;  // 16 pieces per thread at most
         const int bq = bwb >> 2, total = bq * bh;
         const int dq = 256 / bq, dr = 256 - dq * bq;  // 256 = dq * bq + dr
-        // ... but ONE branch on the (workgroup-uniform) size of the box, in front of three straight-line versions (8, 12, 16
-        // pieces), costs nothing: most LINEAR tiles of a small-angle warp need at most half the pieces (+1.8 % deskewed
-        // images/s in the bench)
+        const uint64_t sb = (uint64_t)src;
+        const uint32_t nbytes = (uint32_t)min((int64_t)0xfffffff0ll, (int64_t)p.srows * p.sstep);
+        uint32_t rs[4] = {(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)sb),
+                          (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(sb >> 32) & 0xffffu),
+                          (uint32_t)__builtin_amdgcn_readfirstlane(nbytes), 0x00020000u};
+        typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+        const v4u rsrc = {rs[0], rs[1], rs[2], rs[3]};
+        const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t *)box +
+                              (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) * 256u;  // this wave's 64 dwords of a piece
+        const bool inside = bb0 >= 0 && bb0 + bwb <= p.scols && by0 >= 0 && by0 + bh <= p.srows;
         auto stage = [&](auto np_tag) {
             constexpr int NPV = decltype(np_tag)::value;
             int ly = (int)threadIdx.x / bq, lq = (int)threadIdx.x - ly * bq;
-            uint32_t v[NPV];
-            bool in[NPV];
 #pragma unroll
             for (int n = 0; n < NPV; n++) {
                 const int gy = by0 + ly, gb = bb0 + lq * 4;
-                in[n] = (int)threadIdx.x + n * 256 < total && (unsigned)gy < (unsigned)p.srows && (unsigned)gb < (unsigned)p.scols;
-                v[n] = *(const uint32_t *)(src + (in[n] ? (int64_t)gy * p.sstep + gb : 0));
+                // (a negative row or a piece past the box: an offset no buffer of less than 4 GB contains)
+                const uint32_t voff = ((int)threadIdx.x + n * 256 < total && gy >= 0) ? (uint32_t)(gy * (int)p.sstep + gb) : 0xfffffff0u;
+                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, 0 offen lds"
+                             :
+                             : "s"(lds0 + (uint32_t)n * 1024u), "v"(voff), "s"(rsrc)
+                             : "memory", "m0");
                 ly += dq, lq += dr;
                 if (lq >= bq) lq -= bq, ly++;
             }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (!inside) {  // workgroup-uniform
+                __syncthreads();
+                ly = (int)threadIdx.x / bq, lq = (int)threadIdx.x - ly * bq;
 #pragma unroll
-            for (int n = 0; n < NPV; n++)
-                if ((int)threadIdx.x + n * 256 < total) *(uint32_t *)&box[((int)threadIdx.x + n * 256) * 4] = in[n] ? v[n] : border4;
+                for (int n = 0; n < NPV; n++) {
+                    const int gy = by0 + ly, gb = bb0 + lq * 4;
+                    if ((int)threadIdx.x + n * 256 < total && !((unsigned)gy < (unsigned)p.srows && (unsigned)gb < (unsigned)p.scols))
+                        *(uint32_t *)&box[((int)threadIdx.x + n * 256) * 4] = border4;
+                    ly += dq, lq += dr;
+                    if (lq >= bq) lq -= bq, ly++;
+                }
+            }
         };
-        if (total <= (NP / 2) * 256) stage(std::integral_constant<int, NP / 2>{});
+        // 16-byte pieces (buffer_load_dwordx4 ... lds: lane L writes M0 + 16 L) for a box wholly inside the image
+        auto stage16 = [&](auto np_tag) {
+            constexpr int NPV = decltype(np_tag)::value;
+            const int bq4 = bwb >> 4, total4 = bq4 * bh;
+            const int dq4 = 256 / bq4, dr4 = 256 - dq4 * bq4;
+            int ly = (int)threadIdx.x / bq4, lq = (int)threadIdx.x - ly * bq4;
+            const uint32_t lds16 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t *)box +
+                                   (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) * 1024u;
+#pragma unroll
+            for (int n = 0; n < NPV; n++) {
+                const uint32_t voff = (int)threadIdx.x + n * 256 < total4 ? (uint32_t)((by0 + ly) * (int)p.sstep + bb0 + lq * 16) : 0xfffffff0u;
+                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
+                             :
+                             : "s"(lds16 + (uint32_t)n * 4096u), "v"(voff), "s"(rsrc)
+                             : "memory", "m0");
+                ly += dq4, lq += dr4;
+                if (lq >= bq4) lq -= bq4, ly++;
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        };
+        if (x4) {
+            constexpr int NP4 = DW_LDS / 16 / 256;  // 16-byte pieces per thread at most
+            const int total4 = (bwb >> 4) * bh;
+            if (total4 <= (NP4 / 2) * 256) stage16(std::integral_constant<int, NP4 / 2>{});
+            else if (total4 <= (3 * NP4 / 4) * 256) stage16(std::integral_constant<int, 3 * NP4 / 4>{});
+            else stage16(std::integral_constant<int, NP4>{});
+        } else if (total <= (NP / 2) * 256) stage(std::integral_constant<int, NP / 2>{});
         else if (total <= (3 * NP / 4) * 256) stage(std::integral_constant<int, 3 * NP / 4>{});
         else stage(std::integral_constant<int, NP>{});
     }
@@ -170,8 +294,8 @@ __global__ __launch_bounds__(256) void deskew_warp_kernel(const DeskewPass p)
             if (y >= drows) break;
             uint8_t *D = dst + (int64_t)y * p.dstep + x0;
             for (int j = 0; j < 4 && x0 + j < dcols; j++)
-                D[j] = (uint8_t)dw_tap_global<LINEAR>(src, p.sstep, p.srows, p.scols, rows[k].x + rd + adv[j], rows[k].y + rd + bdv[j],
-                                                      p.border);
+                D[j] = (uint8_t)dw_tap_global<LINEAR>(src, p.sstep, p.srows, p.scols, rowtab[y - ty0].x + rd + adv[j],
+                                                      rowtab[y - ty0].y + rd + bdv[j], p.border);
         }
         return;
     }
@@ -179,52 +303,95 @@ __global__ __launch_bounds__(256) void deskew_warp_kernel(const DeskewPass p)
     // bits stay; |coordinates| < 30000 pixels, so nothing overflows).  Straight-line: the 16 / 32 pixels' taps are all requested before the first is blended,
     // and nothing below is conditional except the last tile column's byte stores -- a row past the tile's last one
     // recomputes that row's pixels (its table entry was clamped) and stores them there again, the same bytes.
+    // The box's origin rides on the thread's column entries (multiples of 1024: the fraction bits stay; |coordinates| <
+    // 30000 pixels, so nothing overflows): a sample is two additions, two shifts and one multiply-add away from its LDS byte.
     const int orgx = rd - (bb0 << 10), orgy = rd - (by0 << 10);
-    uint32_t outs[DW_TH / 8];
 #pragma unroll
-    for (int k = 0; k < DW_TH / 8; k++) {
-        const int X0 = rows[k].x + orgx, Y0 = rows[k].y + orgy;
-        uint32_t out = 0;
+    for (int j = 0; j < 4; j++) adv[j] += orgx, bdv[j] += orgy;
+    // stores: 32-bit offsets from the scan's canvas (a canvas is far below 4 GB); a tile whose every thread stores whole
+    // aligned dwords -- all but the canvas's last tile column, or an unaligned canvas -- has no per-lane store branches
+    const uint32_t dstep32 = (uint32_t)p.dstep;
+    const bool aligned4 = ((p.dstep | p.out_stride | (int64_t)(uintptr_t)p.dst) & 3) == 0 && p.dstep < (1 << 24) &&
+                          (int64_t)p.DR * p.dstep < (int64_t)0x7fffffff;
+    const bool tile_whole = aligned4 && tx0 + DW_TW <= dcols;  // workgroup-uniform
+    const bool whole = aligned4 && x0 + 4 <= dcols;
+    const int rt0 = (int)(threadIdx.x >> 5);  // this thread's first row of the tile; rowtab is clamped to the tile's last row
+    // DW_KU rows of four pixels at a time: their taps are all requested before the first is blended; the loop over the
+    // groups is NOT unrolled (with all 8 rows in flight the kernel needed 104 VGPRs: four workgroups per CU)
+    constexpr int DW_KU = LINEAR ? 2 : 4;
+#pragma unroll 1
+    for (int k0 = 0; k0 < DW_TH / 8; k0 += DW_KU) {
+        uint32_t outs[DW_KU];
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const int Xf = X0 + adv[j], Yf = Y0 + bdv[j];
-            const int idx = dw_mad24(Yf >> 10, bwb, Xf >> 10);
-            int v;
-            if (!LINEAR) {
-                v = box[idx];
-            } else {
-                // ((v0 w0 + v1 w1 + v2 w2 + v3 w3 + 2^14) >> 15 with w = 32 (32 - fy)(32 - fx), ..) as two horizontal
-                // blends and a vertical one: the same integer, and <= 255 without a clamp
-                const int fx = (Xf >> 5) & 31, fy = (Yf >> 5) & 31;
-                const uint8_t *B = &box[idx];
-                const int b0 = B[0], b1 = B[1], b2 = B[bwb], b3 = B[bwb + 1];
-                const int top = dw_mad24(fx, b1 - b0, b0 << 5), bot = dw_mad24(fx, b3 - b2, b2 << 5);
-                v = dw_mad24(fy, bot - top, (top << 5) + 512) >> 10;
+        for (int kk = 0; kk < DW_KU; kk++) {
+            const int2_t rw = rowtab[rt0 + 8 * (k0 + kk)];
+            uint32_t bts[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int Xf = rw.x + adv[j], Yf = rw.y + bdv[j];
+                const int idx = dw_mad24(Yf >> 10, bwb, Xf >> 10);
+                if (!LINEAR) {
+                    bts[j] = box[idx];
+                } else {
+                    // ((v0 w0 + v1 w1 + v2 w2 + v3 w3 + 2^14) >> 15 with w = 32 (32 - fy)(32 - fx), ..) as two horizontal
+                    // blends and a vertical one: the same integer, and <= 255 without a clamp
+                    const int fx = (Xf >> 5) & 31, fy = (Yf >> 5) & 31;
+                    const uint8_t *B = &box[idx];
+                    const int b0 = B[0], b1 = B[1], b2 = B[bwb], b3 = B[bwb + 1];
+                    const int top = dw_mad24(fx, b1 - b0, b0 << 5), bot = dw_mad24(fx, b3 - b2, b2 << 5);
+                    bts[j] = (uint32_t)(dw_mad24(fy, bot - top, (top << 5) + 512) >> 10);
+                }
             }
-            out |= (uint32_t)v << (8 * j);
+            // four bytes, each < 256 in a register of its own -> one dword: three v_lshl_or
+            outs[kk] = ((bts[1] << 8) | bts[0]) | (((bts[3] << 8) | bts[2]) << 16);
         }
-        outs[k] = out;
-    }
-    const bool whole = x0 + 4 <= dcols && ((p.dstep | p.out_stride | (int64_t)(uintptr_t)p.dst) & 3) == 0;
 #pragma unroll
-    for (int k = 0; k < DW_TH / 8; k++) {
-        uint8_t *D = dst + (int64_t)min(yq + 8 * k, ty1) * p.dstep + x0;
-        if (whole) {
-            *(uint32_t *)D = outs[k];
-        } else {
-            for (int j = 0; j < 4 && x0 + j < dcols; j++) D[j] = (uint8_t)(outs[k] >> (8 * j));
+        for (int kk = 0; kk < DW_KU; kk++) {
+            // a row past the tile's last one recomputed that row's pixels (rowtab is clamped) and stores them there again
+            const uint32_t off = (uint32_t)__mul24(min(yq + 8 * (k0 + kk), ty1), (int)dstep32) + (uint32_t)x0;
+            if (tile_whole) {
+                *(uint32_t *)(dst + off) = outs[kk];
+            } else if (whole) {
+                *(uint32_t *)(dst + off) = outs[kk];
+            } else {
+                uint8_t *D = dst + (int64_t)min(yq + 8 * (k0 + kk), ty1) * p.dstep + x0;
+                for (int j = 0; j < 4 && x0 + j < dcols; j++) D[j] = (uint8_t)(outs[kk] >> (8 * j));
+            }
         }
     }
 }
 
-hipError_t launch_deskew_warp(const DeskewPass &p, int scans, int interp, hipStream_t s)
+size_t deskew_tile_bytes(const DeskewPass &p, int scans)
+{
+    // (tiles of the LINEAR kernel: the smaller tile, so the buffer serves both)
+    constexpr int th = DW_TH_LIN < DW_TH_NN ? DW_TH_LIN : DW_TH_NN;
+    return sizeof(DeskewTile) * (size_t)((p.DC + DW_TW - 1) / DW_TW) * (size_t)((p.DR + th - 1) / th) * (size_t)scans;
+}
+
+hipError_t launch_deskew_warp(const DeskewPass &p0, int scans, int interp, void *d_tiles, hipStream_t s)
 {
     if (scans <= 0) return hipSuccess;
-    if ((p.DC & 3) != 0) return hipErrorInvalidValue;
-    const bool LINEAR = interp != 0;
-    dim3 grid((p.DC + DW_TW - 1) / DW_TW, (p.DR + DW_TH - 1) / DW_TH, scans);
-    if (interp == 0) hipLaunchKernelGGL(deskew_warp_kernel<false>, grid, dim3(256), 0, s, p);
-    else hipLaunchKernelGGL(deskew_warp_kernel<true>, grid, dim3(256), 0, s, p);
+    DeskewPass p = p0;
+#ifdef DW_ORDER
+    p.order = DW_ORDER;
+#else
+    p.order = 2;
+#endif
+    if ((p.DC & 3) != 0 || !d_tiles) return hipErrorInvalidValue;
+    DeskewTile *tiles = (DeskewTile *)d_tiles;
+    if (interp == 0) {
+        constexpr bool LINEAR = false;
+        const int ntx = (p.DC + DW_TW - 1) / DW_TW, nty = (p.DR + DW_TH - 1) / DW_TH;
+        hipLaunchKernelGGL(deskew_tiles_kernel<false>, dim3((ntx * nty + 63) / 64, scans), dim3(64), 0, s, p, tiles, ntx, nty);
+        p.ntx = ntx, p.nty = nty;
+        hipLaunchKernelGGL(deskew_warp_kernel<false>, p.order == 2 ? dim3(8 * ntx * ((nty + 7) / 8) * scans) : p.order ? dim3(scans, ntx, nty) : dim3(ntx, nty, scans), dim3(256), 0, s, p, tiles);
+    } else {
+        constexpr bool LINEAR = true;
+        const int ntx = (p.DC + DW_TW - 1) / DW_TW, nty = (p.DR + DW_TH - 1) / DW_TH;
+        hipLaunchKernelGGL(deskew_tiles_kernel<true>, dim3((ntx * nty + 63) / 64, scans), dim3(64), 0, s, p, tiles, ntx, nty);
+        p.ntx = ntx, p.nty = nty;
+        hipLaunchKernelGGL(deskew_warp_kernel<true>, p.order == 2 ? dim3(8 * ntx * ((nty + 7) / 8) * scans) : p.order ? dim3(scans, ntx, nty) : dim3(ntx, nty, scans), dim3(256), 0, s, p, tiles);
+    }
     return hipGetLastError();
 }
 

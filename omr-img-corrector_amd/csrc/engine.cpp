@@ -1115,7 +1115,19 @@ int batch_run(omr_batch_ctx *ctx, const uint8_t *d_scans, int64_t scan_stride, i
             p.DR = ctx->dk_rows;
             p.border = dk->border;
             p.out_size = dk->d_out_size ? dk->d_out_size + 2 * (size_t)i : nullptr;
-            OMR_HIP(launch_deskew_warp(p, z, dk->interp, ctx->post_streams[k]));
+            // the per-tile records: one buffer per post stream (the warps of a stream run one after the other)
+            if (ctx->dk_tiles.size() < ctx->post_streams.size()) ctx->dk_tiles.resize(ctx->post_streams.size());
+            if (!ctx->dk_tiles[(size_t)k]) ctx->dk_tiles[(size_t)k].reset(new DevBuf);
+            {
+                const size_t need = deskew_tile_bytes(p, lanes ? ctx->lanes : ctx->group);
+                if (ctx->dk_tiles[(size_t)k]->bytes < need) {
+                    NoPoolScope ctx_owned;
+                    OMR_HIP(hipStreamSynchronize(ctx->post_streams[k]));
+                    ctx->dk_tiles[(size_t)k]->release();
+                    OMR_HIP(ctx->dk_tiles[(size_t)k]->alloc(need));
+                }
+            }
+            OMR_HIP(launch_deskew_warp(p, z, dk->interp, ctx->dk_tiles[(size_t)k]->p, ctx->post_streams[k]));
         }
         if (hipEventRecord(ctx->ev_post[set], ctx->post_streams[k]) != hipSuccess)
             return fail(OMR_ERR_GPU, "hipEventRecord failed");

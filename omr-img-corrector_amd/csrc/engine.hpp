@@ -222,6 +222,7 @@ struct omr_batch_ctx {
     bool dk_built = false;
     int dk_rows = 0, dk_cols = 0;  // largest canvas (cols rounded up to 4)
     omr::DevBuf dk_size, dk_adelta, dk_bdelta, dk_xy0;
+    std::vector<std::unique_ptr<omr::DevBuf>> dk_tiles;  // per post stream: the warp's per-tile records (deskew.hip)
     std::mutex mu;
     std::mutex guard_mu;  // omr_batch_sync is called with and without `mu` held: the guard flags have a lock of their own
     ~omr_batch_ctx();

@@ -174,8 +174,11 @@ struct DeskewPass {
     int32_t DC, DR;           // largest canvas over the candidates (DC a multiple of 4)
     int32_t border;           // border value (0..255)
     int32_t *out_size;        // [scans][2] canvas rows, cols of every scan (device), or null
+    int32_t order, ntx, nty;  // (set by launch_deskew_warp) the workgroup order and the tiles across / down the largest canvas
 };
-hipError_t launch_deskew_warp(const DeskewPass &p, int scans, int interp, hipStream_t s);
+// d_tiles: deskew_tile_bytes(p, scans) bytes of scratch (the per-tile records made by the launch's first kernel)
+size_t deskew_tile_bytes(const DeskewPass &p, int scans);
+hipError_t launch_deskew_warp(const DeskewPass &p, int scans, int interp, void *d_tiles, hipStream_t s);
 
 // ---- tuned single-channel stage kernels (stages.hip); each falls back to the generic form -------
 hipError_t launch_rgb2gray_fast(const uint8_t *d_src, int64_t sstep, int rows, int cols, int cn, uint8_t *d_dst,

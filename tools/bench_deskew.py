@@ -1,7 +1,7 @@
 """The batch warp on its own (development aid): 8 A4 scans per launch, the batch context synchronised after every
 call so that no sweep of a following group shares the chip with the warp.  Run under
 `rocprofv3 --kernel-trace --stats` to read deskew_warp_kernel's duration; prints the wall-clock figures.
-Usage: python tools/bench_deskew.py [reps]"""
+Usage: python tools/bench_deskew.py [reps] [scans per launch, default 8]"""
 import os
 import sys
 import time
@@ -15,12 +15,14 @@ import torch
 from oics import projection, synth
 
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 10
-ROWS, COLS, G = 3508, 2480, 8
-cards = [synth.make_card(ROWS, COLS, 3 + i)[0] for i in range(G)]
+ROWS, COLS = 3508, 2480
+G = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+base = [synth.make_card(ROWS, COLS, 3 + i)[0] for i in range(8)]
+cards = [base[i % 8] for i in range(G)]
 dev = torch.device("cuda:0")
 scans = torch.from_numpy(np.stack(cards)).to(dev)
 b = projection.Batch(ROWS, COLS, 10, 0.05, n_streams=1)
-b.set_group(G)
+b.set_group(G) if G <= 64 else b.set_lanes(G)
 dr, dc = b.deskew_canvas()
 out = torch.empty((G, dr, dc), dtype=torch.uint8, device=dev)
 size = torch.zeros((G, 2), dtype=torch.int32, device=dev)
