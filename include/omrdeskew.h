@@ -265,7 +265,9 @@ int omr_host_batch_run(omr_host_batch *hb, const omr_image *scans, int32_t n, in
 int omr_host_batch_set_launch(omr_host_batch *hb, int32_t scans_per_launch);
 
 /* Host-buffer batch over the visible devices (SURVEY.md 8b `omr_sweep_batch`): scans[i] goes
- * to device i % n_devices (an omr_host_batch made for this one call: plan and ring creation are inside the call; packed transfers);
+ * to device i % n_devices (an omr_host_batch made for this one call: plan and ring creation are inside the call; packed transfers).
+ * The scans may have DIFFERENT shapes (the reference corrects one file per call, any size, task.rs:19-38): they are bucketed by
+ * (rows, cols), one context per shape, and the results land at the scans' own positions;
  * the only "collective" is the host-side gather of the results.  n_devices <= 0 = every visible device;
  * n_devices > omr_device_count() is OMR_ERR_BADARG (never a silent clamp).
  * best_angle[i] = (best_idx[i] - N) * step (projection.rs:189-190). */

@@ -1223,7 +1223,7 @@ int omr_batch_set_group(omr_batch_ctx *ctx, int32_t scans_per_launch)
 }
 
 // Scan-lane sweep for this context: up to max_scans_per_launch scans per launch (rounded up to whole groups of 64),
-// 64 scans per wavefront.  Builds every strip's program on the host's cores and uploads them (once); 0 switches back
+// 64 scans per wavefront.  Generates every strip's program ON THE DEVICE (slane_build.hip; once per context); 0 switches back
 // to the run-merging path.  OMR_ERR_NOTIMPL (and the context unchanged) when a candidate does not fit the scheme.
 int omr_batch_set_lanes(omr_batch_ctx *ctx, int32_t max_scans_per_launch)
 {

@@ -786,19 +786,60 @@ int omr_get_standard_deviation(const double *v, size_t n, double *out)
     return OMR_OK;
 }
 
-// Host-buffer batch over the visible devices: omr_host_batch (oics_hostbatch.cpp) made for this one call.
+// Host-buffer batch over the visible devices: an omr_host_batch (oics_hostbatch.cpp) made for this one call -- one per SHAPE:
+// the reference corrects one file per call, any size (app/src-tauri/src/task.rs:19-38; its own dataset holds two shapes,
+// 1240x1150 and ~1237x1300), so a batch may mix shapes.  The scans are bucketed by (rows, cols), every bucket is swept with a
+// context of its own (plan, ring, stages), and the results land at the scans' original positions.
 int omr_sweep_batch(const omr_image *scans, int32_t n, uint16_t max_angle, double step, int32_t n_devices,
                     int32_t *best_idx, double *best_angle, double *v_sd_opt, double *h_sd_opt)
 {
     if (!scans || n < 0 || !best_idx) return fail(OMR_ERR_BADARG, "bad batch arguments");
     if (n == 0) return OMR_OK;
-    int rc = check_image(&scans[0], true);
-    if (rc) return rc;
-    omr_host_batch *hb = nullptr;
-    if ((rc = omr_host_batch_create(scans[0].rows, scans[0].cols, max_angle, step, n_devices, n, &hb))) return rc;
-    rc = omr_host_batch_run(hb, scans, n, OMR_HOST_PACKED, best_idx, best_angle, v_sd_opt, h_sd_opt);
-    omr_host_batch_destroy(hb);
-    return rc;
+    int N = 0;
+    const int A = candidate_count(max_angle, step, &N);
+    if (A <= 0) return fail(OMR_ERR_BADARG, "empty candidate range");
+    std::vector<std::pair<int, int>> shapes;  // in order of first appearance
+    std::vector<std::vector<int>> members;
+    for (int i = 0; i < n; i++) {
+        int rc = check_image(&scans[i], true);
+        if (rc) return rc;
+        const std::pair<int, int> sh(scans[i].rows, scans[i].cols);
+        size_t k = 0;
+        while (k < shapes.size() && shapes[k] != sh) k++;
+        if (k == shapes.size()) {
+            shapes.push_back(sh);
+            members.emplace_back();
+        }
+        members[k].push_back(i);
+    }
+    const bool one = shapes.size() == 1;
+    for (size_t k = 0; k < shapes.size(); k++) {
+        const std::vector<int> &idx = members[k];
+        const int m = (int)idx.size();
+        omr_host_batch *hb = nullptr;
+        int rc = omr_host_batch_create(shapes[k].first, shapes[k].second, max_angle, step, n_devices, m, &hb);
+        if (rc) return rc;
+        if (one) {
+            rc = omr_host_batch_run(hb, scans, n, OMR_HOST_PACKED, best_idx, best_angle, v_sd_opt, h_sd_opt);
+        } else {
+            std::vector<omr_image> sub((size_t)m);
+            std::vector<int32_t> b((size_t)m);
+            std::vector<double> ang((size_t)m), vs(v_sd_opt ? (size_t)m * A : 0), hs(h_sd_opt ? (size_t)m * A : 0);
+            for (int j = 0; j < m; j++) sub[(size_t)j] = scans[idx[(size_t)j]];
+            rc = omr_host_batch_run(hb, sub.data(), m, OMR_HOST_PACKED, b.data(), ang.data(), v_sd_opt ? vs.data() : nullptr,
+                                    h_sd_opt ? hs.data() : nullptr);
+            for (int j = 0; j < m && rc == OMR_OK; j++) {
+                const int i = idx[(size_t)j];
+                best_idx[i] = b[(size_t)j];
+                if (best_angle) best_angle[i] = ang[(size_t)j];
+                if (v_sd_opt) memcpy(v_sd_opt + (size_t)i * A, vs.data() + (size_t)j * A, sizeof(double) * (size_t)A);
+                if (h_sd_opt) memcpy(h_sd_opt + (size_t)i * A, hs.data() + (size_t)j * A, sizeof(double) * (size_t)A);
+            }
+        }
+        omr_host_batch_destroy(hb);
+        if (rc) return rc;
+    }
+    return OMR_OK;
 }
 
 }  // extern "C"

@@ -35,6 +35,7 @@
 //                                   shift), the first pk of a word also carries its segment count n << 26 (n >= 1) and bit 31 when n <= 4
 //                S = 2 / 4 / 8 slots per word laid out (4 / 8 / 16 dwords per row), 2 .. 8 executed, chosen per strip
 #pragma once
+#include <stddef.h>
 #include <stdint.h>
 
 #include <vector>
@@ -137,13 +138,21 @@ struct SlaneTask {
     uint32_t nrec;       // records (a multiple of 4)
     uint32_t hpitch;     // bytes between pair rows of the row counts
     int32_t cls;         // slot class: slots laid out / executed per word (slane_slots, slane_exec_slots)
-    int32_t wave;        // the pair rows of its scan group's LDS accumulators this wave flushes: first (bits 2:0), number 0 / 1 / 2 (bits 5:4)
+    int32_t wave;        // the pair rows of its scan group's LDS accumulators this wave flushes: first (bits 4:0, SL_WAVE_FIRST_BITS),
+                         // their number 0 .. 8 (bits 11:8, SL_WAVE_COUNT_SHIFT) -- tools/gen_slane_asm.py reads the same fields
     uint64_t planes;     // counter dump of (task, scan group): [word][SL_DUMP planes][64]
     uint32_t lds_base;   // LDS address of the scan group's row-count accumulators in the workgroup
     uint32_t pad1;
     uint64_t pad2[6];
 };
+constexpr int SL_WAVE_FIRST_BITS = 5, SL_WAVE_COUNT_SHIFT = 8, SL_WAVE_COUNT_BITS = 4;
 static_assert(sizeof(SlaneTask) == 128, "SlaneTask layout (slane_asm.inc loads it by offset)");
+// the offsets the wave program loads from (tools/gen_slane_asm.py: s_load ... %[desc], <offset>)
+static_assert(offsetof(SlaneTask, seg) == 0 && offsetof(SlaneTask, fet) == 8 && offsetof(SlaneTask, hrsrc) == 16 &&
+                  offsetof(SlaneTask, rsrc) == 32 && offsetof(SlaneTask, nrec) == 48 && offsetof(SlaneTask, hpitch) == 52 &&
+                  offsetof(SlaneTask, cls) == 56 && offsetof(SlaneTask, wave) == 60 && offsetof(SlaneTask, planes) == 64 &&
+                  offsetof(SlaneTask, lds_base) == 72,
+              "SlaneTask field offsets are part of the wave program");
 
 // slane_build.hip: the same programs generated on the device (the default; the host generator above is the reference
 // implementation).  Scratch per task (= candidate * NS + strip): cmin / cmax / first / last [task][rowsG], most [task],

@@ -257,7 +257,8 @@ int SlaneScratch::create(const SlanePlan &p, int groups)
                     k.nrec = (uint32_t)p.nrec;
                     k.hpitch = (uint32_t)(nscp * 4);
                     k.cls = real ? S.cls : 0;
-                    k.wave = first | (count << 8);
+                    static_assert(SL_BLOCK / 2 <= (1 << SL_WAVE_FIRST_BITS) && 8 < (1 << SL_WAVE_COUNT_BITS), "SlaneTask::wave fields");
+                    k.wave = first | (count << SL_WAVE_COUNT_SHIFT);
                     k.lds_base = (uint32_t)((sg % sgw) * 2 * (SL_BLOCK / 2) * SL_LANES * 4);
                 }
             }

@@ -304,6 +304,27 @@ def test_host_batch_pageable_pinned_and_packed(oracle):
     assert (b6 == best[:20]).all() and (v6.view(np.uint64) == vs[:20].view(np.uint64)).all()
 
 
+def test_sweep_batch_of_mixed_shapes(oracle):
+    """omr_sweep_batch buckets a batch by shape (the reference corrects one file per call, any size, task.rs:19-38; its own
+    dataset holds 1240x1150 and ~1237x1300 sheets): three shapes interleaved, one of them with >= 64 scans (scan-lane
+    sweep), the others on the run-merging path; every result at its scan's own position, bit for bit the oracle's."""
+    shapes = [(115, 124), (130, 124), (97, 131)]
+    counts = [70, 9, 21]
+    scans, kinds = [], []
+    pools = [[np.where(s <= 127, 0, 255).astype(np.uint8) for s in make_scans(r, c, k, 77 + r)] for (r, c), k in zip(shapes, counts)]
+    at = [0, 0, 0]
+    order = np.random.Generator(np.random.PCG64(4)).permutation(np.repeat(np.arange(3), counts))
+    for k in order:
+        scans.append(pools[k][at[k]])
+        at[k] += 1
+    best, ang, vs, hs = projection.sweep_batch(scans, 6, 0.5, n_devices=1, want_sd=True)
+    N, A = oracle.candidate_count(6, 0.5)
+    for i, img in enumerate(scans):
+        _, _, evs, ehs = oracle.sweep(img, 6, 0.5)
+        assert (vs[i].view(np.uint64) == evs.view(np.uint64)).all() and (hs[i].view(np.uint64) == ehs.view(np.uint64)).all(), i
+        assert best[i] == oracle.argmax_path1(evs, ehs)[0] and ang[i] == (best[i] - N) * 0.5
+
+
 def test_host_batch_refuses_more_devices_than_visible():
     with pytest.raises(oics.OmrError) as e:
         projection.HostBatch(100, 100, 5, 1.0, 8, n_devices=64)

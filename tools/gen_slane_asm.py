@@ -29,6 +29,25 @@ Register map (fixed; the statement clobbers s0-s13, s16-s101, v1-v127, so lane *
   v40 / v41 odd row's words  v42 a carry  v43 free  v[44:59] four landing sets of four entries  v[60:123] ring
   v124 zero (ring register 64: white runs)  v[125:127] aligned windows, and the carries of the carry-save step between
   words (v125 = ring register 65: dummy commits)
+Invariants of the wave program (checked by lint_scalar_loads() below for every variant this file can emit; the memory fault
+of round 4 -- profiles/r04_lanes_ablation.md -- was a violation of the second one):
+  * scalar loads return OUT OF ORDER, so the only usable wait is lgkmcnt(0) = everything outstanding (the row-count ds_add of
+    an odd row counts too).  Between an s_load and the next lgkmcnt(0) its destination SGPRs are IN FLIGHT: nothing may read
+    them, write them, or load into them again;
+  * which sets are in flight where:  L<cls>_loop (top of a turn): A, B (rows 0, 1 of the turn: requested by row 14 of the
+    previous turn, or by the prologue); C, D hold the consumed records of rows 14, 15 -- s[48:57] are free there, which the
+    L2 prefetch (a buffer descriptor in s[48:51]) and the flush (s[48:57]) use.  Every even row r starts with lgkmcnt(0) --
+    nothing in flight -- and then requests rows r + 2, r + 3 into sets (r + 2) % 4, (r + 3) % 4, which rows r, r + 1 do not
+    touch.  The flush ends on its own lgkmcnt(0).  After the last turn A, B are still in flight (two records past the
+    stream's end: the program buffer has slack for them): the epilogue waits before it loads the dump pointer into s[16:17];
+  * vector loads (the ring's fetches, the prefetch) return IN ORDER, four fetches per row into landing set r % 4, committed
+    four rows later behind a COUNTED wait, vmcnt(12); extra loads among the younger ones (the prefetch: two per turn of the
+    strip's first scan group) only make that wait stricter.  Row-count atomics are stores: they may retire out of order with
+    respect to loads, which can only lengthen a counted wait, never satisfy it early;
+  * M0: every word leaves M0 = 0 behind its indexed reads (s_mov m0, 0 in front of the funnel shifts), so every vector-ALU
+    instruction outside word() and commit_and_fetch() runs unindexed; vector MEMORY instructions ignore the index mode;
+  * row phases (LDS slot, carry-save level, flush) are taken from -s8 modulo 64: the number of records is a multiple of 64,
+    not of 128.
 Usage: python tools/gen_slane_asm.py   (writes the .inc; the build only reads it)"""
 import os
 
@@ -147,7 +166,7 @@ def flush(out, L):
     if "noatomic" not in ABLATE:
         out += ["s_load_dwordx4 s[48:51], %[desc], 16", "s_load_dwordx2 s[52:53], %[desc], 48",
                 "s_waitcnt lgkmcnt(0)"] + ([] if "nobarrier" in ABLATE else ["s_barrier"]) + [
-                "s_bfe_u32 s57, s9, 0x40008",                              # pair rows this wave sends on (bits 11:8)
+                "s_bfe_u32 s57, s9, 0x40008",                              # pair rows this wave sends on (bits 11:8 = SL_WAVE_COUNT_SHIFT / _BITS, slane.hpp)
                 "s_cmp_eq_u32 s57, 0", "s_cbranch_scc1 %s_nofl" % L,
                 "s_sub_u32 s54, s52, s8",                                  # row index of the turn (12 mod 16)
                 # the block's buffer: that bit of -s8, as the adds computed it (the number of records is a multiple of 64, not
@@ -249,6 +268,7 @@ def body(o, S, L, E=None):
     if "norec" in ABLATE:
         rec_loads(o, 2, S, 2, True)
         rec_loads(o, 3, S, 3, True)
+        o.append("s_waitcnt lgkmcnt(0)")  # (the prefetch below borrows set C's registers)
     o.append("L%s_loop:" % L)
     if PREFETCH:
         # The records of the turn PREFETCH turns ahead, pulled into L2 by two vector loads (a lane per 128-byte line) of the
@@ -340,10 +360,75 @@ def kernel():
     return o
 
 
+def lint_scalar_loads(ins):
+    """Scalar loads return OUT OF ORDER and the only wait there is is lgkmcnt(0) -- everything outstanding.  So between an
+    s_load and the next s_waitcnt lgkmcnt(0) its destination SGPRs are in flight: no instruction may read them (stale or
+    half-written), write them (the late load would overwrite the new value: the round-4 fault -- the epilogue loaded the dump
+    pointer into s[16:17] while two records were still travelling into s[16:31]) or be a second load into them.  This pass
+    walks the generated program once, in program order, and asserts exactly that; at a label the state is the union over the
+    edges that reach it (forward branches recorded when they are seen; a backward branch must not carry more in flight than
+    the label was first entered with).  It runs for every variant the generator can emit, probes included."""
+    import re
+    fly, at_label, pending = set(), {}, {}
+
+    def regs(txt):
+        out = set()
+        txt = txt.replace("%[desc]", "s[14:15]")
+        for a, b in re.findall(r"\bs\[(\d+):(\d+)\]", txt):
+            out |= set(range(int(a), int(b) + 1))
+        for a in re.findall(r"\bs(\d+)\b", re.sub(r"\bs\[\d+:\d+\]", " ", txt)):
+            out.add(int(a))
+        return out
+
+    for n, line in enumerate(ins):
+        line = line.strip()
+        if line.endswith(":"):
+            lab = line[:-1]
+            fly |= pending.pop(lab, set())
+            at_label[lab] = set(fly)
+            continue
+        op, _, rest = line.partition(" ")
+        if op == "s_waitcnt":
+            if "lgkmcnt(0)" in rest:
+                fly.clear()
+            continue
+        if op.startswith("s_load_dword"):
+            dst, _, src = rest.partition(",")
+            d, r = regs(dst), regs(src)
+            assert not (d & fly), "instruction %d (%s): a second load into SGPRs that are still in flight: %s" % (n, line, sorted(d & fly))
+            assert not (r & fly), "instruction %d (%s): address registers in flight: %s" % (n, line, sorted(r & fly))
+            fly |= d
+            continue
+        used = regs(rest)
+        assert not (used & fly), "instruction %d (%s) touches SGPRs with a scalar load in flight: %s" % (n, line, sorted(used & fly))
+        if op in ("s_branch",) or op.startswith("s_cbranch"):
+            lab = rest.strip()
+            if lab in at_label:  # backward
+                assert fly <= at_label[lab], "instruction %d (%s): the back edge carries loads in flight the label did not start with: %s" % (
+                    n, line, sorted(fly - at_label[lab]))
+            else:
+                pending[lab] = pending.get(lab, set()) | set(fly)
+            if op == "s_branch":
+                fly = set()  # unreachable until the next label
+    assert not pending, "branches to labels that never came: %s" % sorted(pending)
+
+
 CLOB = ['"memory"', '"scc"', '"vcc"', '"m0"'] + ['"s%d"' % i for i in list(range(0, 14)) + list(range(16, 102))] + \
        ['"v%d"' % i for i in range(1, 128)]
 
 out = ["// GENERATED by tools/gen_slane_asm.py -- do not edit; see that file for the register map.\n"]
+lint_scalar_loads(kernel())
+# the lint must see the fault of round 4: the same program without the wait in front of the epilogue's load
+_k = kernel()
+_i = max(i for i, x in enumerate(_k) if x.startswith("s_load_dwordx2 s[16:17]"))
+assert _k[_i - 1] == "s_waitcnt lgkmcnt(0)"
+try:
+    if "norec" in ABLATE:  # (that probe requests no records in the loop: nothing is in flight at the epilogue)
+        raise AssertionError
+    lint_scalar_loads(_k[:_i - 1] + _k[_i:])
+    raise SystemExit("lint_scalar_loads did not notice a load into s[16:17] under records in flight")
+except AssertionError:
+    pass
 body_txt = "\\n\\t\"\n    \"".join(kernel())
 out.append("#define SLANE_ASM \\\n    \"%s\\n\\t\"\n" % body_txt.replace("\n", " \\\n"))
 out.append("#define SLANE_ASM_CLOBBERS %s\n" % ", ".join(CLOB))
