@@ -17,12 +17,17 @@
 //                % 32: the row's LAST column is the last bit of the last word, the columns that do not exist are
 //                the first bits of word 0
 //   records    : one per destination row, plus SL_PRE virtual rows ahead of row 0 that only fill the ring and virtual
-//                rows at the end up to a multiple of 64.  Two streams per strip:
+//                rows at the end up to a multiple of 64.  Two streams per strip (format v3, round 5):
 //                  fetch stream, 8 dwords per row: 4 x (E << 8) = the byte offsets of the entries whose loads are
-//                                   ISSUED while this row is swept (0 = the all-zero entry: a dummy), then 2 dwords
-//                                   = 4 x u16 (ring register | 0x8000) to COMMIT before this row: where the loads
-//                                   issued SL_AHEAD rows earlier belong (register 65 = dummy; 0x8000 = M0's DST_REL
-//                                   bit), then 2 unused dwords
+//                                   ISSUED while this row is swept (0 = the all-zero entry: a dummy) -- two PAIRS: loads
+//                                   2 p and 2 p + 1 fetch two adjacent word columns of one source row into an aligned pair of
+//                                   landing registers --, then 1 dword = 2 x u16 (ring register | 0x8000) to COMMIT before
+//                                   this row: where the two pairs issued SL_AHEAD rows earlier belong -- an EVEN ring
+//                                   register: one v_mov_b64 with DST_REL moves a pair (an odd index is rounded down by the
+//                                   hardware, tools/mov64_probe.hip); register SL_DUMMY = 66 swallows a dummy pair; 0x8000
+//                                   = M0's DST_REL bit --, then 1 dword = the TURN HEADER: the most segments any word of
+//                                   the 16 rows from this record on needs (1 .. 8; the kernel reads it at the first record
+//                                   of a turn and executes exactly that many slots per word), then 2 unused dwords
 //                  segment stream, SL_K words x S dwords per row.  A word is assembled from its segments in
 //                                   increasing bit order by funnel shifts, no masks:
 //                                     X = (ring[idx + 1] : ring[idx]) >> sh      (the segment's bits, bit 0 first)
@@ -49,7 +54,9 @@ constexpr int SL_FETCH = 4;                             // loads per row
 constexpr int SL_FREC = 8;                              // dwords per row of the fetch stream
 constexpr int SL_AHEAD = 4;                             // rows between a load and its commit
 constexpr int SL_ZERO = SL_RING_ROWS * SL_RING_COLS;   // ring register that holds 0 (white runs read it)
-constexpr int SL_DUMMY = SL_ZERO + 1;                   // register that swallows dummy fetches
+constexpr int SL_DUMMY = SL_ZERO + 2;                   // (even) register pair that swallows dummy fetch pairs
+constexpr int SL_PAIRS = 2;                             // fetch pairs per row
+constexpr int SL_TURN = 16;                             // rows per turn of the kernel's loop: one header per turn
 constexpr uint32_t SL_PK_MODE = 0x60000u;               // pk >> 5 -> M0[13:12]: SRC0_REL | SRC1_REL
 constexpr uint32_t SL_COMMIT_MODE = 0x8000u;            // M0[15]: DST_REL
 constexpr int SL_PRE = 24;                              // virtual rows ahead of row 0

@@ -112,7 +112,8 @@ __global__ __launch_bounds__(256) void slane_fill_kernel(SlaneBuild b, int ntask
     const uint32_t nocommit = (uint32_t)SL_DUMMY | SL_COMMIT_MODE;
     uint32_t *f = fet + (int64_t)q * SL_FREC;
     f[0] = f[1] = f[2] = f[3] = 0u;
-    f[4] = f[5] = nocommit | (nocommit << 16);
+    f[4] = nocommit | (nocommit << 16);
+    f[5] = 1u;  // turn header (slane_turns_kernel writes the real ones)
     f[6] = f[7] = 0u;
 }
 
@@ -123,7 +124,7 @@ __global__ __launch_bounds__(64) void slane_sched_kernel(SlaneBuild b, int ntask
     if (task >= ntasks) return;
     const SlaneGeom &g = b.g;
     const int64_t tb = (int64_t)task * g.rowsG;
-    uint8_t *used = b.used + (int64_t)task * b.nrec, *freg = b.freg + (int64_t)task * b.nrec * SL_FETCH;
+    uint8_t *used = b.used + (int64_t)task * b.nrec, *freg = b.freg + (int64_t)task * b.nrec * SL_FETCH;  // (freg: SL_PAIRS of the 4 bytes per record)
     uint32_t *fet = b.prog + b.fet_off[task];
     bool ok = true;
     for (int s = 0; s < g.rowsG && ok; s++) {
@@ -140,15 +141,17 @@ __global__ __launch_bounds__(64) void slane_sched_kernel(SlaneBuild b, int ntask
             if (lp >= 0) lb = max(lb, lp - SL_AHEAD + 1);
         }
         int rec = b.first[tb + s] - SL_AHEAD;
-        for (int j = ncols - 1; j >= 0; j--) {
-            while (rec >= lb && used[rec + SL_PRE] == SL_FETCH) rec--;
+        for (int pr = (ncols + 1) / 2 - 1; pr >= 0; pr--) {  // word columns 2 pr, 2 pr + 1 of the row: one pair (slane_plan.cpp)
+            while (rec >= lb && used[rec + SL_PRE] == SL_PAIRS) rec--;
             if (rec < lb) {
                 ok = false;
                 break;
             }
             const int q = rec + SL_PRE, u = used[q];
-            freg[(int64_t)q * SL_FETCH + u] = (uint8_t)((s & (SL_RING_ROWS - 1)) * SL_RING_COLS + j);
-            fet[(int64_t)q * SL_FREC + u] = (uint32_t)((1 + (int64_t)s * g.colsG + (lo + j + g.gx)) << 8);  // g.entry(s - gy, lo + j)
+            freg[(int64_t)q * SL_FETCH + u] = (uint8_t)((s & (SL_RING_ROWS - 1)) * SL_RING_COLS + 2 * pr);
+            const int64_t e0 = 1 + (int64_t)s * g.colsG + (lo + 2 * pr + g.gx);  // g.entry(s - gy, lo + 2 pr)
+            fet[(int64_t)q * SL_FREC + 2 * u] = (uint32_t)(e0 << 8);
+            fet[(int64_t)q * SL_FREC + 2 * u + 1] = 2 * pr + 1 < ncols ? (uint32_t)((e0 + 1) << 8) : 0u;
             used[q] = (uint8_t)(u + 1);
         }
     }
@@ -157,11 +160,26 @@ __global__ __launch_bounds__(64) void slane_sched_kernel(SlaneBuild b, int ntask
         return;
     }
     for (int q = SL_AHEAD; q < b.nrec; q++) {  // what row q commits = what row q - SL_AHEAD fetched
-        const uchar4 fr = *(const uchar4 *)&freg[(int64_t)(q - SL_AHEAD) * SL_FETCH];
-        uint32_t *f = fet + (int64_t)q * SL_FREC;
-        f[4] = ((uint32_t)fr.x | SL_COMMIT_MODE) | (((uint32_t)fr.y | SL_COMMIT_MODE) << 16);
-        f[5] = ((uint32_t)fr.z | SL_COMMIT_MODE) | (((uint32_t)fr.w | SL_COMMIT_MODE) << 16);
+        const uint8_t *fr = &freg[(int64_t)(q - SL_AHEAD) * SL_FETCH];
+        fet[(int64_t)q * SL_FREC + 4] = ((uint32_t)fr[0] | SL_COMMIT_MODE) | (((uint32_t)fr[1] | SL_COMMIT_MODE) << 16);
     }
+}
+
+// thread = (task, turn): the turn header -- the most segments any word of the turn's SL_TURN records needs -- read back from the
+// encoded segment words (after slane_words_kernel)
+__global__ __launch_bounds__(256) void slane_turns_kernel(SlaneBuild b, int ntasks)
+{
+    const int nturns = (b.nrec + SL_TURN - 1) / SL_TURN;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (int64_t)ntasks * nturns) return;
+    const int task = (int)(i / nturns), q0 = (int)(i - (int64_t)task * nturns) * SL_TURN;
+    const int S = slane_slots(b.cls[task]), RD = SL_K * S;
+    const uint32_t *seg = b.prog + b.seg_off[task];
+    uint32_t *fet = b.prog + b.fet_off[task];
+    uint32_t most = 1;
+    for (int q = q0; q < q0 + SL_TURN && q < b.nrec; q++)
+        for (int k = 0; k < SL_K; k++) most = max(most, (seg[(int64_t)q * RD + k * S] >> SL_NSHIFT) & 15u);
+    for (int q = q0; q < q0 + SL_TURN && q < b.nrec; q++) fet[(int64_t)q * SL_FREC + 5] = most;
 }
 
 // grid (tasks, ceil(rows / 128))
@@ -211,6 +229,10 @@ hipError_t launch_slane_build_emit(const SlaneBuild &b, int ntasks, hipStream_t 
     hipLaunchKernelGGL(slane_fill_kernel, dim3(ntasks + 1, (b.nrec + 255) / 256), dim3(256), 0, s, b, ntasks);
     hipLaunchKernelGGL(slane_sched_kernel, dim3((ntasks + 63) / 64), dim3(64), 0, s, b, ntasks);
     hipLaunchKernelGGL(slane_words_kernel, dim3(ntasks, (b.g.rows + 127) / 128), dim3(256), 0, s, b);
+    {
+        const int64_t n = (int64_t)ntasks * ((b.nrec + SL_TURN - 1) / SL_TURN);
+        hipLaunchKernelGGL(slane_turns_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, b, ntasks);
+    }
     return hipGetLastError();
 }
 

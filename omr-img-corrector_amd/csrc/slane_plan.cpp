@@ -61,7 +61,8 @@ void slane_null_program(int nrec, int cls, uint32_t *seg, uint32_t *fet)
     for (size_t q = 0; q < (size_t)nrec; q++) {
         uint32_t *f = fet + q * SL_FREC;
         f[0] = f[1] = f[2] = f[3] = 0u;
-        f[4] = f[5] = nocommit | (nocommit << 16);
+        f[4] = nocommit | (nocommit << 16);
+        f[5] = 1u;  // turn header: one segment per word
         f[6] = f[7] = 0u;
     }
 }
@@ -176,8 +177,8 @@ bool slane_strip_program(const SlaneGeom &g, const int32_t *ad, const int32_t *b
     // ---- fetch schedule.  Record q (row q - SL_PRE) issues its loads while its row is swept; they are committed to
     // the ring before row q + SL_AHEAD (in between they sit in the wave's landing registers).  Source row s lives in
     // registers (s & 15) * 4 + j: it may be committed only after the last row that reads source row s - 16 is done.
-    std::vector<uint8_t> used((size_t)NREC, 0);
-    std::vector<uint8_t> freg((size_t)NREC * SL_FETCH, (uint8_t)SL_DUMMY);  // ring register of every fetch
+    std::vector<uint8_t> used((size_t)NREC, 0);                                       // fetch PAIRS taken per record
+    std::vector<uint8_t> freg((size_t)NREC * SL_PAIRS, (uint8_t)SL_DUMMY);            // (even) ring register of every pair
     for (int s = 0; s < RG; s++) {
         if (last[(size_t)s] < 0) continue;
         const int ncols = cmax[(size_t)s] - cmin[(size_t)s] + 1;
@@ -187,20 +188,20 @@ bool slane_strip_program(const SlaneGeom &g, const int32_t *ad, const int32_t *b
         if (s >= SL_RING_ROWS && last[(size_t)(s - SL_RING_ROWS)] >= 0)
             lb = std::max(lb, last[(size_t)(s - SL_RING_ROWS)] - SL_AHEAD + 1);
         int rec = first[(size_t)s] - SL_AHEAD;
-        for (int j = ncols - 1; j >= 0; j--) {
-            while (rec >= lb && used[(size_t)(rec + SL_PRE)] == SL_FETCH) rec--;
+        for (int pr = (ncols + 1) / 2 - 1; pr >= 0; pr--) {  // word columns 2 pr, 2 pr + 1 of the row: one pair
+            while (rec >= lb && used[(size_t)(rec + SL_PRE)] == SL_PAIRS) rec--;
             if (rec < lb) return false;
             const size_t q = (size_t)(rec + SL_PRE);
-            const uint32_t reg = (uint32_t)((s & (SL_RING_ROWS - 1)) * SL_RING_COLS + j);
-            freg[q * SL_FETCH + used[q]] = (uint8_t)reg;
-            fet[q * SL_FREC + used[q]++] = (uint32_t)(g.entry(s - g.gy, cmin[(size_t)s] + j) << 8);
+            const int u = used[q]++;
+            freg[q * SL_PAIRS + (size_t)u] = (uint8_t)((s & (SL_RING_ROWS - 1)) * SL_RING_COLS + 2 * pr);
+            fet[q * SL_FREC + 2 * (size_t)u] = (uint32_t)(g.entry(s - g.gy, cmin[(size_t)s] + 2 * pr) << 8);
+            // (the second column of a row's last pair may not exist: the all-zero entry lands in a ring register no segment reads)
+            fet[q * SL_FREC + 2 * (size_t)u + 1] = 2 * pr + 1 < ncols ? (uint32_t)(g.entry(s - g.gy, cmin[(size_t)s] + 2 * pr + 1) << 8) : 0u;
         }
     }
     for (int q = SL_AHEAD; q < NREC; q++) {  // what row q commits = what row q - SL_AHEAD fetched
-        const uint8_t *fr = &freg[(size_t)(q - SL_AHEAD) * SL_FETCH];
-        uint32_t *f = fet + (size_t)q * SL_FREC;
-        f[4] = ((uint32_t)fr[0] | SL_COMMIT_MODE) | (((uint32_t)fr[1] | SL_COMMIT_MODE) << 16);
-        f[5] = ((uint32_t)fr[2] | SL_COMMIT_MODE) | (((uint32_t)fr[3] | SL_COMMIT_MODE) << 16);
+        const uint8_t *fr = &freg[(size_t)(q - SL_AHEAD) * SL_PAIRS];
+        fet[(size_t)q * SL_FREC + 4] = ((uint32_t)fr[0] | SL_COMMIT_MODE) | (((uint32_t)fr[1] | SL_COMMIT_MODE) << 16);
     }
     // ---- the rows' words
     for (int r = 0; r < R; r++)
@@ -219,8 +220,15 @@ bool slane_strip_program(const SlaneGeom &g, const int32_t *ad, const int32_t *b
                 w[j] = sh | (idx << 5) | SL_PK_MODE | (q << SL_QSHIFT);
             }
             w[0] |= (uint32_t)n << SL_NSHIFT;
-            if (n <= 4) w[0] |= SL_SHORT;  // the kernel skips the second group of four slots
+            if (n <= 4) w[0] |= SL_SHORT;  // (a flag the kernel no longer reads: with exact slot counts per turn a per-word skip costs more than it saves)
         }
+    // ---- turn headers: the most segments any word of a turn of SL_TURN records needs (virtual rows: one white run)
+    for (int q0 = 0; q0 < NREC; q0 += SL_TURN) {
+        uint32_t most = 1;
+        for (int q = q0; q < q0 + SL_TURN && q < NREC; q++)
+            for (int k = 0; k < SL_K; k++) most = std::max(most, (seg[(size_t)q * RD + (size_t)k * S] >> SL_NSHIFT) & 15u);
+        for (int q = q0; q < q0 + SL_TURN && q < NREC; q++) fet[(size_t)q * SL_FREC + 5] = most;
+    }
     return true;
 }
 

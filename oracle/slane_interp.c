@@ -10,12 +10,17 @@
 #define SL_FETCH 4
 #define SL_FREC 8
 #define SL_AHEAD 4
-#define SL_RING 66 /* 64 ring registers, register 64 holds 0, register 65 swallows dummy fetches */
+#define SL_TURN 16
+#define SL_RING 68 /* 64 ring registers, register 64 holds 0 (65 is its upper neighbour), the pair 66 / 67 swallows dummy fetch pairs */
 
 /* seg: n_records rows of seg_dwords dwords (K words x S segments, pk = sh | idx << 5 | 0x60000 | q << 21 | n << 26 in the
- * first); fet: n_records rows of 8 dwords: 4 byte offsets (E << 8) whose loads are issued in this row, 2 dwords = 4 x u16
- * (ring register | 0x8000) committed before this row (the loads of SL_AHEAD rows earlier, landed in the set of landing
- * registers row % SL_AHEAD); bits: entries[E][lanes] dwords (entry 0 all zero);
+ * first); fet: n_records rows of 8 dwords (format v3): 4 byte offsets (E << 8) whose loads are issued in this row -- two
+ * PAIRS --, 1 dword = 2 x u16 (EVEN ring register | 0x8000): where the two pairs that landed in this row's set of landing
+ * registers (the loads of SL_AHEAD rows earlier) are committed before this row, as the kernel's v_mov_b64 does (an odd
+ * index would be rounded down by the hardware: refused here), 1 dword = the turn header: the slots per word the kernel
+ * executes during the SL_TURN rows from a turn's first record on (the slots past a word's own count are the generator's
+ * pads: they must be no-ops, and a header smaller than a word's count would drop segments); bits: entries[E][lanes] dwords
+ * (entry 0 all zero);
  * hrow[r * lanes + lane] += black pixels of row r in this strip (r = record - pre_rows, 0 <= r < rows);
  * vcol[(k * 32 + bit) * lanes + lane] += black pixels of bit `bit` of the strip's word k (the caller maps bits to columns).
  * Returns 0, or -1 when a fetch / register index is out of range or a virtual row carries bits. */
@@ -24,6 +29,7 @@ int orc_slane_run_strip(const uint32_t *seg, int seg_dwords, const uint32_t *fet
 {
     const int S = seg_dwords / K;
     uint32_t ring[SL_RING][64], T[SL_AHEAD][SL_FETCH][64];
+    int turn_slots = 0;
     if (lanes > 64) return -1;
     memset(ring, 0, sizeof ring);
     memset(T, 0, sizeof T);
@@ -31,11 +37,16 @@ int orc_slane_run_strip(const uint32_t *seg, int seg_dwords, const uint32_t *fet
         const uint32_t *rec = fet + (int64_t)q * SL_FREC;
         const int set = q % SL_AHEAD;
         /* commit what landed in this row's set of landing registers, then issue this row's loads into it */
-        for (int f = 0; f < SL_FETCH; f++) {
-            const uint32_t m0 = (rec[SL_FETCH + f / 2] >> (16 * (f & 1))) & 0xffffu; /* M0 image: register | DST_REL */
+        for (int pr = 0; pr < SL_FETCH / 2; pr++) {
+            const uint32_t m0 = (rec[SL_FETCH] >> (16 * pr)) & 0xffffu; /* M0 image: register | DST_REL */
             const uint32_t reg = m0 & 255u;
-            if (reg >= SL_RING || reg == 64u || (m0 >> 8) != 0x80u) return -1;
-            memcpy(ring[reg], T[set][f], sizeof(uint32_t) * (size_t)lanes);
+            if (reg + 1 >= SL_RING || (reg & 1u) || reg == 64u || (m0 >> 8) != 0x80u) return -1;
+            memcpy(ring[reg], T[set][2 * pr], sizeof(uint32_t) * (size_t)lanes);
+            memcpy(ring[reg + 1], T[set][2 * pr + 1], sizeof(uint32_t) * (size_t)lanes);
+        }
+        if (q % SL_TURN == 0) { /* the kernel reads the header at the first record of a turn */
+            turn_slots = (int)rec[SL_FETCH + 1];
+            if (turn_slots < 1 || turn_slots > S) return -1;
         }
         for (int f = 0; f < SL_FETCH; f++) {
             const int64_t e = rec[f] >> 8;
@@ -45,10 +56,10 @@ int orc_slane_run_strip(const uint32_t *seg, int seg_dwords, const uint32_t *fet
         for (int k = 0; k < K; k++) {
             const uint32_t *w = seg + (int64_t)q * seg_dwords + k * S;
             const int n = (int)((w[0] >> 26) & 31u);
-            if (n < 1 || n > S) return -1;
+            if (n < 1 || n > S || n > turn_slots) return -1; /* the kernel would stop before this word's last segment */
             for (int lane = 0; lane < lanes; lane++) {
                 uint32_t D = 0xdeadbeefu; /* whatever the register held: the first segment overwrites it */
-                for (int j = 0; j < n; j++) {
+                for (int j = 0; j < turn_slots; j++) { /* exactly the header's slots, pads included */
                     const uint32_t pk = w[j];
                     const uint32_t idx = (pk >> 5) & 255u, sh = pk & 31u, qq = (pk >> 21) & 31u;
                     if (((pk >> 5) & 0xff00u) != 0x3000u || idx + 1 >= SL_RING) return -1; /* M0 image: index | SRC0_REL | SRC1_REL */

@@ -1,5 +1,6 @@
 """Generates omr-img-corrector_amd/csrc/slane_asm.inc: the scan-lane sweep's wave program as
-gfx950 assembly text; ONE asm statement that dispatches on the strip's segment-slot class (2 / 4 / 8 slots per word laid out, 2 .. 8 executed: seven loop bodies).
+gfx950 assembly text; ONE asm statement that dispatches on the strip's segment-slot class (2 / 4 / 8 slots per word laid out) and,
+once per turn of 16 rows, on the turn's header (1 .. S slots executed: 2 + 4 + 8 loop bodies; program format v3, round 5).
 
 Why assembly: the wave keeps its source words in a ring of 64 VGPRs addressed through the gfx9 VGPR index mode (M0),
 its segment descriptors live in SGPRs filled by s_load, and the column counters are a carry-save tree in fixed
@@ -15,7 +16,8 @@ a segment is ONE dword (slane.hpp) -- no masks, a word is assembled by funnel sh
     X = v_alignbit(ring[idx + 1], ring[idx], sh)      (VGPR index mode: M0 = pk >> 5)
     D = X << q  (first segment)   |   D = v_alignbit(X, D, q)  (the others: X's low q bits enter at the top)
 Per row:  wait until the loads issued four rows ago have landed (counted: vector loads return in order) -> commit them
-into the ring (v_mov with DST_REL) -> issue this row's four loads -> two words -> row count (pairs of rows meet the
+into the ring (two v_mov_b64 with DST_REL: a row's four loads are two pairs of adjacent word columns, tools/mov64_probe.hip
+showed that a 64-bit move takes an even index) -> issue this row's four loads -> two words -> row count (pairs of rows meet the
 workgroup's other strips in LDS; one global atomic per pair row and block of BLOCK rows) -> (odd rows) carry-save column counters.
 
 Register map (fixed; the statement clobbers s0-s13, s16-s101, v1-v127, so lane * 4 arrives in v0):
@@ -23,7 +25,7 @@ Register map (fixed; the statement clobbers s0-s13, s16-s101, v1-v127, so lane *
   row phases are taken from -s8)  s9 pair rows the wave flushes (first in bits 4:0, number in bits 11:8) | LDS base of the scan group's accumulators (a multiple of 4096)
   s[10:11] second shifts of a segment pair / scratch  s[14:15] the task (input)
   segment sets A-D: s[16:31] s[32:47] s[48:63] s[64:79]   fetch offsets A-D: s[80:83] s[84:87] s[88:91] s[92:95]
-  commit pairs A-D: s[96:97] s[98:99] s[100:101] s[12:13]
+  commit word + turn header A-D: s[96:97] s[98:99] s[100:101] s[12:13]
   v[1:18] / v[19:36] column counters of word 0 / 1: planes p0..p12, pending carries c0..c4
   v37 LDS address of the turn's row-count slots  v38 odd row's count / fourth aligned window  v39 row count
   v40 / v41 odd row's words  v42 a carry  v43 free  v[44:59] four landing sets of four entries  v[60:123] ring
@@ -117,16 +119,17 @@ def word(out, k, sset, S, dreg, tag, E=None):
 
 def commit_and_fetch(out, x, tset):
     """x = record set of this row; loads return in order: at most (AHEAD - 1) * 4 younger loads may still fly when this
-    row's landing set has arrived (row-count atomics in flight only make the wait longer)"""
+    row's landing set has arrived (row-count atomics in flight only make the wait longer).  The four loads of a row are two
+    PAIRS -- two adjacent word columns of one source row in an aligned pair of landing registers -- and a pair is committed
+    by ONE v_mov_b64 with DST_REL to an even ring register (format v3: 2 + 2 instructions per row instead of 4 + 4)."""
     t = T0 + 4 * tset
     out.append("s_waitcnt vmcnt(%d)" % ((AHEAD - 1) * 4))
-    c0, c1 = FCOM[x], FCOM[x] + 1
-    for f, ins in enumerate(("s_and_b32 m0, s%d, 0xffff" % c0, "s_lshr_b32 m0, s%d, 16" % c0,
-                             "s_and_b32 m0, s%d, 0xffff" % c1, "s_lshr_b32 m0, s%d, 16" % c1)):
+    c0 = FCOM[x]
+    for f, ins in enumerate(("s_and_b32 m0, s%d, 0xffff" % c0, "s_lshr_b32 m0, s%d, 16" % c0)):
         if "nocommit" in ABLATE:
             break
-        out.append(ins)                                          # ring register | DST_REL
-        out.append("v_mov_b32 v%d, v%d" % (RING, t + f))
+        out.append(ins)                                          # even ring register | DST_REL
+        out.append("v_mov_b64 v[%d:%d], v[%d:%d]" % (RING, RING + 1, t + 2 * f, t + 2 * f + 1))
     # (M0 is left as it is: the loads below are not vector-ALU instructions -- the index mode does not touch them -- and the
     # next vector-ALU instruction is a word's first indexed v_alignbit, right behind its own M0 write)
     for f in range(4):
@@ -261,8 +264,11 @@ def rec_loads(out, x, S, row, force=False):
     out.append("s_load_dwordx2 s[%d:%d], s[2:3], %d" % (FCOM[x], FCOM[x] + 1, row * 32 + 16))
 
 
-def body(o, S, L, E=None):
-    """the row loop of one slot class: S slots laid out per word, E executed"""
+def body(o, S, L):
+    """the row loop of the strips laid out with S slots per word.  A turn = TURN rows; the turn's header (the fetch record of its
+    first row, second dword of the commit pair: set A) says how many slots per word its busiest word needs, and the turn
+    runs in the loop body that executes exactly that many: S bodies, one dispatch per turn (format v3; the strip's own
+    maximum -- round 4 -- executed 0.5 slots per word more)."""
     rec_loads(o, 0, S, 0, True)
     rec_loads(o, 1, S, 1, True)
     if "norec" in ABLATE:
@@ -294,19 +300,32 @@ def body(o, S, L, E=None):
     # LDS address of this turn's pair slots: buffer = bit log2(BLOCK) of the row index, slot = the bits below it down to 1
     o += ["s_sub_u32 s10, 0, s8", "s_bfe_u32 s10, s10, 0x%x" % ((LB << 16) | 1), "s_lshl_b32 s10, s10, 8", "s_and_b32 s11, s9, 0xfffff000",
           "s_add_u32 s10, s10, s11", "v_add_u32 v%d, s10, %%[lane4]" % LADDR]
-    for r in range(TURN):
-        if r % 2 == 0:  # a batch of two rows: everything requested two rows ago is here; request the next two rows
-            o.append("s_waitcnt lgkmcnt(0)")
-            rec_loads(o, (r + 2) % 4, S, r + 2)
-            rec_loads(o, (r + 3) % 4, S, r + 3)
-        odd = r & 1
-        commit_and_fetch(o, r % 4, r % 4)
-        d = (ST[0], ST[1]) if not odd else DODD
-        word(o, 0, SEG[r % 4], S, d[0], "L%s_r%dw0" % (L, r), E)
-        word(o, 1, SEG[r % 4], S, d[1], "L%s_r%dw1" % (L, r), E)
-        row_count(o, d[0], d[1], odd == 1, r // 2)
-        if odd:
-            carry_save(o, "L%s_cs%d" % (L, r), (r & 2) != 0, r // 4)
+    # rows 0, 1 of the turn (sets A, B; A carries the turn's header) are here; request rows 2, 3; dispatch on the header
+    o.append("s_waitcnt lgkmcnt(0)")
+    rec_loads(o, 2, S, 2)
+    rec_loads(o, 3, S, 3)
+    hdr = FCOM[0] + 1
+    for E in range(1, S):
+        o += ["s_cmp_eq_u32 s%d, %d" % (hdr, E), "s_cbranch_scc1 L%s_e%d" % (L, E)]
+    for E in range(S, 0, -1):
+        Ex = max(1, E - 1) if "lessE" in ABLATE else E  # timing probe: what one executed slot per word costs
+        o.append("L%s_e%d:" % (L, E))
+        for r in range(TURN):
+            if r % 2 == 0 and r > 0:  # a batch of two rows: everything requested two rows ago is here; request the next two rows
+                o.append("s_waitcnt lgkmcnt(0)")
+                rec_loads(o, (r + 2) % 4, S, r + 2)
+                rec_loads(o, (r + 3) % 4, S, r + 3)
+            odd = r & 1
+            commit_and_fetch(o, r % 4, r % 4)
+            d = (ST[0], ST[1]) if not odd else DODD
+            word(o, 0, SEG[r % 4], S, d[0], "L%s_e%d_r%dw0" % (L, E, r), Ex)
+            word(o, 1, SEG[r % 4], S, d[1], "L%s_e%d_r%dw1" % (L, E, r), Ex)
+            row_count(o, d[0], d[1], odd == 1, r // 2)
+            if odd:
+                carry_save(o, "L%s_e%d_cs%d" % (L, E, r), (r & 2) != 0, r // 4)
+        if E > 1:
+            o.append("s_branch L%s_tail" % L)
+    o.append("L%s_tail:" % L)
     flush(o, "L%s" % L)
     # (hotrec, a timing probe: the stream pointers stand still, every turn re-reads the first turn's records out of the scalar
     # cache -- the same instructions without the records' latency)
@@ -333,16 +352,13 @@ def kernel():
               "s_cmp_eq_u32 s10, 2", "s_cbranch_scc0 L%s_p2" % U, "s_setprio 2", "L%s_p2:" % U,
               "s_cmp_eq_u32 s10, 3", "s_cbranch_scc0 L%s_p3" % U, "s_setprio 3", "L%s_p3:" % U]
     o += ["s_set_gpr_idx_on s10, gpr_idx(SRC0)", "s_mov_b32 m0, 0"]  # index mode on for good; M0 = 0: nothing indexed
-    # slot classes (slane.hpp): laid out / executed = 2/2, 4/4, 8/8, 4/3, 8/5, 8/6, 8/7
-    CLASSES = ((0, 2, 2), (1, 4, 4), (2, 8, 8), (3, 4, 3), (4, 8, 5), (5, 8, 6), (6, 8, 7))
-    for cls, S, E in CLASSES[:-1]:
-        o += ["s_cmp_eq_u32 s11, %d" % cls, "s_cbranch_scc1 L%s_c%d" % (U, cls)]
-    for cls, S, E in reversed(CLASSES):
-        o.append("L%s_c%d:" % (U, cls))
-        if "lessE" in ABLATE:  # timing probe: what one executed slot per word costs (an upper bound for exact slot counts per turn)
-            E = max(1, E - 1)
-        body(o, S, "%s_c%d" % (U, cls), E)
-        if cls:
+    # slot classes (slane.hpp) 0 .. 6 -> slots laid out per word 2, 4, 8, 4, 8, 8, 8; how many are EXECUTED is the turn's business
+    for cls, S in ((0, 2), (1, 4), (3, 4)):
+        o += ["s_cmp_eq_u32 s11, %d" % cls, "s_cbranch_scc1 L%s_s%d" % (U, S)]
+    for S in (8, 4, 2):
+        o.append("L%s_s%d:" % (U, S))
+        body(o, S, "%s_s%d" % (U, S))
+        if S != 2:
             o.append("s_branch L%s_dump" % U)
     # ---- dump the plane registers: [word][p0..p12][lane]
     o.append("L%s_dump:" % U)
