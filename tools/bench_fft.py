@@ -40,9 +40,10 @@ for name, rows, cols in (("C5 4096x4096", 4096, 4096), ("A4 2480x3508", 3508, 24
         ts.append(time.perf_counter() - t0)
     px = rows * cols
     t = float(np.mean(ts))
-    # algorithmic bytes per scan: u8 in, complex f32 spectrum written and read by each of the two 1-D
-    # passes, |F| float32 out and in, two 8-bit pictures out (transposes and the log plane are overhead)
-    alg = px * (1 + 8 * 4 + 4 * 2 + 2)
+    # algorithmic bytes per scan = SURVEY.md Appendix C's count for config 5 (round-3 / round-4 verdicts: price the path on the
+    # survey's bytes, not on this builder's own formulation): the u8 scan in + four passes over the complex f32 spectrum =
+    # 1 + 4 x 8 = 33 B per pixel (553 MB per 4096 x 4096 scan)
+    alg = px * (1 + 4 * 8)
     # what the kernels actually move per scan: u8 in, the half spectrum (complex f32, cols / 2 + 1 columns) written
     # and read once, |F| of the half spectrum (f32) written and read once, two 8-bit pictures out
     half = rows * (cols // 2 + 1)

@@ -226,7 +226,7 @@ with open(os.path.join(dst, tag + "_fft.md"), "w") as f:
     f.write("# %s -- FFT path (BASELINE config 5)\n\n" % tag + STAMP)
     j = last_json(read("fft.log"))
     if j:
-        f.write("`python3 tools/bench_fft.py 64 4` (mean over the repetitions; algorithmic = SURVEY's reference formulation, 43 B/px; "
+        f.write("`python3 tools/bench_fft.py 64 4` (mean over the repetitions; algorithmic = SURVEY.md Appendix C's count, 33 B/px: the u8 scan in + four passes over the complex f32 spectrum; "
                 "kernel = what the kernels move: u8 in, half spectrum and |F| of it written and read once, two pictures out):\n\n")
         f.write("| case | scans/s | ms/scan (mean) | best | algorithmic GB/s | of 8 TB/s | kernel-bytes GB/s | of 8 TB/s |\n|---|---|---|---|---|---|---|---|\n")
         for k, v in j.items():
