@@ -220,6 +220,48 @@ def test_lanes_the_launch_bench_py_times(oracle):
     assert len({vs[i].tobytes() for i in range(n)}) == n, "500 different scans must give 500 different score vectors"
 
 
+def _a4_600_card(seed):
+    return synth.make_card(7016, 4960, seed)
+
+
+def test_lanes_a4_at_600_dpi(oracle):
+    """A batch of 600-dpi A4 scans (4960 x 7016, 34.8 MP each; 13 counter planes per word: more than 4095 rows) through
+    the scan-lane sweep at the full +-10 deg @ 0.05 deg sweep -- 18 GB of programs generated on the device --: 66 scans in
+    launches of 64 (a partial second launch), two of them against the oracle on all 400 candidates, every repeat of a card
+    bit-identical to its first copy, the reference's < 0.5 deg criterion (lib.rs:103-113) on all."""
+    import multiprocessing as mp
+    rows, cols, n = 7016, 4960, 66
+    with mp.get_context("spawn").Pool(min(3, os.cpu_count() or 1)) as pool:
+        base = pool.map(_a4_600_card, range(90, 93))
+    dev = torch.device("cuda:0")
+    buf = torch.empty((n, rows, cols), dtype=torch.uint8, device=dev)
+    tb = [torch.from_numpy(b[0]).to(dev) for b in base]
+    for i in range(n):
+        buf[i] = tb[i % 3]
+    del tb
+    A = 400
+    best = torch.zeros(n, dtype=torch.int32, device=dev)
+    vs = torch.zeros((n, A), dtype=torch.float64, device=dev)
+    hs = torch.zeros((n, A), dtype=torch.float64, device=dev)
+    b = projection.Batch(rows, cols, 10, 0.05, n_streams=1)
+    b.set_lanes(64)
+    assert b.lanes_program_bytes() > 15e9
+    b.run_device(buf.data_ptr(), rows * cols, cols, n, 127, best.data_ptr(), vs.data_ptr(), hs.data_ptr())
+    b.sync()
+    b.close()
+    del buf
+    torch.cuda.empty_cache()
+    best, vs, hs = best.cpu().numpy(), vs.cpu().numpy(), hs.cpu().numpy()
+    for i in range(n):
+        assert (vs[i].view(np.uint64) == vs[i % 3].view(np.uint64)).all() and (hs[i].view(np.uint64) == hs[i % 3].view(np.uint64)).all(), i
+        assert best[i] == best[i % 3] and abs((best[i] - 200) * 0.05 - base[i % 3][1]) < 0.5
+    for i in (1, 65):  # launch 0 / the partial launch 1
+        binimg = np.where(base[i % 3][0] <= 127, 0, 255).astype(np.uint8)
+        _, _, evs, ehs = oracle.sweep(binimg, 10, 0.05, threads=os.cpu_count() or 4, want_proj=False, fast=True)
+        assert (vs[i].view(np.uint64) == evs.view(np.uint64)).all() and (hs[i].view(np.uint64) == ehs.view(np.uint64)).all(), i
+        assert best[i] == oracle.argmax_path1(evs, ehs)[0]
+
+
 @pytest.mark.parametrize("n", [320, 467, 512])
 def test_lanes_five_to_eight_scan_groups_every_scan(oracle, n):
     """A small shape through the same launch form -- set_lanes(512), 4 x 4 workgroups, two quads of scan groups, 5 / 8
