@@ -656,15 +656,13 @@ int enqueue_sweep(const SweepTables &t, SweepScratch &s, int kernel_sel, const u
         OMR_HIP(launch_runs(ph, t.list_runs.as<int32_t>(), t.n_runs, s.guard.as<int32_t>(), vp, stream));
         s.guard_pending = true;
     }
-    for (int z = 0; z < scans && n_g > 0; z++) {  // the gather kernels take one scan per launch
-        const uint32_t *bz = s.bits.as<uint32_t>() + (size_t)z * d.rows * d.wpr;
-        uint32_t *vz = vp + (size_t)z * d.A * d.cols, *hz = hp + (size_t)z * d.A * d.rows;
+    if (n_g > 0) {  // the gathered candidates of ALL scans of the launch group in one launch
         if (gather_lds)
-            OMR_HIP(launch_sweep_lds(bz, d, t.adelta.as<int32_t>(), t.bdelta.as<int32_t>(), t.xy0.as<int2_t>(),
-                                     t.tiles.as<LdsTile>(), glist, n_g, vz, hz, stream));
+            OMR_HIP(launch_sweep_lds(s.bits.as<uint32_t>(), d, t.adelta.as<int32_t>(), t.bdelta.as<int32_t>(), t.xy0.as<int2_t>(),
+                                     t.tiles.as<LdsTile>(), glist, n_g, vp, hp, stream, scans));
         else
-            OMR_HIP(launch_sweep_generic(bz, d, t.adelta.as<int32_t>(), t.bdelta.as<int32_t>(), t.xy0.as<int2_t>(), glist,
-                                         n_g, vz, hz, stream));
+            OMR_HIP(launch_sweep_generic(s.bits.as<uint32_t>(), d, t.adelta.as<int32_t>(), t.bdelta.as<int32_t>(), t.xy0.as<int2_t>(), glist,
+                                         n_g, vp, hp, stream, scans));
     }
     if (ev1) OMR_HIP(hipEventRecord(ev1, stream));
     if (post_stream && ev_mid) {

@@ -156,12 +156,18 @@ hipError_t launch_tables(const double *d_Minv, SweepDims d, int round_delta, int
 __global__ __launch_bounds__(GEN_WAVES *OMR_WAVE) void sweep_generic_kernel(
     const uint32_t *__restrict__ bits, SweepDims d, const int32_t *__restrict__ adelta,
     const int32_t *__restrict__ bdelta, const int2_t *__restrict__ xy0, const int32_t *__restrict__ list,
-    uint32_t *__restrict__ vproj, uint32_t *__restrict__ hproj)
+    uint32_t *__restrict__ vproj, uint32_t *__restrict__ hproj, int ntx)
 {
     __shared__ uint32_t hacc[GEN_BAND];
     const int a = list ? list[blockIdx.z] : (int)blockIdx.z;
     const int lane = threadIdx.x & 63;
-    const int x = blockIdx.x * (GEN_WAVES * OMR_WAVE) + threadIdx.x;
+    // blockIdx.x = scan of the launch * ntx + tile across: the scans of a launch group share one launch (one launch per scan
+    // left a 248 x 230 sheet's 319 gathered candidates with 319 half-empty workgroups per launch)
+    const int zs = blockIdx.x / ntx, bx = blockIdx.x - zs * ntx;
+    bits += (int64_t)zs * d.rows * d.wpr;
+    vproj += (int64_t)zs * d.A * d.cols;
+    hproj += (int64_t)zs * d.A * d.rows;
+    const int x = bx * (GEN_WAVES * OMR_WAVE) + threadIdx.x;
     const int y0 = blockIdx.y * GEN_BAND;
     const int y1 = min(d.rows, y0 + GEN_BAND);
     const bool active = x < d.cols;
@@ -200,13 +206,14 @@ __global__ __launch_bounds__(GEN_WAVES *OMR_WAVE) void sweep_generic_kernel(
 
 hipError_t launch_sweep_generic(const uint32_t *d_bits, SweepDims d, const int32_t *d_adelta,
                                 const int32_t *d_bdelta, const int2_t *d_xy0, const int32_t *d_list, int n_list,
-                                uint32_t *d_vproj, uint32_t *d_hproj, hipStream_t s)
+                                uint32_t *d_vproj, uint32_t *d_hproj, hipStream_t s, int scans)
 {
     const int nz = d_list ? n_list : d.A;
-    if (nz <= 0) return hipSuccess;
-    dim3 grid((d.cols + GEN_WAVES * OMR_WAVE - 1) / (GEN_WAVES * OMR_WAVE), (d.rows + GEN_BAND - 1) / GEN_BAND, nz);
+    if (nz <= 0 || scans <= 0) return hipSuccess;
+    const int ntx = (d.cols + GEN_WAVES * OMR_WAVE - 1) / (GEN_WAVES * OMR_WAVE);
+    dim3 grid(ntx * scans, (d.rows + GEN_BAND - 1) / GEN_BAND, nz);
     hipLaunchKernelGGL(sweep_generic_kernel, grid, dim3(GEN_WAVES * OMR_WAVE), 0, s, d_bits, d, d_adelta, d_bdelta,
-                       d_xy0, d_list, d_vproj, d_hproj);
+                       d_xy0, d_list, d_vproj, d_hproj, ntx);
     return hipGetLastError();
 }
 
@@ -220,18 +227,26 @@ hipError_t launch_sweep_generic(const uint32_t *d_bits, SweepDims d, const int32
 #define LDS_BAND 512
 #define LDS_SLAB_WORDS 1024  // per-wave window budget (4 KiB)
 
-__global__ __launch_bounds__(LDS_WAVES *OMR_WAVE) void sweep_lds_kernel(
+// (LW waves = 64 LW columns per workgroup: 8, or 4 for images of at most 256 columns -- the app's 248 x 230 working size --
+// whose other four waves would sit idle on 16 KB of LDS slabs)
+template <int LW>
+__global__ __launch_bounds__(LW *OMR_WAVE) void sweep_lds_kernel(
     const uint32_t *__restrict__ bits, SweepDims d, const int32_t *__restrict__ adelta,
     const int32_t *__restrict__ bdelta, const int2_t *__restrict__ xy0, const LdsTile *__restrict__ tiles,
-    const int32_t *__restrict__ list, uint32_t *__restrict__ vproj, uint32_t *__restrict__ hproj)
+    const int32_t *__restrict__ list, uint32_t *__restrict__ vproj, uint32_t *__restrict__ hproj, int ntx)
 {
-    __shared__ uint32_t slab_all[LDS_WAVES * LDS_SLAB_WORDS];
+    __shared__ uint32_t slab_all[LW * LDS_SLAB_WORDS];
     __shared__ uint32_t hacc[LDS_BAND];
     const int a = list ? list[blockIdx.z] : (int)blockIdx.z;
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     uint32_t *slab = slab_all + wave * LDS_SLAB_WORDS;
-    const int xw = blockIdx.x * (LDS_WAVES * OMR_WAVE) + wave * OMR_WAVE;  // wave's first column
+    // blockIdx.x = scan of the launch * ntx + tile across (see sweep_generic_kernel)
+    const int zs = blockIdx.x / ntx, bx = blockIdx.x - zs * ntx;
+    bits += (int64_t)zs * d.rows * d.wpr;
+    vproj += (int64_t)zs * d.A * d.cols;
+    hproj += (int64_t)zs * d.A * d.rows;
+    const int xw = bx * (LW * OMR_WAVE) + wave * OMR_WAVE;  // wave's first column
     const int x = xw + lane;
     const int y0 = blockIdx.y * LDS_BAND;
     const int y1 = min(d.rows, y0 + LDS_BAND);
@@ -248,7 +263,7 @@ __global__ __launch_bounds__(LDS_WAVES *OMR_WAVE) void sweep_lds_kernel(
     const int slab_byte = wave * LDS_SLAB_WORDS * 4;
     const unsigned long long active_mask = __ballot(active);
 
-    for (int i = threadIdx.x; i < LDS_BAND; i += LDS_WAVES * OMR_WAVE) hacc[i] = 0;
+    for (int i = threadIdx.x; i < LDS_BAND; i += LW * OMR_WAVE) hacc[i] = 0;
     __syncthreads();
 
     uint32_t vacc = 0;
@@ -364,7 +379,7 @@ __global__ __launch_bounds__(LDS_WAVES *OMR_WAVE) void sweep_lds_kernel(
         if (hbase < y1 && lane < y1 - hbase && hrow) atomicAdd(&hacc[hbase - y0 + lane], (uint32_t)hrow);
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < y1 - y0; i += LDS_WAVES * OMR_WAVE) {
+    for (int i = threadIdx.x; i < y1 - y0; i += LW * OMR_WAVE) {
         const uint32_t v = hacc[i];
         if (v) atomicAdd(&hproj[(int64_t)a * d.rows + y0 + i], v);
     }
@@ -373,13 +388,20 @@ __global__ __launch_bounds__(LDS_WAVES *OMR_WAVE) void sweep_lds_kernel(
 
 hipError_t launch_sweep_lds(const uint32_t *d_bits, SweepDims d, const int32_t *d_adelta, const int32_t *d_bdelta,
                             const int2_t *d_xy0, const LdsTile *d_tiles, const int32_t *d_list, int n_list,
-                            uint32_t *d_vproj, uint32_t *d_hproj, hipStream_t s)
+                            uint32_t *d_vproj, uint32_t *d_hproj, hipStream_t s, int scans)
 {
     const int nz = d_list ? n_list : d.A;
-    if (nz <= 0) return hipSuccess;
-    dim3 grid((d.cols + LDS_WAVES * OMR_WAVE - 1) / (LDS_WAVES * OMR_WAVE), (d.rows + LDS_BAND - 1) / LDS_BAND, nz);
-    hipLaunchKernelGGL(sweep_lds_kernel, grid, dim3(LDS_WAVES * OMR_WAVE), 0, s, d_bits, d, d_adelta, d_bdelta, d_xy0,
-                       d_tiles, d_list, d_vproj, d_hproj);
+    if (nz <= 0 || scans <= 0) return hipSuccess;
+    if (d.cols <= 4 * OMR_WAVE) {
+        dim3 grid(scans, (d.rows + LDS_BAND - 1) / LDS_BAND, nz);
+        hipLaunchKernelGGL(sweep_lds_kernel<4>, grid, dim3(4 * OMR_WAVE), 0, s, d_bits, d, d_adelta, d_bdelta, d_xy0, d_tiles, d_list,
+                           d_vproj, d_hproj, 1);
+        return hipGetLastError();
+    }
+    const int ntx = (d.cols + LDS_WAVES * OMR_WAVE - 1) / (LDS_WAVES * OMR_WAVE);
+    dim3 grid(ntx * scans, (d.rows + LDS_BAND - 1) / LDS_BAND, nz);
+    hipLaunchKernelGGL(sweep_lds_kernel<LDS_WAVES>, grid, dim3(LDS_WAVES * OMR_WAVE), 0, s, d_bits, d, d_adelta, d_bdelta, d_xy0,
+                       d_tiles, d_list, d_vproj, d_hproj, ntx);
     return hipGetLastError();
 }
 

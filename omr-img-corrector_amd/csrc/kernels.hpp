@@ -39,14 +39,14 @@ hipError_t launch_tables(const double *d_Minv, SweepDims d, int round_delta, int
 // vproj [A][cols], hproj [A][rows] must be zero on entry (integer atomics).
 hipError_t launch_sweep_generic(const uint32_t *d_bits, SweepDims d, const int32_t *d_adelta,
                                 const int32_t *d_bdelta, const int2_t *d_xy0, const int32_t *d_list,
-                                int n_list, uint32_t *d_vproj, uint32_t *d_hproj, hipStream_t s);
+                                int n_list, uint32_t *d_vproj, uint32_t *d_hproj, hipStream_t s, int scans = 1);
 
 // LDS-staged sweep (rotation-like matrices whose per-wave source window fits the LDS budget).
 // d_list (may be NULL = all candidates): the candidates to sweep, n_list of them.
 hipError_t launch_sweep_lds(const uint32_t *d_bits, SweepDims d, const int32_t *d_adelta,
                             const int32_t *d_bdelta, const int2_t *d_xy0, const LdsTile *d_tiles,
                             const int32_t *d_list, int n_list, uint32_t *d_vproj, uint32_t *d_hproj,
-                            hipStream_t s);
+                            hipStream_t s, int scans = 1);  // scans: bit images rows x wpr apart, projections A x cols / A x rows apart
 
 // ---- run-merging ("S") sweep ---------------------------------------------------------------
 // For every listed candidate the kernel builds 32 destination pixels at a time,
