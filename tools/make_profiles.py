@@ -203,12 +203,26 @@ with open(os.path.join(dst, tag + "_deskew.md"), "w") as f:
     stats_table("deskew_stats", f, 8)
     f.write("\nHBM-side traffic (FETCH_SIZE and WRITE_SIZE each in a pass of its own) against the algorithmic bytes (scan in once + canvas out once):\n\n")
     hbm_table("deskew_fetch", "deskew_write", f, needles=("deskew_warp_kernel",))
+    if read("deskew64.log"):
+        f.write("\n## 64 scans per launch (`python3 tools/bench_deskew.py 6 64`: the per-tile records' kernel and the launch overhead amortised)\n\n```\n%s```\n\n"
+                % "\n".join(l for l in read("deskew64.log").splitlines() if "amdgpu.ids" not in l))
+        stats_table("deskew64_stats", f, 8)
 
 # ---- micro-benchmark behind DESIGN.md's LDS-DMA statements
 if read("lds_dma_window.log"):
     with open(os.path.join(dst, tag + "_lds_dma.md"), "w") as f:
         f.write("# %s -- LDS-DMA probe behind DESIGN.md section 4.1 (tools/lds_dma_window.hip)\n\n" % tag + STAMP)
         f.write("```\n%s```\n" % read("lds_dma_window.log"))
+
+if read("mov64_probe.log") or read("pf_probe.log"):
+    with open(os.path.join(dst, tag + "_slane_microbench.md"), "w") as f:
+        f.write("# %s -- probes behind two statements of DESIGN.md section 4.6\n\n" % tag + STAMP)
+        f.write("`tools/mov64_probe.hip`: does `v_mov_b64` take a DST_REL index of the VGPR index mode?  (The ring commits of program format v3 "
+                "move a pair of landing registers with one instruction.)\n\n```\n%s```\n\n" % read("mov64_probe.log"))
+        f.write("`tools/pf_probe.hip`: `global_load_dword vdst, voffset, s[base:base+1]` under a partial EXEC and the index mode, step by step "
+                "(the first prefetch attempt of round 5 used this form and faulted inside the sweep kernel; in isolation every step passes -- the "
+                "kernel's prefetch now goes through a buffer descriptor whose range check drops every lane it is not meant to load).\n\n```\n%s```\n"
+                % read("pf_probe.log"))
 
 # ---- stages / fft / hough / calls
 with open(os.path.join(dst, tag + "_stages.md"), "w") as f:
@@ -286,6 +300,12 @@ with open(os.path.join(dst, tag + "_calls.md"), "w") as f:
         "\n".join(l for l in read("calls.log").splitlines() if "amdgpu.ids" not in l) + "\n",
         "\n".join(l for l in read("host.log").splitlines() if "amdgpu.ids" not in l) + "\n",
         "\n".join(l for l in read("threads.log").splitlines() if "amdgpu.ids" not in l) + "\n"))
+    if read("ksmall.log"):
+        f.write("\nThe app's default sweep as a batch (+-45 deg @ 0.2 deg = 450 candidates on 248 x 230 working images, getLibParams.ts:30-60), "
+                "`python3 tools/ksmall.py 4096 64`:\n\n```\n%s\n```\n" % "\n".join(l for l in read("ksmall.log").splitlines() if "amdgpu.ids" not in l))
+    if read("klanes600.log"):
+        f.write("\nA batch of 600-dpi A4 scans (4960 x 7016) through the scan-lane sweep, `python3 tools/klanes.py 128 64 2 7016 4960`:\n\n```\n%s\n```\n"
+                % "\n".join(l for l in read("klanes600.log").splitlines() if "amdgpu.ids" not in l))
 cp = "\n".join(l for l in read("core_protocol.log").splitlines() if "amdgpu.ids" not in l)
 if cp.strip():
     with open(os.path.join(dst, tag + "_core_protocol.md"), "w") as f:

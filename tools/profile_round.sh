@@ -65,6 +65,10 @@ elif [ "$PART" = "a" ]; then
   step calls timeout -k 10 300 python3 tools/bench_calls.py
   step host timeout -k 10 300 python3 tools/bench_host.py 512 3
   step threads timeout -k 10 300 python3 tools/bench_threads.py
+  step ksmall timeout -k 10 300 python3 tools/ksmall.py 4096 64
+  step klanes600 timeout -k 10 300 python3 tools/klanes.py 128 64 2 7016 4960
+  step deskew64 timeout -k 10 300 python3 tools/bench_deskew.py 6 64
+  prof deskew64_stats --stats -- python3 tools/bench_deskew.py 6 64
 else
   # 5. stage kernels, FFT, Hough: un-profiled numbers, kernel stats, FETCH_SIZE / WRITE_SIZE each alone
   step stages timeout -k 10 300 python3 tools/bench_stages.py 30
@@ -92,8 +96,8 @@ else
   echo "[profile] hough done"
   step core_protocol timeout -k 10 600 python3 tools/core_protocol.py
   # 6. micro-benchmarks behind DESIGN.md's statements
-  for t in lds_dma_window; do
-    hipcc -O2 --offload-arch=gfx950 tools/$t.hip -o /tmp/$t > "$OUT/$t.build.log" 2>&1 && timeout -k 10 200 /tmp/$t > "$OUT/$t.log" 2>&1 || true
+  for t in lds_dma_window mov64_probe pf_probe; do
+    rm -f "$OUT/$t.log"; hipcc -O2 --offload-arch=gfx950 -Wno-inline-asm tools/$t.hip -o /tmp/$t > "$OUT/$t.build.log" 2>&1 && timeout -k 10 200 /tmp/$t > "$OUT/$t.log" 2>&1 || true
   done
 fi
 echo "[profile] part $PART done"
