@@ -403,7 +403,7 @@ def main():
     if args.cards:
         cards = np.load(args.cards)
         D = cards.shape[0]
-        thetas = [0.0] * D
+        thetas = None  # (cards from a file carry no injected angles: the accuracy check is the un-profiled run's)
     else:
         cards, thetas = make_cards(D, 2 + rank_env * D)  # seed 2 = C2's card
     pmc_res = None
@@ -535,7 +535,7 @@ def main():
     out = None
     if rank == 0:
         detected = [(int(k) - N) * STEP for k in best.cpu().tolist()]
-        acc_ok = all(abs(d - thetas[order[i]]) < 0.5 for i, d in enumerate(detected))  # lib.rs:103-113
+        acc_ok = all(abs(d - thetas[order[i]]) < 0.5 for i, d in enumerate(detected)) if thetas else None  # lib.rs:103-113
         out = base_record(args, world, value, elapsed, B, A, G, D, "scan-lane" if lanes_mode else "run-merging")
         if deskew:
             out["deskew_images_per_s"] = deskew["linear"]
@@ -698,7 +698,7 @@ def main():
         # the bench fails on its own checks (round-4 verdict, weak 10): no `value` with exit code 0 from a kernel that
         # misses the reference's criterion (lib.rs:103-113) or differs from the oracle
         problems = []
-        if not out.get("accuracy_ok", True):
+        if out.get("accuracy_ok") is False:
             problems.append("accuracy_ok is false (a detected angle is >= 0.5 deg from the injected one)")
         if "cpu_baseline" in out and not out["cpu_baseline"].get("parity_vs_gpu", True):
             problems.append("cpu_baseline.parity_vs_gpu is false (GPU scores differ from the oracle's)")
