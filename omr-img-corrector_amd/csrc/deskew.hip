@@ -97,7 +97,9 @@ __global__ __launch_bounds__(64) void deskew_tiles_kernel(const DeskewPass p, De
         const int bwb = bb1 - bb0, bh = by1 - by0 + 1;
         // (a scan whose rows are not whole aligned dwords -- width, pitch or address not a multiple of 4 -- takes the
         // unstaged path: the staging loop then has no partial dwords and no branches)
-        const bool dwords = ((p.sstep | p.scan_stride | (int64_t)(uintptr_t)p.src | (int64_t)p.scols) & 3) == 0;
+        // ... nor a scan of 2 GB or more: the staging loads address it by 32-bit byte offsets through a buffer descriptor
+        const bool dwords = ((p.sstep | p.scan_stride | (int64_t)(uintptr_t)p.src | (int64_t)p.scols) & 3) == 0 &&
+                            (int64_t)p.srows * p.sstep < (int64_t)0x7fffffff;
         const bool staged = dwords && bwb > 0 && bh > 0 && (int64_t)bwb * bh <= DW_LDS && bx0 > -30000 && bx1 < 30000 &&
                             by0 > -30000 && by1 < 30000;
         // A tile whose box lies wholly outside the scan (the corners of a CONTAIN canvas: up to a fifth of it at 10 degrees)
