@@ -117,7 +117,36 @@ def word(out, k, sset, S, dreg, tag, E=None):
         out.append("%s:" % tag)
 
 
-def commit_and_fetch(out, x, tset):
+def words2(out, sset, S, d0, d1, E, t):
+    """Both words of a row, group by group (a group = up to four segments of either word): the indexed reads of word 0 go to
+    the four window registers, those of word 1 to the row's four LANDING registers -- they were committed a moment ago and this
+    row's loads are issued only after the words (fetch()) --, so ONE `s_mov m0, 0` serves the funnel shifts of both words and
+    the two words' chains are independent instruction streams.  Word 1's second shifts come out of vcc."""
+    E = E or S
+    pk = lambda k, j: "s%d" % (sset + k * S + j)
+    X = (XR, (t, t + 1, t + 2, t + 3))
+    D = (d0, d1)
+    Q = ("s10", "s11"), ("vcc_lo", "vcc_hi")
+    groups = [list(range(0, min(E, 4)))] + ([list(range(4, E))] if E > 4 else [])
+    for g, js in enumerate(groups):
+        for k in range(2):
+            for n, j in enumerate(js):
+                out.append("s_lshr_b32 m0, %s, 5" % pk(k, j))        # ring index + SRC0_REL | SRC1_REL
+                out.append("v_alignbit_b32 v%d, v%d, v%d, %s" % (X[k][n], RING + 1, RING, pk(k, j)))
+        out.append("s_mov_b32 m0, 0")
+        for n, j in enumerate(js):
+            for k in range(2):
+                if n % 2 == 0:  # the pair (j, j + 1) sits in an even-aligned SGPR pair: sets and laid-out slot counts are even
+                    out.append("s_lshr_b64 %s, s[%d:%d], 21" % ("s[10:11]" if k == 0 else "vcc", sset + k * S + j, sset + k * S + j + 1))
+            for k in range(2):
+                q = Q[k][n & 1]
+                if g == 0 and n == 0:
+                    out.append("v_lshlrev_b32 v%d, %s, v%d" % (D[k], q, X[k][n]))
+                else:
+                    out.append("v_alignbit_b32 v%d, v%d, v%d, %s" % (D[k], X[k][n], D[k], q))
+
+
+def commit(out, x, tset):
     """x = record set of this row; loads return in order: at most (AHEAD - 1) * 4 younger loads may still fly when this
     row's landing set has arrived (row-count atomics in flight only make the wait longer).  The four loads of a row are two
     PAIRS -- two adjacent word columns of one source row in an aligned pair of landing registers -- and a pair is committed
@@ -130,8 +159,13 @@ def commit_and_fetch(out, x, tset):
             break
         out.append(ins)                                          # even ring register | DST_REL
         out.append("v_mov_b64 v[%d:%d], v[%d:%d]" % (RING, RING + 1, t + 2 * f, t + 2 * f + 1))
-    # (M0 is left as it is: the loads below are not vector-ALU instructions -- the index mode does not touch them -- and the
-    # next vector-ALU instruction is a word's first indexed v_alignbit, right behind its own M0 write)
+    # (M0 is left as it is: the next vector-ALU instruction is a word's first indexed v_alignbit, right behind its own M0 write)
+
+
+def fetch(out, x, tset):
+    """this row's four loads into its landing set, issued BEHIND the row's words (which borrow the landing registers as
+    window registers of word 1): they have until the commit four rows on"""
+    t = T0 + 4 * tset
     for f in range(4):
         if "nofetch" not in ABLATE:
             if "hotfetch" in ABLATE:  # timing probe: every source load reads entry 0 (always in the vector cache): what the source fetch's latency costs
@@ -316,10 +350,15 @@ def body(o, S, L):
                 rec_loads(o, (r + 2) % 4, S, r + 2)
                 rec_loads(o, (r + 3) % 4, S, r + 3)
             odd = r & 1
-            commit_and_fetch(o, r % 4, r % 4)
+            commit(o, r % 4, r % 4)
             d = (ST[0], ST[1]) if not odd else DODD
-            word(o, 0, SEG[r % 4], S, d[0], "L%s_e%d_r%dw0" % (L, E, r), Ex)
-            word(o, 1, SEG[r % 4], S, d[1], "L%s_e%d_r%dw1" % (L, E, r), Ex)
+            if "words1" in ABLATE:  # (round 5's first form: one word after the other, the loads in front of them)
+                fetch(o, r % 4, r % 4)
+                word(o, 0, SEG[r % 4], S, d[0], "L%s_e%d_r%dw0" % (L, E, r), Ex)
+                word(o, 1, SEG[r % 4], S, d[1], "L%s_e%d_r%dw1" % (L, E, r), Ex)
+            else:
+                words2(o, SEG[r % 4], S, d[0], d[1], Ex, T0 + 4 * (r % 4))
+                fetch(o, r % 4, r % 4)
             row_count(o, d[0], d[1], odd == 1, r // 2)
             if odd:
                 carry_save(o, "L%s_e%d_cs%d" % (L, E, r), (r & 2) != 0, r // 4)
