@@ -68,6 +68,16 @@ for c in range(batches):
         if not ((v[i].view(np.uint64) == evs.view(np.uint64)).all() and (h[i].view(np.uint64) == ehs.view(np.uint64)).all()
                 and bs[i] == orc.argmax_path1(evs, ehs)[0]):
             bad.append(("scores", c, i, rows, cols, max_angle, step, n, lanes))
+    # the same batch from HOST memory (omr_host_batch_run): binarised on the host, pageable u8 and PACKED transfers (the copier
+    # threads pack to 1 bit per pixel, slane_pack_bits_kernel interleaves) must reproduce the resident run's bits
+    if c % 3 == 0:
+        hostscans = [np.where(sc <= 127, 0, 255).astype(np.uint8) for sc in scans]
+        hb = projection.HostBatch(rows, cols, max_angle, step, n, n_devices=1)
+        for packed in (False, True):
+            hb_best, _, hb_v, hb_h = hb.run(hostscans, want_sd=True, packed=packed)
+            if not ((hb_best == bs).all() and (hb_v.view(np.uint64) == v.view(np.uint64)).all() and (hb_h.view(np.uint64) == h.view(np.uint64)).all()):
+                bad.append(("host batch", "packed" if packed else "pageable", c, rows, cols, max_angle, step, n))
+        hb.close()
     print("batch %d: %dx%d +-%d @ %g, %d scans in launches of %d: %d mismatches so far" % (c, rows, cols, max_angle, step, n, lanes, len(bad)),
           flush=True)
 print("batches", batches, "refused (-213)", refused, "scans checked", checked, "mismatches", len(bad), bad[:5])
