@@ -204,7 +204,7 @@ int omr_call_pool_stats(int32_t device, int32_t *live_slots, int32_t *idle_slots
  * word column, shift and destination bits make up every destination word (projection.rs:47-65 ->
  * transfer.rs:459-486) -- is one wave-uniform PROGRAM per (candidate, strip of two word columns), enumerated
  * from warpAffine's integer tables.  This entry point builds one strip's program on the HOST (no GPU needed):
- * n_records rows (pre_rows virtual ones first) of seg_dwords_per_row dwords in the segment stream and of 8 dwords
+ * n_records rows (pre_rows virtual ones first) of seg_dwords_per_row dwords in the segment stream and of 4 dwords
  * in the fetch stream (layout: csrc/slane.hpp); guard_cols / guard_rows = the zero guard (word columns, rows) the
  * program's entry numbers assume around the interleaved bit image.  NULL output pointers query the sizes.
  * OMR_ERR_NOTIMPL when the strip does not fit the scheme (such candidates stay with the run-merging kernel). */

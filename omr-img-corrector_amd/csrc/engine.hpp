@@ -172,6 +172,7 @@ struct SlaneScratch {
     bool keep_rows = false, rows_dirty = false;  // inspection: leave the row counts in place after a launch
     bool guard_pending = false;                  // slane_kernel was launched on this set since its guard flag was last read
     size_t rows_bytes = 0;                       // of hrows: the row counts and, behind them, the totals [candidate][scan]
+    uint32_t *bits_base = nullptr;  // the first scan group's bit image inside `bits` (aligned to SlaneGeom::group_stride())
     DevBuf bits, hrows, vproj, planes, descs[3], vsd, hsd, best, guard;  // descs[lg]: workgroups of (16 >> lg) strips x (1 << lg) scan groups
     int create(const SlanePlan &p, int groups);
 };

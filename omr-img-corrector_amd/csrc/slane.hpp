@@ -8,7 +8,10 @@
 // through the scalar unit; the only per-lane data is the scan's own bits.
 //
 //   bit image  : interleaved, entry E(s, c) = 64 dwords = word column c of source row s of the 64 scans of a
-//                scan group; entry 0 is all zero (dummy fetches); a zero guard of gx word columns and gy rows all round
+//                scan group; entry 0 is all zero (dummy fetches); a zero guard of gx word columns and gy rows all round.
+//                The images of the scan groups lie group_stride() bytes apart -- a power of two -- from a base aligned to it,
+//                so no image straddles a 4 GB boundary: the kernel forms a load's address by ONE 32-bit add to the image's
+//                base (below)
 //   strip      : SL_K = 2 adjacent destination word columns; a wave owns (scan group, candidate, strip) and
 //                walks ALL destination rows top to bottom
 //   ring       : the wave keeps the source entries it needs in 64 VGPRs: register (s & 15) * 4 + (c - cb(s));
@@ -18,16 +21,21 @@
 //                the first bits of word 0
 //   records    : one per destination row, plus SL_PRE virtual rows ahead of row 0 that only fill the ring and virtual
 //                rows at the end up to a multiple of 64.  Two streams per strip (format v3, round 5):
-//                  fetch stream, 8 dwords per row: 4 x (E << 8) = the byte offsets of the entries whose loads are
-//                                   ISSUED while this row is swept (0 = the all-zero entry: a dummy) -- two PAIRS: loads
-//                                   2 p and 2 p + 1 fetch two adjacent word columns of one source row into an aligned pair of
-//                                   landing registers --, then 1 dword = 2 x u16 (ring register | 0x8000) to COMMIT before
-//                                   this row: where the two pairs issued SL_AHEAD rows earlier belong -- an EVEN ring
-//                                   register: one v_mov_b64 with DST_REL moves a pair (an odd index is rounded down by the
-//                                   hardware, tools/mov64_probe.hip); register SL_DUMMY = 66 swallows a dummy pair; 0x8000
-//                                   = M0's DST_REL bit --, then 1 dword = the TURN HEADER: the most segments any word of
-//                                   the 16 rows from this record on needs (1 .. 8; the kernel reads it at the first record
-//                                   of a turn and executes exactly that many slots per word), then 2 unused dwords
+//                  fetch stream, 4 dwords per row (format v4): 2 x (E << 8) = the byte offsets of the first entries of the two
+//                                   PAIRS whose loads are ISSUED while this row is swept (0 = the all-zero entry: a dummy) -- a
+//                                   pair = entries E and E + 1, two adjacent word columns of one source row, into an aligned
+//                                   pair of landing registers.  The kernel adds the offset to the base of a copy of the
+//                                   image's buffer descriptor (one s_add_u32 per pair) and issues the two loads with the
+//                                   CONSTANT offsets 0 and 256: a vector-memory instruction whose offset comes out of an SGPR
+//                                   costs an issue turn more than one with a constant offset, 2.7 ms per launch
+//                                   (profiles/r05_lanes_ablation.md) --, then 1
+//                                   dword = 2 x u16 (ring register | 0x8000) to COMMIT before this row: where the two pairs
+//                                   issued SL_AHEAD rows earlier belong -- an EVEN ring register: one v_mov_b64 with DST_REL
+//                                   moves a pair (an odd index is rounded down by the hardware, tools/mov64_probe.hip);
+//                                   register SL_DUMMY = 66 swallows a dummy pair; 0x8000 = M0's DST_REL bit --, then 1 dword
+//                                   = the TURN HEADER: the most segments any word of the 16 rows from this record on needs
+//                                   (1 .. 8; the kernel reads it at the first record of a turn and executes exactly that
+//                                   many slots per word).  One s_load_dwordx4 per row
 //                  segment stream, SL_K words x S dwords per row.  A word is assembled from its segments in
 //                                   increasing bit order by funnel shifts, no masks:
 //                                     X = (ring[idx + 1] : ring[idx]) >> sh      (the segment's bits, bit 0 first)
@@ -50,8 +58,8 @@ namespace omr {
 constexpr int SL_K = 2;
 constexpr int SL_RING_ROWS = 16;
 constexpr int SL_RING_COLS = 4;
-constexpr int SL_FETCH = 4;                             // loads per row
-constexpr int SL_FREC = 8;                              // dwords per row of the fetch stream
+constexpr int SL_FETCH = 4;                             // loads (= landing registers) per row: SL_PAIRS pairs of adjacent entries
+constexpr int SL_FREC = 4;                              // dwords per row of the fetch stream
 constexpr int SL_AHEAD = 4;                             // rows between a load and its commit
 constexpr int SL_ZERO = SL_RING_ROWS * SL_RING_COLS;   // ring register that holds 0 (white runs read it)
 constexpr int SL_DUMMY = SL_ZERO + 2;                   // (even) register pair that swallows dummy fetch pairs
@@ -78,7 +86,7 @@ struct SlaneGeom {
                              // through the same run as its neighbours, so border words need no extra segments
     int colsG = 0, rowsG = 0;
     int NS = 0;              // strips
-    int64_t entries = 0;     // 1 + rowsG * colsG
+    int64_t entries = 0;     // 1 + rowsG * colsG (+ 1 spare in memory: the partner of a pair that starts at the last entry)
     void set(int r, int c, int guard_cols = SL_GX, int guard_rows = 0)
     {
         rows = r, cols = c, NW = (c + 31) / 32, off = (32 - c % 32) % 32, NS = (NW + SL_K - 1) / SL_K;
@@ -87,6 +95,13 @@ struct SlaneGeom {
         entries = 1 + (int64_t)rowsG * colsG;
     }
     int64_t entry(int s, int c) const { return 1 + (int64_t)(s + gy) * colsG + (c + gx); }
+    size_t image_bytes() const { return (size_t)(entries + 1) * SL_LANES * 4; }  // per scan group
+    size_t group_stride() const  // bytes between the images of two scan groups: the power of two that holds one
+    {
+        size_t st = 1 << 20;
+        while (st < image_bytes()) st <<= 1;
+        return st;
+    }
 };
 
 // how far the samples of a candidate reach outside the image: word columns / rows of guard it needs (from the four

@@ -111,10 +111,9 @@ __global__ __launch_bounds__(256) void slane_fill_kernel(SlaneBuild b, int ntask
         for (int j = 0; j < S; j++) seg[(int64_t)q * RD + k * S + j] = j == 0 ? white : pad;
     const uint32_t nocommit = (uint32_t)SL_DUMMY | SL_COMMIT_MODE;
     uint32_t *f = fet + (int64_t)q * SL_FREC;
-    f[0] = f[1] = f[2] = f[3] = 0u;
-    f[4] = nocommit | (nocommit << 16);
-    f[5] = 1u;  // turn header (slane_turns_kernel writes the real ones)
-    f[6] = f[7] = 0u;
+    f[0] = f[1] = 0u;
+    f[2] = nocommit | (nocommit << 16);
+    f[3] = 1u;  // turn header (slane_turns_kernel writes the real ones)
 }
 
 // thread = task.  used[task][nrec] starts 0, freg[task][nrec][4] starts SL_DUMMY (set by the host with hipMemset)
@@ -150,8 +149,7 @@ __global__ __launch_bounds__(64) void slane_sched_kernel(SlaneBuild b, int ntask
             const int q = rec + SL_PRE, u = used[q];
             freg[(int64_t)q * SL_FETCH + u] = (uint8_t)((s & (SL_RING_ROWS - 1)) * SL_RING_COLS + 2 * pr);
             const int64_t e0 = 1 + (int64_t)s * g.colsG + (lo + 2 * pr + g.gx);  // g.entry(s - gy, lo + 2 pr)
-            fet[(int64_t)q * SL_FREC + 2 * u] = (uint32_t)(e0 << 8);
-            fet[(int64_t)q * SL_FREC + 2 * u + 1] = 2 * pr + 1 < ncols ? (uint32_t)((e0 + 1) << 8) : 0u;
+            fet[(int64_t)q * SL_FREC + u] = (uint32_t)(e0 << 8);
             used[q] = (uint8_t)(u + 1);
         }
     }
@@ -161,7 +159,7 @@ __global__ __launch_bounds__(64) void slane_sched_kernel(SlaneBuild b, int ntask
     }
     for (int q = SL_AHEAD; q < b.nrec; q++) {  // what row q commits = what row q - SL_AHEAD fetched
         const uint8_t *fr = &freg[(int64_t)(q - SL_AHEAD) * SL_FETCH];
-        fet[(int64_t)q * SL_FREC + 4] = ((uint32_t)fr[0] | SL_COMMIT_MODE) | (((uint32_t)fr[1] | SL_COMMIT_MODE) << 16);
+        fet[(int64_t)q * SL_FREC + 2] = ((uint32_t)fr[0] | SL_COMMIT_MODE) | (((uint32_t)fr[1] | SL_COMMIT_MODE) << 16);
     }
 }
 
@@ -179,7 +177,7 @@ __global__ __launch_bounds__(256) void slane_turns_kernel(SlaneBuild b, int ntas
     uint32_t most = 1;
     for (int q = q0; q < q0 + SL_TURN && q < b.nrec; q++)
         for (int k = 0; k < SL_K; k++) most = max(most, (seg[(int64_t)q * RD + k * S] >> SL_NSHIFT) & 15u);
-    for (int q = q0; q < q0 + SL_TURN && q < b.nrec; q++) fet[(int64_t)q * SL_FREC + 5] = most;
+    for (int q = q0; q < q0 + SL_TURN && q < b.nrec; q++) fet[(int64_t)q * SL_FREC + 3] = most;
 }
 
 // grid (tasks, ceil(rows / 128))

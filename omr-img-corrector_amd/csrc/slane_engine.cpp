@@ -158,6 +158,8 @@ int SlanePlan::build(const SweepTables &t, bool on_host)
         }
     }
     g.set(d.rows, d.cols, gx, gy);
+    if (g.image_bytes() > 0xffffffffull)  // a pair's byte offset is a dword of the fetch stream, a scan group's image one buffer descriptor
+        return fail(OMR_ERR_NOTIMPL, "scan-lane sweep: the bit image of a scan group (%zu bytes with its guard) exceeds 4 GB", g.image_bytes());
     A = d.A;
     nrec = slane_records(d.rows);
     const int NS = g.NS;
@@ -201,9 +203,12 @@ int SlaneScratch::create(const SlanePlan &p, int groups)
     nsg = groups;
     const SlaneGeom &g = p.g;
     const size_t nscp = (size_t)nsg * SL_LANES, ntasks = p.tasks.size();
-    const size_t bits_b = sizeof(uint32_t) * (size_t)nsg * g.entries * SL_LANES;
+    // the scan groups' bit images, group_stride() (a power of two) apart from a base aligned to it: none straddles a 4 GB
+    // boundary, so the kernel's 32-bit add to a descriptor's base never carries (slane.hpp)
+    const size_t gstride = g.group_stride(), bits_b = ((size_t)nsg + 1) * gstride;
     OMR_HIP(bits.alloc(bits_b));
     OMR_HIP(hipMemset(bits.p, 0, bits_b));  // entry 0 and the guard columns stay zero for good
+    bits_base = (uint32_t *)(((uintptr_t)bits.p + gstride - 1) & ~(uintptr_t)(gstride - 1));
     // row counts, two records per dword, and behind them the black-pixel totals [candidate][scan] (added up by the
     // column-count kernel): both are accumulated with atomics, so every launch leaves them zero again
     rows_bytes = sizeof(uint32_t) * ((size_t)p.A * (p.nrec / 2) * nscp + (size_t)p.A * nscp);
@@ -249,10 +254,10 @@ int SlaneScratch::create(const SlanePlan &p, int groups)
                     k.hrsrc[2] = counts ? (uint32_t)((size_t)(p.nrec / 2) * nscp * 4 - (size_t)sg * SL_LANES * 4) : 0u;
                     k.hrsrc[3] = 0x00020000u;
                     k.planes = (uint64_t)planes.p + 4ull * ((real ? ti * nsg + sg : ntasks * nsg) * SL_K * SL_DUMP * SL_LANES);
-                    const uint64_t base = (uint64_t)bits.p + (counts ? 4ull * (uint64_t)sg * g.entries * SL_LANES : 0ull);
+                    const uint64_t base = (uint64_t)bits_base + (counts ? (uint64_t)sg * gstride : 0ull);
                     k.rsrc[0] = (uint32_t)base;
                     k.rsrc[1] = (uint32_t)(base >> 32) & 0xffffu;
-                    k.rsrc[2] = real ? (uint32_t)(g.entries * SL_LANES * 4) : 0u;
+                    k.rsrc[2] = real ? (uint32_t)g.image_bytes() : 0u;
                     k.rsrc[3] = 0x00020000u;
                     k.nrec = (uint32_t)p.nrec;
                     k.hpitch = (uint32_t)(nscp * 4);
@@ -285,8 +290,8 @@ int slane_enqueue(const SlanePlan &p, SlaneScratch &s, const uint8_t *d_img, int
         OMR_HIP(hipMemsetAsync(s.hrows.p, 0, s.rows_bytes, stream));
         s.rows_dirty = false;
     }
-    if (packed) OMR_HIP(launch_slane_pack_bits((const uint32_t *)d_img, scan_stride / 4, p.g, nscans, s.bits.as<uint32_t>(), stream));
-    else OMR_HIP(launch_slane_pack(d_img, scan_stride, step, p.g, nscans, black_max, s.bits.as<uint32_t>(), stream));
+    if (packed) OMR_HIP(launch_slane_pack_bits((const uint32_t *)d_img, scan_stride / 4, p.g, nscans, s.bits_base, stream));
+    else OMR_HIP(launch_slane_pack(d_img, scan_stride, step, p.g, nscans, black_max, s.bits_base, stream));
     if (ev0) OMR_HIP(hipEventRecord(ev0, stream));
     {   // the workgroup's composition: 16 strips x 1 scan group, 8 x 2 or 4 x 4 (the scratch holds a table for each)
         const int lg = used <= 1 ? 0 : used == 2 ? 1 : 2, sgw = 1 << lg, places = 16 >> lg;

@@ -60,10 +60,9 @@ void slane_null_program(int nrec, int cls, uint32_t *seg, uint32_t *fet)
     const uint32_t nocommit = (uint32_t)SL_DUMMY | SL_COMMIT_MODE;
     for (size_t q = 0; q < (size_t)nrec; q++) {
         uint32_t *f = fet + q * SL_FREC;
-        f[0] = f[1] = f[2] = f[3] = 0u;
-        f[4] = nocommit | (nocommit << 16);
-        f[5] = 1u;  // turn header: one segment per word
-        f[6] = f[7] = 0u;
+        f[0] = f[1] = 0u;                  // two dummy pairs
+        f[2] = nocommit | (nocommit << 16);
+        f[3] = 1u;                         // turn header: one segment per word
     }
 }
 
@@ -194,14 +193,13 @@ bool slane_strip_program(const SlaneGeom &g, const int32_t *ad, const int32_t *b
             const size_t q = (size_t)(rec + SL_PRE);
             const int u = used[q]++;
             freg[q * SL_PAIRS + (size_t)u] = (uint8_t)((s & (SL_RING_ROWS - 1)) * SL_RING_COLS + 2 * pr);
-            fet[q * SL_FREC + 2 * (size_t)u] = (uint32_t)(g.entry(s - g.gy, cmin[(size_t)s] + 2 * pr) << 8);
-            // (the second column of a row's last pair may not exist: the all-zero entry lands in a ring register no segment reads)
-            fet[q * SL_FREC + 2 * (size_t)u + 1] = 2 * pr + 1 < ncols ? (uint32_t)(g.entry(s - g.gy, cmin[(size_t)s] + 2 * pr + 1) << 8) : 0u;
+            // (the pair's second entry is fetched as well, needed or not: it lands in a ring register no segment reads then)
+            fet[q * SL_FREC + (size_t)u] = (uint32_t)(g.entry(s - g.gy, cmin[(size_t)s] + 2 * pr) << 8);
         }
     }
     for (int q = SL_AHEAD; q < NREC; q++) {  // what row q commits = what row q - SL_AHEAD fetched
         const uint8_t *fr = &freg[(size_t)(q - SL_AHEAD) * SL_PAIRS];
-        fet[(size_t)q * SL_FREC + 4] = ((uint32_t)fr[0] | SL_COMMIT_MODE) | (((uint32_t)fr[1] | SL_COMMIT_MODE) << 16);
+        fet[(size_t)q * SL_FREC + 2] = ((uint32_t)fr[0] | SL_COMMIT_MODE) | (((uint32_t)fr[1] | SL_COMMIT_MODE) << 16);
     }
     // ---- the rows' words
     for (int r = 0; r < R; r++)
@@ -227,7 +225,7 @@ bool slane_strip_program(const SlaneGeom &g, const int32_t *ad, const int32_t *b
         uint32_t most = 1;
         for (int q = q0; q < q0 + SL_TURN && q < NREC; q++)
             for (int k = 0; k < SL_K; k++) most = std::max(most, (seg[(size_t)q * RD + (size_t)k * S] >> SL_NSHIFT) & 15u);
-        for (int q = q0; q < q0 + SL_TURN && q < NREC; q++) fet[(size_t)q * SL_FREC + 5] = most;
+        for (int q = q0; q < q0 + SL_TURN && q < NREC; q++) fet[(size_t)q * SL_FREC + 3] = most;
     }
     return true;
 }

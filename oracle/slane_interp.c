@@ -7,15 +7,16 @@
 #include <stdint.h>
 #include <string.h>
 
-#define SL_FETCH 4
-#define SL_FREC 8
+#define SL_FETCH 4 /* landing registers per row: two pairs */
+#define SL_FREC 4
 #define SL_AHEAD 4
 #define SL_TURN 16
 #define SL_RING 68 /* 64 ring registers, register 64 holds 0 (65 is its upper neighbour), the pair 66 / 67 swallows dummy fetch pairs */
 
 /* seg: n_records rows of seg_dwords dwords (K words x S segments, pk = sh | idx << 5 | 0x60000 | q << 21 | n << 26 in the
- * first); fet: n_records rows of 8 dwords (format v3): 4 byte offsets (E << 8) whose loads are issued in this row -- two
- * PAIRS --, 1 dword = 2 x u16 (EVEN ring register | 0x8000): where the two pairs that landed in this row's set of landing
+ * first); fet: n_records rows of 4 dwords (format v4): 2 byte offsets (E << 8) of the first entries of the PAIRS whose loads are issued in this row
+ * -- a pair = entries e and e + 1, two adjacent word columns of one source row, into an aligned pair of landing registers --,
+ * 1 dword = 2 x u16 (EVEN ring register | 0x8000): where the two pairs that landed in this row's set of landing
  * registers (the loads of SL_AHEAD rows earlier) are committed before this row, as the kernel's v_mov_b64 does (an odd
  * index would be rounded down by the hardware: refused here), 1 dword = the turn header: the slots per word the kernel
  * executes during the SL_TURN rows from a turn's first record on (the slots past a word's own count are the generator's
@@ -38,20 +39,22 @@ int orc_slane_run_strip(const uint32_t *seg, int seg_dwords, const uint32_t *fet
         const int set = q % SL_AHEAD;
         /* commit what landed in this row's set of landing registers, then issue this row's loads into it */
         for (int pr = 0; pr < SL_FETCH / 2; pr++) {
-            const uint32_t m0 = (rec[SL_FETCH] >> (16 * pr)) & 0xffffu; /* M0 image: register | DST_REL */
+            const uint32_t m0 = (rec[2] >> (16 * pr)) & 0xffffu; /* M0 image: register | DST_REL */
             const uint32_t reg = m0 & 255u;
             if (reg + 1 >= SL_RING || (reg & 1u) || reg == 64u || (m0 >> 8) != 0x80u) return -1;
             memcpy(ring[reg], T[set][2 * pr], sizeof(uint32_t) * (size_t)lanes);
             memcpy(ring[reg + 1], T[set][2 * pr + 1], sizeof(uint32_t) * (size_t)lanes);
         }
         if (q % SL_TURN == 0) { /* the kernel reads the header at the first record of a turn */
-            turn_slots = (int)rec[SL_FETCH + 1];
+            turn_slots = (int)rec[3];
             if (turn_slots < 1 || turn_slots > S) return -1;
         }
-        for (int f = 0; f < SL_FETCH; f++) {
-            const int64_t e = rec[f] >> 8;
-            if (e >= n_entries || (rec[f] & 255u)) return -1;
-            memcpy(T[set][f], bits + e * lanes, sizeof(uint32_t) * (size_t)lanes);
+        for (int pr = 0; pr < SL_FETCH / 2; pr++) {
+            const int64_t e = rec[pr] >> 8;
+            if (e >= n_entries || (rec[pr] & 255u)) return -1;
+            memcpy(T[set][2 * pr], bits + e * lanes, sizeof(uint32_t) * (size_t)lanes);
+            if (e + 1 < n_entries) memcpy(T[set][2 * pr + 1], bits + (e + 1) * lanes, sizeof(uint32_t) * (size_t)lanes);
+            else memset(T[set][2 * pr + 1], 0, sizeof(uint32_t) * (size_t)lanes);
         }
         for (int k = 0; k < K; k++) {
             const uint32_t *w = seg + (int64_t)q * seg_dwords + k * S;

@@ -245,7 +245,7 @@ def test_lanes_a4_at_600_dpi(oracle):
     hs = torch.zeros((n, A), dtype=torch.float64, device=dev)
     b = projection.Batch(rows, cols, 10, 0.05, n_streams=1)
     b.set_lanes(64)
-    assert b.lanes_program_bytes() > 15e9
+    assert b.lanes_program_bytes() > 12e9  # (the point of the case: programs and offsets beyond 4 GB)
     b.run_device(buf.data_ptr(), rows * cols, cols, n, 127, best.data_ptr(), vs.data_ptr(), hs.data_ptr())
     b.sync()
     b.close()

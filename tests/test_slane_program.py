@@ -40,7 +40,7 @@ def strip_program(rows, cols, M, strip):
     if rc != 0:
         return None
     seg = np.zeros(rd.value * nrec.value, np.uint32)
-    fet = np.zeros(8 * nrec.value, np.uint32)
+    fet = np.zeros(4 * nrec.value, np.uint32)  # SL_FREC (slane.hpp, format v4)
     rc = L.omr_slane_strip_program(rows, cols, Mc.ctypes.data_as(f64p), strip, seg.ctypes.data_as(u32p),
                                    fet.ctypes.data_as(u32p), C.byref(rd), C.byref(nrec), C.byref(pre), C.byref(most), C.byref(gx),
                                    C.byref(gy))

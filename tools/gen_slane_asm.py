@@ -16,16 +16,21 @@ a segment is ONE dword (slane.hpp) -- no masks, a word is assembled by funnel sh
     X = v_alignbit(ring[idx + 1], ring[idx], sh)      (VGPR index mode: M0 = pk >> 5)
     D = X << q  (first segment)   |   D = v_alignbit(X, D, q)  (the others: X's low q bits enter at the top)
 Per row:  wait until the loads issued four rows ago have landed (counted: vector loads return in order) -> commit them
-into the ring (two v_mov_b64 with DST_REL: a row's four loads are two pairs of adjacent word columns, tools/mov64_probe.hip
-showed that a 64-bit move takes an even index) -> issue this row's four loads -> two words -> row count (pairs of rows meet the
+into the ring (two v_mov_b64 with DST_REL: a row's two loads each bring a pair of adjacent word columns, tools/mov64_probe.hip
+showed that a 64-bit move takes an even index) -> two words -> issue this row's loads: per pair ONE s_add_u32 moves the base of
+the descriptor copy s[96:99] to the pair's first entry and two loads with the constant offsets 0 / 256 follow (format v4) -- a
+vector-memory instruction whose offset comes out of an SGPR costs an issue turn more than one with a constant offset, 2.7 ms
+per launch with four loads per row (profiles/r05_lanes_ablation.md); the images of the scan groups are placed so that the add
+never carries (slane.hpp) -> row count (pairs of rows meet the
 workgroup's other strips in LDS; one global atomic per pair row and block of BLOCK rows) -> (odd rows) carry-save column counters.
 
 Register map (fixed; the statement clobbers s0-s13, s16-s101, v1-v127, so lane * 4 arrives in v0):
   s[0:1] segment stream  s[2:3] fetch stream  s[4:7] bit-image descriptor  s8 rows left (a multiple of 64 at the start:
   row phases are taken from -s8)  s9 pair rows the wave flushes (first in bits 4:0, number in bits 11:8) | LDS base of the scan group's accumulators (a multiple of 4096)
   s[10:11] second shifts of a segment pair / scratch  s[14:15] the task (input)
-  segment sets A-D: s[16:31] s[32:47] s[48:63] s[64:79]   fetch offsets A-D: s[80:83] s[84:87] s[88:91] s[92:95]
-  commit word + turn header A-D: s[96:97] s[98:99] s[100:101] s[12:13]
+  segment sets A-D: s[16:31] s[32:47] s[48:63] s[64:79]   fetch records A-D (two pair offsets, commit word, turn header):
+  s[80:83] s[84:87] s[88:91] s[92:95]   s[96:99] the image's descriptor with the base moved to the pair being loaded
+  (s[100:101], s[12:13]: free since format v4)
   v[1:18] / v[19:36] column counters of word 0 / 1: planes p0..p12, pending carries c0..c4
   v37 LDS address of the turn's row-count slots  v38 odd row's count / fourth aligned window  v39 row count
   v40 / v41 odd row's words  v42 a carry  v43 free  v[44:59] four landing sets of four entries  v[60:123] ring
@@ -58,6 +63,9 @@ LB = {16: 4, 32: 5, 64: 6}[BLOCK]
 TURN = int(os.environ.get("SLANE_TURN", "16"))  # rows per turn of the loop (4, 8 or 16): the loop's own scalar work is paid once per turn
 ABLATE = os.environ.get("SLANE_ABLATE", "").split(",")  # timing probes only (results are wrong except noskip): norec, noatomic, nofetch, noskip
 PREFETCH = int(os.environ.get("SLANE_PREFETCH", "1"))  # turns ahead the record streams are pulled into L2 by a vector load (0 = off)
+LOADBITS = os.environ.get("SLANE_LOADBITS", "")  # cache-policy bits of the source loads (measured: profiles/r05_lanes_ablation.md)
+if LOADBITS:
+    LOADBITS = " " + LOADBITS
 PFREG = 43                     # its landing register (never read)
 RING = 60
 T0 = 44
@@ -73,8 +81,9 @@ NST = 5
 NDUMP = 2 * NPL                # registers dumped: the planes of either word (the parked carries are spent: the number of
                                # rows is a multiple of 64)
 SEG = (16, 32, 48, 64)         # segment sets A..D
-FOFF = (80, 84, 88, 92)        # fetch offsets of sets A..D
-FCOM = (96, 98, 100, 12)       # commit pairs of sets A..D
+FOFF = (80, 84, 88, 92)        # fetch records of sets A..D: two pair offsets, the commit word, the turn header
+NLOAD = 4                      # loads per row
+RSRC = 96                      # s[96:99]: the image's descriptor, its base moved to the pair being loaded (num_records = the pair)
 AHEAD = 4
 
 
@@ -129,14 +138,17 @@ def words2(out, sset, S, d0, d1, E, t):
     Q = ("s10", "s11"), ("vcc_lo", "vcc_hi")
     groups = [list(range(0, min(E, 4)))] + ([list(range(4, E))] if E > 4 else [])
     for g, js in enumerate(groups):
+        if "nom0" in ABLATE:  # timing probe: what the M0 writes in front of the indexed reads cost (every window reads ring 0 / 1)
+            out.append("s_mov_b32 m0, 0x3000")
         for k in range(2):
             for n, j in enumerate(js):
-                out.append("s_lshr_b32 m0, %s, 5" % pk(k, j))        # ring index + SRC0_REL | SRC1_REL
+                if "nom0" not in ABLATE:
+                    out.append("s_lshr_b32 m0, %s, 5" % pk(k, j))        # ring index + SRC0_REL | SRC1_REL
                 out.append("v_alignbit_b32 v%d, v%d, v%d, %s" % (X[k][n], RING + 1, RING, pk(k, j)))
         out.append("s_mov_b32 m0, 0")
         for n, j in enumerate(js):
             for k in range(2):
-                if n % 2 == 0:  # the pair (j, j + 1) sits in an even-aligned SGPR pair: sets and laid-out slot counts are even
+                if n % 2 == 0 and "noq" not in ABLATE:  # the pair (j, j + 1) sits in an even-aligned SGPR pair: sets and laid-out slot counts are even
                     out.append("s_lshr_b64 %s, s[%d:%d], 21" % ("s[10:11]" if k == 0 else "vcc", sset + k * S + j, sset + k * S + j + 1))
             for k in range(2):
                 q = Q[k][n & 1]
@@ -152,8 +164,9 @@ def commit(out, x, tset):
     PAIRS -- two adjacent word columns of one source row in an aligned pair of landing registers -- and a pair is committed
     by ONE v_mov_b64 with DST_REL to an even ring register (format v3: 2 + 2 instructions per row instead of 4 + 4)."""
     t = T0 + 4 * tset
-    out.append("s_waitcnt vmcnt(%d)" % ((AHEAD - 1) * 4))
-    c0 = FCOM[x]
+    if "nowait" not in ABLATE:  # (timing probe: what waiting for the landing set costs)
+        out.append("s_waitcnt vmcnt(%d)" % ((AHEAD - 1) * NLOAD))
+    c0 = FOFF[x] + 2
     for f, ins in enumerate(("s_and_b32 m0, s%d, 0xffff" % c0, "s_lshr_b32 m0, s%d, 16" % c0)):
         if "nocommit" in ABLATE:
             break
@@ -164,14 +177,21 @@ def commit(out, x, tset):
 
 def fetch(out, x, tset):
     """this row's four loads into its landing set, issued BEHIND the row's words (which borrow the landing registers as
-    window registers of word 1): they have until the commit four rows on"""
+    window registers of word 1): they have until the commit four rows on.  Per pair: the descriptor copy's base moves to the
+    pair's first entry (operands are read when an instruction is issued: the copy may be rewritten right behind a load), then
+    two loads with constant offsets."""
     t = T0 + 4 * tset
-    for f in range(4):
-        if "nofetch" not in ABLATE:
-            if "hotfetch" in ABLATE:  # timing probe: every source load reads entry 0 (always in the vector cache): what the source fetch's latency costs
-                out.append("buffer_load_dword v%d, %%[lane4], s[4:7], 0 offen" % (t + f))
-                continue
-            out.append("buffer_load_dword v%d, %%[lane4], s[4:7], s%d offen" % (t + f, FOFF[x] + f))
+    for f in range(2):
+        if "nofetch" in ABLATE:
+            break
+        if "hotsgpr" in ABLATE:  # timing probe (format v3's loads): the offset comes out of an SGPR (s7 = 0x20000), one hot line
+            out.append("buffer_load_dword v%d, %%[lane4], s[4:7], s7 offen" % (t + 2 * f))
+            out.append("buffer_load_dword v%d, %%[lane4], s[4:7], s7 offen" % (t + 2 * f + 1))
+            continue
+        if "hotfetch" not in ABLATE:  # (timing probe: every source load reads entries 0 / 1, always in the vector cache)
+            out.append("s_add_u32 s%d, s4, s%d" % (RSRC, FOFF[x] + f))
+        out.append("buffer_load_dword v%d, %%[lane4], s[%d:%d], 0 offen%s" % (t + 2 * f, RSRC, RSRC + 3, LOADBITS))
+        out.append("buffer_load_dword v%d, %%[lane4], s[%d:%d], 0 offen offset:256%s" % (t + 2 * f + 1, RSRC, RSRC + 3, LOADBITS))
 
 
 def row_count(out, d0, d1, odd, second):
@@ -294,8 +314,7 @@ def rec_loads(out, x, S, row, force=False):
         return
     nd = 2 * S  # segment dwords per row
     out.append("s_load_dwordx%d s[%d:%d], s[0:1], %d" % (nd, SEG[x], SEG[x] + nd - 1, row * nd * 4))
-    out.append("s_load_dwordx4 s[%d:%d], s[2:3], %d" % (FOFF[x], FOFF[x] + 3, row * 32))
-    out.append("s_load_dwordx2 s[%d:%d], s[2:3], %d" % (FCOM[x], FCOM[x] + 1, row * 32 + 16))
+    out.append("s_load_dwordx4 s[%d:%d], s[2:3], %d" % (FOFF[x], FOFF[x] + 3, row * 16))
 
 
 def body(o, S, L):
@@ -319,7 +338,7 @@ def body(o, S, L):
         # and nothing can be read that was not meant to be.  Loads return in order, so the counted vmcnt waits of
         # commit_and_fetch stay correct (two more loads among the younger ones only make them stricter for a few rows);
         # v43 is never read.
-        seg_b, fet_b = TURN * 2 * S * 4, TURN * 32
+        seg_b, fet_b = TURN * 2 * S * 4, TURN * 16
         assert PREFETCH * seg_b < 4096, "the prefetch distance must fit the load's 12-bit offset"
         o += ["s_and_b32 s10, s9, 0xfffff000", "s_cmp_lg_u32 s10, 0", "s_cbranch_scc1 L%s_nopf" % L,
               "s_mov_b32 s48, s0", "s_and_b32 s49, s1, 0xffff", "s_mov_b32 s50, %d" % ((PREFETCH + 1) * seg_b + 64),
@@ -338,7 +357,7 @@ def body(o, S, L):
     o.append("s_waitcnt lgkmcnt(0)")
     rec_loads(o, 2, S, 2)
     rec_loads(o, 3, S, 3)
-    hdr = FCOM[0] + 1
+    hdr = FOFF[0] + 3
     for E in range(1, S):
         o += ["s_cmp_eq_u32 s%d, %d" % (hdr, E), "s_cbranch_scc1 L%s_e%d" % (L, E)]
     for E in range(S, 0, -1):
@@ -370,7 +389,7 @@ def body(o, S, L):
     # cache -- the same instructions without the records' latency)
     HOT = "hotrec" in ABLATE
     o += ["s_add_u32 s0, s0, %d" % (0 if HOT else TURN * 2 * S * 4), "s_addc_u32 s1, s1, 0",
-          "s_add_u32 s2, s2, %d" % (0 if HOT else TURN * 32), "s_addc_u32 s3, s3, 0",
+          "s_add_u32 s2, s2, %d" % (0 if HOT else TURN * 16), "s_addc_u32 s3, s3, 0",
           "s_sub_u32 s8, s8, %d" % TURN, "s_cmp_lg_u32 s8, 0", "s_cbranch_scc1 L%s_loop" % L]
 
 
@@ -386,6 +405,9 @@ def kernel():
         o.append("v_mov_b32 v%d, 0" % v)
     o.append("s_waitcnt lgkmcnt(0)")
     o.append("s_or_b32 s9, s9, s10")
+    # the descriptor the source loads go through: the image's, its base moved per pair (fetch()), num_records = one pair (a null
+    # task's image has none: its loads read zeros without touching memory)
+    o += ["s_mov_b32 s%d, s4" % RSRC, "s_mov_b32 s%d, s5" % (RSRC + 1), "s_min_u32 s%d, s6, 512" % (RSRC + 2), "s_mov_b32 s%d, s7" % (RSRC + 3)]
     if "prio" in ABLATE:  # the four waves of a SIMD (the scan groups of a strip: bits 15:14 of the LDS base) at four priorities
         o += ["s_bfe_u32 s10, s9, 0x2000e", "s_cmp_eq_u32 s10, 1", "s_cbranch_scc0 L%s_p1" % U, "s_setprio 1", "L%s_p1:" % U,
               "s_cmp_eq_u32 s10, 2", "s_cbranch_scc0 L%s_p2" % U, "s_setprio 2", "L%s_p2:" % U,
