@@ -14,8 +14,9 @@
 //                base (below)
 //   strip      : SL_K = 2 adjacent destination word columns; a wave owns (scan group, candidate, strip) and
 //                walks ALL destination rows top to bottom
-//   ring       : the wave keeps the source entries it needs in 64 VGPRs: register (s & 15) * 4 + (c - cb(s));
-//                every source row s has its own column base cb(s), chosen by the generator
+//   ring       : the wave keeps the source entries it needs in 64 VGPRs: source row s owns registers (s & 15) * 4 .. + 3,
+//                its word columns from the row's own column base cb(s) on (slane_ring_register: a row of three columns keeps
+//                its middle column twice)
 //   words      : destination word w covers destination columns 32 w - off .. 32 w - off + 31 with off = (32 - cols % 32)
 //                % 32: the row's LAST column is the last bit of the last word, the columns that do not exist are
 //                the first bits of word 0
@@ -132,6 +133,15 @@ SL_HD inline int slane_seg_dwords(int cls) { return SL_K * slane_slots(cls); }  
 inline int slane_class(int most)
 {
     return most <= 2 ? 0 : most == 3 ? 3 : most == 4 ? 1 : most <= 7 ? most - 1 : most == 8 ? 2 : -1;
+}
+// Where word column d (0 .. 3, counted from the row's first column) of a source row of ncols columns sits among the row's four
+// ring registers, for a segment that starts in it (two_words: some of its bits come from column d + 1, so the register above
+// must hold that column).  Rows of 1, 2 or 4 columns: register d.  Rows of THREE columns are loaded as the pairs (0, 1) and
+// (1, 2) -- registers 0, 1, 2, 3 = columns 0, 1, 1, 2.
+SL_HD inline int slane_ring_register(int d, int ncols, bool two_words)
+{
+    if (ncols != 3) return d;
+    return d == 2 ? 3 : (d == 1 && two_words) ? 2 : d;
 }
 inline int slane_records(int rows) { return (SL_PRE + rows + 63) & ~63; }  // the kernel keeps only the rows LEFT: phases are taken modulo 64
 

@@ -148,7 +148,8 @@ __global__ __launch_bounds__(64) void slane_sched_kernel(SlaneBuild b, int ntask
             }
             const int q = rec + SL_PRE, u = used[q];
             freg[(int64_t)q * SL_FETCH + u] = (uint8_t)((s & (SL_RING_ROWS - 1)) * SL_RING_COLS + 2 * pr);
-            const int64_t e0 = 1 + (int64_t)s * g.colsG + (lo + 2 * pr + g.gx);  // g.entry(s - gy, lo + 2 pr)
+            // g.entry(s - gy, lo + 2 pr); a row of three columns loads its second pair as (column 1, column 2): slane_plan.cpp
+            const int64_t e0 = 1 + (int64_t)s * g.colsG + (lo + 2 * pr - (ncols == 3 && pr == 1 ? 1 : 0) + g.gx);
             fet[(int64_t)q * SL_FREC + u] = (uint32_t)(e0 << 8);
             used[q] = (uint8_t)(u + 1);
         }
@@ -198,7 +199,9 @@ __global__ __launch_bounds__(256) void slane_words_kernel(SlaneBuild b)
         if (s >= 0) {
             const int c = sb_floor_div32(src);
             sh = (uint32_t)(src - 32 * c);
-            idx = (uint32_t)((s & (SL_RING_ROWS - 1)) * SL_RING_COLS + (c - b.cmin[tb + s]));
+            const int lo = b.cmin[tb + s];
+            idx = (uint32_t)((s & (SL_RING_ROWS - 1)) * SL_RING_COLS +
+                             slane_ring_register(c - lo, b.cmax[tb + s] - lo + 1, sh + (uint32_t)len > 32u));
         }
         const uint32_t q = (uint32_t)(j == 0 ? 32 - len : len);
         const uint32_t pk = sh | (idx << 5) | SL_PK_MODE | (q << SL_QSHIFT);
