@@ -1337,7 +1337,7 @@ int omr_batch_lanes_projections(omr_batch_ctx *ctx, int32_t set, int32_t scan, i
         OMR_HIP(hipMemcpy2D(pairs.data(), 4, s.hrows.as<uint32_t>() + (size_t)a * (p.nrec / 2) * nscp + scan, nscp * 4, 4,
                             pairs.size(), hipMemcpyDeviceToHost));
         for (int r = 0; r < p.g.rows; r++) {
-            const int q = r + SL_PRE;
+            const int q = r + p.hrow0;
             hproj[r] = (pairs[(size_t)q >> 1] >> ((q & 1) * 16)) & 0xffffu;
         }
     }

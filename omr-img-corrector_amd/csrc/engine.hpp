@@ -6,6 +6,7 @@
 #include <memory>
 #include <mutex>
 #include <string>
+#include <map>
 #include <vector>
 
 #include "kernels.hpp"
@@ -154,12 +155,23 @@ struct SlanePlan;
 struct SlaneScratch;
 struct SlanePlan {
     SlaneGeom g;
-    int A = 0, nrec = 0;
+    int A = 0, nrec = 0, nexec = 0, hrow0 = 0;  // records numbered / in the streams; the number of image row 0's record
     bool built = false;
     int64_t prog_dwords = 0, null_seg = 0, null_fet = 0;  // the null program: empty words, nothing to fetch
     DevBuf prog, d_tasks;
     std::vector<SlaneStrip> strips;  // [A][NS]
     std::vector<int32_t> tasks;      // candidate * NS + strip, in launch order
+    // the launch order in chunks of 32 candidates (slane_kernel's units): the work of one workgroup of a chunk and its size,
+    // and the units dealt to the XCDs for every composition of a launch met so far (slane_deal_units, slane.hip)
+    std::vector<double> chunk_weight;
+    std::vector<int> chunk_size;
+    struct UnitTab {
+        DevBuf tab;
+        int per_xcd = 0;
+    };
+    mutable std::map<int, UnitTab> unit_tabs;  // key = ncq (strip groups x groups of scan groups)
+    mutable std::mutex unit_mu;
+    int units_for(int ncq, const int32_t **d_tab, int *per_xcd) const;
     // OMR_ERR_NOTIMPL when a candidate does not fit the scheme.  on_host: slane_plan.cpp's generator (the reference
     // implementation, 16 host threads + upload) instead of slane_build.hip's
     int build(const SweepTables &t, bool on_host = false);

@@ -36,7 +36,7 @@ int omr_slane_strip_program(int32_t rows, int32_t cols, const double *fwd_M, int
     if (most < 0) return fail(OMR_ERR_NOTIMPL, "strip %d does not fit the scan-lane scheme (segments / ring columns)", strip);
     const int cls = slane_class(most);
     if (seg_dwords_per_row) *seg_dwords_per_row = slane_seg_dwords(cls);
-    if (n_records) *n_records = slane_records(rows);
+    if (n_records) *n_records = slane_exec_records(rows);
     if (pre_rows) *pre_rows = SL_PRE;
     if (!seg_out || !fetch_out) return OMR_OK;  // size query
     if (!slane_strip_program(g, ad.data(), bd.data(), x0.data(), y0.data(), strip, cls, seg_out, fetch_out))

@@ -21,7 +21,7 @@
 //                % 32: the row's LAST column is the last bit of the last word, the columns that do not exist are
 //                the first bits of word 0
 //   records    : one per destination row, plus SL_PRE virtual rows ahead of row 0 that only fill the ring and virtual
-//                rows at the end up to a multiple of 64.  Two streams per strip (format v3, round 5):
+//                rows at the end up to a whole turn (slane_exec_records; they are numbered so that the last is a multiple of 64).  Two streams per strip (format v3, round 5):
 //                  fetch stream, 4 dwords per row (format v4): 2 x (E << 8) = the byte offsets of the first entries of the two
 //                                   PAIRS whose loads are ISSUED while this row is swept (0 = the all-zero entry: a dummy) -- a
 //                                   pair = entries E and E + 1, two adjacent word columns of one source row, into an aligned
@@ -38,15 +38,22 @@
 //                                   (1 .. 8; the kernel reads it at the first record of a turn and executes exactly that
 //                                   many slots per word).  One s_load_dwordx4 per row
 //                  segment stream, SL_K words x S dwords per row.  A word is assembled from its segments in
-//                                   increasing bit order by funnel shifts, no masks:
-//                                     X = (ring[idx + 1] : ring[idx]) >> sh      (the segment's bits, bit 0 first)
-//                                     first segment : D = X << q                 (q = 32 - len: top-aligned, zeros below)
-//                                     others        : D = (X : D) >> q           (q = len: X's low bits enter at the top)
-//                                   so a word whose first columns are white (or do not exist) simply has fewer bits,
-//                                   and white runs elsewhere are segments that read ring register 64, which holds 0.
-//                                   pk = sh | idx << 5 | 0x60000 | q << 21 (pk >> 5 is M0 for the indexed v_alignbit:
-//                                   index + SRC0_REL | SRC1_REL; pk itself is its shift operand; pk >> 21 the second
-//                                   shift), the first pk of a word also carries its segment count n << 26 (n >= 1) and bit 31 when n <= 4
+//                                   increasing bit order by funnel shifts, no masks (format v4):
+//                                     first segment : D = (ring[i] : ring[i - 1]) >> sh   read straight into the word so that
+//                                                     its bits are TOP-aligned (whatever lies below is pushed out by the
+//                                                     shifts that follow: the segments of a word cover all 32 bits); i = the
+//                                                     register index + 1: register -1 (a landing register) may be named
+//                                                     when all the segment's bits come from ring register 0
+//                                     others        : X = (ring[idx + 1] : ring[idx]) >> sh   (the segment's bits, bit 0 first)
+//                                                     D = (X : D) >> q                        (q = its length: X's low bits
+//                                                                                              enter at the top)
+//                                   White runs (columns that do not exist, samples beyond the guard) are segments that read
+//                                   ring register 64, which holds 0.
+//                                   pk = sh | idx << 5 | 0x60000 | q' << 21 (pk >> 5 is M0 for the indexed v_alignbit:
+//                                   index + SRC0_REL | SRC1_REL; pk itself is its shift operand); q' = the funnel shift of
+//                                   the NEXT slot (pk >> 21 of slots 2 p and 2 p + 1 come out of one s_lshr_b64 and serve
+//                                   slots 2 p + 1 and 2 p + 2); the first pk of a word also carries its segment count
+//                                   n << 26 (n >= 1)
 //                S = 2 / 4 / 8 slots per word laid out (4 / 8 / 16 dwords per row), 2 .. 8 executed, chosen per strip
 #pragma once
 #include <stddef.h>
@@ -70,7 +77,7 @@ constexpr uint32_t SL_PK_MODE = 0x60000u;               // pk >> 5 -> M0[13:12]:
 constexpr uint32_t SL_COMMIT_MODE = 0x8000u;            // M0[15]: DST_REL
 constexpr int SL_PRE = 24;                              // virtual rows ahead of row 0
 constexpr int SL_QSHIFT = 21, SL_NSHIFT = 26;           // pk fields: second shift, segment count
-constexpr uint32_t SL_SHORT = 0x80000000u;              // first pk of a word: at most four segments
+constexpr uint32_t SL_SHORT = 0x80000000u;              // first pk of a word: at most four segments (no longer read)
 constexpr int SL_GX = 4;                                // least zero guard, word columns on either side
 constexpr int SL_LANES = 64;
 constexpr int SL_BLOCK = 64;                            // rows between two meetings of a workgroup (row counts leave its LDS)
@@ -143,7 +150,21 @@ SL_HD inline int slane_ring_register(int d, int ncols, bool two_words)
     if (ncols != 3) return d;
     return d == 2 ? 3 : (d == 1 && two_words) ? 2 : d;
 }
-inline int slane_records(int rows) { return (SL_PRE + rows + 63) & ~63; }  // the kernel keeps only the rows LEFT: phases are taken modulo 64
+// The first segment of a word (format v4): the window that puts its len bits at the TOP of the word.  In: the ring register
+// idx of the word column its first bit lies in and that bit's place sh; out: the slot's index field (register + 1: the
+// kernel's instruction names the pair (index - 1, index)) and shift.
+SL_HD inline void slane_first_segment(uint32_t &idx, uint32_t &sh, int len)
+{
+    const int shp = (int)sh - (32 - len);  // < 0: every bit comes from register idx itself (sh + len < 32): window (idx - 1, idx)
+    if (shp < 0) sh = (uint32_t)(shp + 32);
+    else sh = (uint32_t)shp, idx += 1;
+}
+// Records are NUMBERED up to a multiple of 64 -- slane_records: the kernel takes its row phases (LDS slot, carry-save level,
+// flush) from the number of rows left, modulo 64, and the row counts are laid out by record number -- but only the last
+// slane_exec_records of them EXIST (whole turns): a wave starts at record number slane_records - slane_exec_records, as if
+// the records before it -- they would be virtual rows that fetch nothing -- had been swept already.
+inline int slane_records(int rows) { return (SL_PRE + rows + 63) & ~63; }
+inline int slane_exec_records(int rows) { return (SL_PRE + rows + SL_TURN - 1) & ~(SL_TURN - 1); }
 
 // warpAffine's integer tables of one candidate on the host (the expressions of tables_kernel, kernels.hip;
 // built -ffp-contract=off): adelta / bdelta per column, (X0, Y0) per row with round_delta = 512
@@ -167,14 +188,14 @@ struct SlaneTask {
     uint32_t hrsrc[4];   // buffer descriptor of the row counts of (candidate, scan group): [record / 2][scan], each u32 = the
                          // counts of records 2 i (low half) and 2 i + 1 (high half)
     uint32_t rsrc[4];    // buffer descriptor of the scan group's interleaved bit image
-    uint32_t nrec;       // records (a multiple of 4)
+    uint32_t nrec;       // records as they are numbered (slane_records: a multiple of 64)
     uint32_t hpitch;     // bytes between pair rows of the row counts
     int32_t cls;         // slot class: slots laid out / executed per word (slane_slots, slane_exec_slots)
     int32_t wave;        // the pair rows of its scan group's LDS accumulators this wave flushes: first (bits 4:0, SL_WAVE_FIRST_BITS),
                          // their number 0 .. 8 (bits 11:8, SL_WAVE_COUNT_SHIFT) -- tools/gen_slane_asm.py reads the same fields
     uint64_t planes;     // counter dump of (task, scan group): [word][SL_DUMP planes][64]
     uint32_t lds_base;   // LDS address of the scan group's row-count accumulators in the workgroup
-    uint32_t pad1;
+    uint32_t nexec;      // records the streams hold (slane_exec_records: whole turns, the last of the numbered ones)
     uint64_t pad2[6];
 };
 constexpr int SL_WAVE_FIRST_BITS = 5, SL_WAVE_COUNT_SHIFT = 8, SL_WAVE_COUNT_BITS = 4;
@@ -183,7 +204,7 @@ static_assert(sizeof(SlaneTask) == 128, "SlaneTask layout (slane_asm.inc loads i
 static_assert(offsetof(SlaneTask, seg) == 0 && offsetof(SlaneTask, fet) == 8 && offsetof(SlaneTask, hrsrc) == 16 &&
                   offsetof(SlaneTask, rsrc) == 32 && offsetof(SlaneTask, nrec) == 48 && offsetof(SlaneTask, hpitch) == 52 &&
                   offsetof(SlaneTask, cls) == 56 && offsetof(SlaneTask, wave) == 60 && offsetof(SlaneTask, planes) == 64 &&
-                  offsetof(SlaneTask, lds_base) == 72,
+                  offsetof(SlaneTask, lds_base) == 72 && offsetof(SlaneTask, nexec) == 76,
               "SlaneTask field offsets are part of the wave program");
 
 // slane_build.hip: the same programs generated on the device (the default; the host generator above is the reference
@@ -215,7 +236,9 @@ hipError_t launch_slane_pack(const uint8_t *d_img, int64_t scan_stride, int64_t 
 hipError_t launch_slane_pack_bits(const uint32_t *d_packed, int64_t scan_stride_dwords, const SlaneGeom &g, int nscans,
                                   uint32_t *d_bits, hipStream_t s);
 // nsg_used = scan groups that carry scans in this launch, nsg = scan groups the scratch (and its descriptors) is laid out for
-hipError_t launch_slane(const SlaneTask *d_descs, int nsgq, int nsgp, int A, int NQ, int sgw_log, int32_t *d_guard, hipStream_t s);
+hipError_t launch_slane(const SlaneTask *d_descs, int nsgq, int nsgp, int A, int NQ, int sgw_log, int32_t *d_guard,
+                        const int32_t *d_unit_tab, int per_xcd, hipStream_t s);
+std::vector<int32_t> slane_deal_units(const std::vector<double> &chunk_weight, const std::vector<int> &chunk_size, int ncq, int *per_xcd);
 hipError_t launch_slane_vproj(const uint32_t *d_planes, const int32_t *d_tasks, int ntasks, int nsg_used, int nsg, int NS,
                               int cols, int off, int nrec, uint16_t *d_vproj, uint32_t *d_total, hipStream_t s);
 hipError_t launch_slane_stddev(const uint16_t *d_vproj, const uint32_t *d_hproj, const uint32_t *d_total, int A, int cols, int rows, int hpairs_per_cand,

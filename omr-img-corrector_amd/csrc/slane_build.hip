@@ -34,7 +34,6 @@ __device__ __forceinline__ int sb_word_runs(const SlaneGeom &g, const int32_t *_
                                             int32_t X0, int32_t Y0, int w, F emit)
 {
     int n = 0, cur_s = -2, cur_base = 0, cur_src = 0, cur_len = 0;
-    bool leading = true;
     for (int i = 0; i < 32; i++) {
         const int x = 32 * w - g.off + i;
         int sy = -1, base = 0;
@@ -42,8 +41,6 @@ __device__ __forceinline__ int sb_word_runs(const SlaneGeom &g, const int32_t *_
             const int sx = (X0 + ad[x]) >> 10, yy = (Y0 + bd[x]) >> 10;
             if (sx >= -32 * (g.gx - 1) && sx < g.cols + 32 * (g.gx - 1) && yy >= -g.gy && yy < g.rows + g.gy) sy = yy + g.gy, base = sx - i;
         }
-        if (leading && sy < 0) continue;
-        leading = false;
         if (cur_len > 0 && cur_s == sy && (sy < 0 || cur_base == base)) {
             cur_len++;
         } else {
@@ -59,10 +56,6 @@ __device__ __forceinline__ int sb_word_runs(const SlaneGeom &g, const int32_t *_
         if (n == SB_MAXSEG) return -1;
         emit(n, cur_s, cur_src, cur_len);
         n++;
-    }
-    if (n == 0) {
-        emit(0, -1, 0, 32);
-        n = 1;
     }
     return n;
 }
@@ -106,7 +99,7 @@ __global__ __launch_bounds__(256) void slane_fill_kernel(SlaneBuild b, int ntask
     const int cls = t < ntasks ? b.cls[t] : 0;
     uint32_t *seg = b.prog + (t < ntasks ? b.seg_off[t] : b.null_seg), *fet = b.prog + (t < ntasks ? b.fet_off[t] : b.null_fet);
     const int S = slane_slots(cls), RD = SL_K * S;
-    const uint32_t white = ((uint32_t)SL_ZERO << 5) | SL_PK_MODE | (1u << SL_NSHIFT) | SL_SHORT, pad = ((uint32_t)SL_ZERO << 5) | SL_PK_MODE;
+    const uint32_t white = ((uint32_t)(SL_ZERO + 1) << 5) | SL_PK_MODE | (1u << SL_NSHIFT), pad = ((uint32_t)SL_ZERO << 5) | SL_PK_MODE;
     for (int k = 0; k < SL_K; k++)
         for (int j = 0; j < S; j++) seg[(int64_t)q * RD + k * S + j] = j == 0 ? white : pad;
     const uint32_t nocommit = (uint32_t)SL_DUMMY | SL_COMMIT_MODE;
@@ -193,7 +186,9 @@ __global__ __launch_bounds__(256) void slane_words_kernel(SlaneBuild b)
     const int64_t tb = (int64_t)task * g.rowsG;
     const int S = slane_slots(b.cls[task]), RD = SL_K * S;
     uint32_t *w = b.prog + b.seg_off[task] + (int64_t)(r + SL_PRE) * RD + k * S;
-    uint32_t w0 = 0;
+    // (slane_plan.cpp: the first segment is read straight into the word, a funnel shift's amount rides in the slot before it;
+    // the first dword is written last, with the count)
+    uint32_t w0 = 0, prev = 0;
     const int n = sb_word_runs(g, ad, bd, xy.x, xy.y, strip * SL_K + k, [&](int j, int s, int src, int len) {
         uint32_t idx = SL_ZERO, sh = 0;
         if (s >= 0) {
@@ -203,16 +198,22 @@ __global__ __launch_bounds__(256) void slane_words_kernel(SlaneBuild b)
             idx = (uint32_t)((s & (SL_RING_ROWS - 1)) * SL_RING_COLS +
                              slane_ring_register(c - lo, b.cmax[tb + s] - lo + 1, sh + (uint32_t)len > 32u));
         }
-        const uint32_t q = (uint32_t)(j == 0 ? 32 - len : len);
-        const uint32_t pk = sh | (idx << 5) | SL_PK_MODE | (q << SL_QSHIFT);
+        if (j == 0) slane_first_segment(idx, sh, len);
+        const uint32_t pk = sh | (idx << 5) | SL_PK_MODE;
+        if (j > 0) {
+            prev |= (uint32_t)len << SL_QSHIFT;
+            if (j == 1) w0 = prev;
+            else if (j - 1 < S) w[j - 1] = prev;
+        }
+        prev = pk;
         if (j == 0) w0 = pk;
-        else if (j < S) w[j] = pk;
     });
-    if (n < 0 || n > S) {
+    if (n < 1 || n > S) {
         atomicExch(b.bad, 1);
         return;
     }
-    w[0] = w0 | ((uint32_t)n << SL_NSHIFT) | (n <= 4 ? SL_SHORT : 0u);
+    if (n > 1) w[n - 1] = prev;
+    w[0] = w0 | ((uint32_t)n << SL_NSHIFT);
 }
 
 }  // namespace

@@ -28,15 +28,15 @@ void SlanePlan::layout()
     int64_t off = 0;
     for (auto &S : strips) {
         S.seg_offset = off;
-        off += ((int64_t)nrec * slane_seg_dwords(S.cls) + 63) & ~63ll;
+        off += ((int64_t)nexec * slane_seg_dwords(S.cls) + 63) & ~63ll;
         S.fet_offset = off;
-        off += ((int64_t)nrec * SL_FREC + 63) & ~63ll;
+        off += ((int64_t)nexec * SL_FREC + 63) & ~63ll;
     }
     // the null program (class 0: nothing to fetch, empty words) for the places of a workgroup beyond the last strip
     null_seg = off;
-    off += ((int64_t)nrec * slane_seg_dwords(0) + 63) & ~63ll;
+    off += ((int64_t)nexec * slane_seg_dwords(0) + 63) & ~63ll;
     null_fet = off;
-    off += ((int64_t)nrec * SL_FREC + 63) & ~63ll;
+    off += ((int64_t)nexec * SL_FREC + 63) & ~63ll;
     prog_dwords = off + 2048;  // the kernel requests two records past a stream's last one (and may prefetch a turn or two beyond it)
 }
 
@@ -55,7 +55,7 @@ int SlanePlan::generate_on_device(const SweepTables &t)
     OMR_HIP(hipMemset(bad.p, 0, 4));
     SlaneBuild b{};
     b.g = g;
-    b.nrec = nrec;
+    b.nrec = nexec;
     b.adelta = t.adelta.as<int32_t>();
     b.bdelta = t.bdelta.as<int32_t>();
     b.xy0 = t.xy0.as<int2_t>();
@@ -79,10 +79,10 @@ int SlanePlan::generate_on_device(const SweepTables &t)
     OMR_HIP(hipMemcpy(d_seg.p, hs.data(), 8 * ntasks, hipMemcpyHostToDevice));
     OMR_HIP(hipMemcpy(d_fet.p, hf.data(), 8 * ntasks, hipMemcpyHostToDevice));
     OMR_HIP(hipMemcpy(d_cls.p, hc.data(), 4 * ntasks, hipMemcpyHostToDevice));
-    OMR_HIP(used.alloc(ntasks * (size_t)nrec));
-    OMR_HIP(freg.alloc(ntasks * (size_t)nrec * SL_FETCH));
-    OMR_HIP(hipMemset(used.p, 0, ntasks * (size_t)nrec));
-    OMR_HIP(hipMemset(freg.p, SL_DUMMY, ntasks * (size_t)nrec * SL_FETCH));
+    OMR_HIP(used.alloc(ntasks * (size_t)nexec));
+    OMR_HIP(freg.alloc(ntasks * (size_t)nexec * SL_FETCH));
+    OMR_HIP(hipMemset(used.p, 0, ntasks * (size_t)nexec));
+    OMR_HIP(hipMemset(freg.p, SL_DUMMY, ntasks * (size_t)nexec * SL_FETCH));
     OMR_HIP(prog.alloc(sizeof(uint32_t) * (size_t)prog_dwords));
     OMR_HIP(hipMemset(prog.p, 0, sizeof(uint32_t) * (size_t)prog_dwords));
     b.used = used.as<uint8_t>(), b.freg = freg.as<uint8_t>();
@@ -134,7 +134,7 @@ int SlanePlan::generate_on_host(const SweepTables &t)
     layout();
     std::vector<uint32_t> host((size_t)prog_dwords, 0u);
     pass(true, host.data());
-    slane_null_program(nrec, 0, host.data() + null_seg, host.data() + null_fet);
+    slane_null_program(nexec, 0, host.data() + null_seg, host.data() + null_fet);
     if (bad.load()) return fail(OMR_ERR_NOTIMPL, "%s", kNoFit);
     OMR_HIP(prog.alloc(sizeof(uint32_t) * (size_t)prog_dwords));
     OMR_HIP(hipMemcpy(prog.p, host.data(), sizeof(uint32_t) * (size_t)prog_dwords, hipMemcpyHostToDevice));
@@ -161,7 +161,7 @@ int SlanePlan::build(const SweepTables &t, bool on_host)
     if (g.image_bytes() > 0xffffffffull)  // a pair's byte offset is a dword of the fetch stream, a scan group's image one buffer descriptor
         return fail(OMR_ERR_NOTIMPL, "scan-lane sweep: the bit image of a scan group (%zu bytes with its guard) exceeds 4 GB", g.image_bytes());
     A = d.A;
-    nrec = slane_records(d.rows);
+    nrec = slane_records(d.rows), nexec = slane_exec_records(d.rows), hrow0 = nrec - nexec + SL_PRE;
     const int NS = g.NS;
     strips.assign((size_t)A * NS, SlaneStrip{0, 0, -1, 0});
     if (int rc = on_host ? generate_on_host(t) : generate_on_device(t)) return rc;
@@ -191,9 +191,32 @@ int SlanePlan::build(const SweepTables &t, bool on_host)
     tasks.clear();
     for (int a : order)
         for (int st = 0; st < NS; st++) tasks.push_back(a * NS + st);
+    chunk_weight.clear(), chunk_size.clear();
+    for (size_t c0 = 0; c0 < order.size(); c0 += 32) {
+        const size_t n = std::min<size_t>(32, order.size() - c0);
+        double w = 0;
+        // (a workgroup's time ~ 5 + executed slots per word, measured: 0.70 ms at 2 slots, 1.21 ms at 7 -- tools/kstamps_lanes.py)
+        for (size_t i = 0; i < n; i++) w += 5.0 * NS + weight(order[c0 + i]);
+        chunk_weight.push_back(w / (double)n), chunk_size.push_back((int)n);
+    }
+    unit_tabs.clear();
     OMR_HIP(d_tasks.alloc(sizeof(int32_t) * tasks.size()));
     OMR_HIP(hipMemcpy(d_tasks.p, tasks.data(), sizeof(int32_t) * tasks.size(), hipMemcpyHostToDevice));
     built = true;
+    return OMR_OK;
+}
+
+// the units of a launch of ncq (strip group, group of scan groups) combinations, dealt to the XCDs (made once per ncq)
+int SlanePlan::units_for(int ncq, const int32_t **d_tab, int *per_xcd) const
+{
+    std::lock_guard<std::mutex> lk(unit_mu);
+    UnitTab &u = unit_tabs[ncq];
+    if (!u.tab.p) {
+        const std::vector<int32_t> h = slane_deal_units(chunk_weight, chunk_size, ncq, &u.per_xcd);
+        OMR_HIP(u.tab.alloc(sizeof(int32_t) * h.size()));
+        OMR_HIP(hipMemcpy(u.tab.p, h.data(), sizeof(int32_t) * h.size(), hipMemcpyHostToDevice));
+    }
+    *d_tab = u.tab.as<int32_t>(), *per_xcd = u.per_xcd;
     return OMR_OK;
 }
 
@@ -260,6 +283,7 @@ int SlaneScratch::create(const SlanePlan &p, int groups)
                     k.rsrc[2] = real ? (uint32_t)g.image_bytes() : 0u;
                     k.rsrc[3] = 0x00020000u;
                     k.nrec = (uint32_t)p.nrec;
+                    k.nexec = (uint32_t)p.nexec;
                     k.hpitch = (uint32_t)(nscp * 4);
                     k.cls = real ? S.cls : 0;
                     static_assert(SL_BLOCK / 2 <= (1 << SL_WAVE_FIRST_BITS) && 8 < (1 << SL_WAVE_COUNT_BITS), "SlaneTask::wave fields");
@@ -295,8 +319,12 @@ int slane_enqueue(const SlanePlan &p, SlaneScratch &s, const uint8_t *d_img, int
     if (ev0) OMR_HIP(hipEventRecord(ev0, stream));
     {   // the workgroup's composition: 16 strips x 1 scan group, 8 x 2 or 4 x 4 (the scratch holds a table for each)
         const int lg = used <= 1 ? 0 : used == 2 ? 1 : 2, sgw = 1 << lg, places = 16 >> lg;
-        OMR_HIP(launch_slane(s.descs[lg].as<SlaneTask>(), (used + sgw - 1) / sgw, ((s.nsg + sgw - 1) / sgw) * sgw, p.A,
-                             (p.g.NS + places - 1) / places, lg, s.guard.as<int32_t>(), stream));
+        const int nsgq = (used + sgw - 1) / sgw, NQ = (p.g.NS + places - 1) / places;
+        const int32_t *d_tab = nullptr;
+        int per_xcd = 0;
+        if (int rc = p.units_for(NQ * nsgq, &d_tab, &per_xcd)) return rc;
+        OMR_HIP(launch_slane(s.descs[lg].as<SlaneTask>(), nsgq, ((s.nsg + sgw - 1) / sgw) * sgw, p.A, NQ, lg, s.guard.as<int32_t>(),
+                             d_tab, per_xcd, stream));
         s.guard_pending = true;
     }
     if (ev1) OMR_HIP(hipEventRecord(ev1, stream));
@@ -309,7 +337,7 @@ int slane_enqueue(const SlanePlan &p, SlaneScratch &s, const uint8_t *d_img, int
                                p.g.off, p.nrec, s.vproj.as<uint16_t>(), s.hrows.as<uint32_t>() + (size_t)p.A * (p.nrec / 2) * nscp, stream));
     double *vs = d_v_sd ? d_v_sd : s.vsd.as<double>(), *hs = d_h_sd ? d_h_sd : s.hsd.as<double>();
     OMR_HIP(launch_slane_stddev(s.vproj.as<uint16_t>(), s.hrows.as<uint32_t>(), s.hrows.as<uint32_t>() + (size_t)p.A * (p.nrec / 2) * nscp,
-                                p.A, p.g.cols, p.g.rows, p.nrec / 2, SL_PRE, used, s.nsg,
+                                p.A, p.g.cols, p.g.rows, p.nrec / 2, p.hrow0, used, s.nsg,
                                 nscans, vs, hs, stream));
     if (d_best) OMR_HIP(launch_argmax_path1(vs, hs, p.A, d_best, stream, nscans));
     // the row counts are accumulated with atomics: cleared here, behind their only reader and off the sweep's stream

@@ -48,12 +48,12 @@ void slane_guard_need(const int32_t *ad, const int32_t *bd, const int32_t *x0, c
     *gy = (int)std::min<int64_t>(oy + 2, 2048);
 }
 
-// The empty program: every word = one white run of 32 bits (first segment: 0 << 0), the other slots no-ops (0 bits
+// The empty program: every word = one white run of 32 bits (first segment: the zero register read straight), the other slots no-ops (0 bits
 // shifted in from the zero register), nothing to fetch, dummy commits.
 void slane_null_program(int nrec, int cls, uint32_t *seg, uint32_t *fet)
 {
     const int RD = slane_seg_dwords(cls), S = slane_slots(cls);
-    const uint32_t white = ((uint32_t)SL_ZERO << 5) | SL_PK_MODE | (1u << SL_NSHIFT) | SL_SHORT, pad = ((uint32_t)SL_ZERO << 5) | SL_PK_MODE;
+    const uint32_t white = ((uint32_t)(SL_ZERO + 1) << 5) | SL_PK_MODE | (1u << SL_NSHIFT), pad = ((uint32_t)SL_ZERO << 5) | SL_PK_MODE;
     for (size_t q = 0; q < (size_t)nrec; q++)
         for (int k = 0; k < SL_K; k++)
             for (int j = 0; j < S; j++) seg[q * RD + (size_t)k * S + j] = j == 0 ? white : pad;
@@ -77,14 +77,13 @@ constexpr int MAXSEG = 8;
 
 inline int floor_div32(int v) { return v >= 0 ? v >> 5 : -((-v + 31) >> 5); }
 
-// The runs of destination word w of row r in increasing bit order.  A white run at the START of the word is left out
-// (the first segment is placed top-aligned with zeros below, slane.hpp); a word that is white altogether is one white
-// run of 32 bits.  Returns the number of runs, -1 when there are more than MAXSEG.
+// The runs of destination word w of row r in increasing bit order; they cover all 32 bits (a white run -- columns that do not
+// exist, samples beyond the guard -- reads the zero register; format v4: the first segment is read straight into the word,
+// so nothing below it is zero by itself).  Returns the number of runs, -1 when there are more than MAXSEG.
 inline int word_segments(const SlaneGeom &g, const int32_t *ad, const int32_t *bd, int32_t X0, int32_t Y0, int w, Seg *out)
 {
     int n = 0;
     int cur_s = -2, cur_base = 0;  // run under construction: source row (-1 white), sx - i
-    bool leading = true;
     for (int i = 0; i < 32; i++) {
         const int x = 32 * w - g.off + i;
         int sy = -1, base = 0;
@@ -94,8 +93,6 @@ inline int word_segments(const SlaneGeom &g, const int32_t *ad, const int32_t *b
             // same run); beyond the guard: a white run.  Source rows are kept as row + gy (never negative).
             if (sx >= -32 * (g.gx - 1) && sx < g.cols + 32 * (g.gx - 1) && yy >= -g.gy && yy < g.rows + g.gy) sy = yy + g.gy, base = sx - i;
         }
-        if (leading && sy < 0) continue;  // white bits at the start of the word need no segment
-        leading = false;
         if (n > 0 && cur_s == sy && (sy < 0 || cur_base == base)) {
             out[n - 1].len++;
         } else {
@@ -104,10 +101,6 @@ inline int word_segments(const SlaneGeom &g, const int32_t *ad, const int32_t *b
             cur_s = sy, cur_base = base;
             n++;
         }
-    }
-    if (n == 0) {  // all white
-        out[0].s = -1, out[0].src = 0, out[0].len = 32;
-        n = 1;
     }
     return n;
 }
@@ -149,7 +142,7 @@ int slane_strip_segments(const SlaneGeom &g, const int32_t *ad, const int32_t *b
 bool slane_strip_program(const SlaneGeom &g, const int32_t *ad, const int32_t *bd, const int32_t *x0, const int32_t *y0,
                          int strip, int cls, uint32_t *seg, uint32_t *fet)
 {
-    const int R = g.rows, RD = slane_seg_dwords(cls), S = slane_slots(cls), NREC = slane_records(R);
+    const int R = g.rows, RD = slane_seg_dwords(cls), S = slane_slots(cls), NREC = slane_exec_records(R);
     std::vector<Seg> segs((size_t)R * SL_K * MAXSEG);
     std::vector<uint8_t> nseg((size_t)R * SL_K);
     const int RG = g.rowsG;  // source rows incl. the guard, indexed row + gy
@@ -219,11 +212,11 @@ bool slane_strip_program(const SlaneGeom &g, const int32_t *ad, const int32_t *b
                     idx = (uint32_t)((sg[j].s & (SL_RING_ROWS - 1)) * SL_RING_COLS +
                                      slane_ring_register(c - cmin[s], cmax[s] - cmin[s] + 1, sh + (uint32_t)sg[j].len > 32u));
                 }
-                const uint32_t q = (uint32_t)(j == 0 ? 32 - sg[j].len : sg[j].len);  // first: shift left; others: funnel
-                w[j] = sh | (idx << 5) | SL_PK_MODE | (q << SL_QSHIFT);
+                if (j == 0) slane_first_segment(idx, sh, sg[j].len);  // read straight into the word: top-aligned by the read itself
+                w[j] = sh | (idx << 5) | SL_PK_MODE;
+                if (j > 0) w[j - 1] |= (uint32_t)sg[j].len << SL_QSHIFT;  // a funnel shift's amount rides in the slot before it
             }
             w[0] |= (uint32_t)n << SL_NSHIFT;
-            if (n <= 4) w[0] |= SL_SHORT;  // (a flag the kernel no longer reads: with exact slot counts per turn a per-word skip costs more than it saves)
         }
     // ---- turn headers: the most segments any word of a turn of SL_TURN records needs (virtual rows: one white run)
     for (int q0 = 0; q0 < NREC; q0 += SL_TURN) {

@@ -13,8 +13,9 @@
 #define SL_TURN 16
 #define SL_RING 68 /* 64 ring registers, register 64 holds 0 (65 is its upper neighbour), the pair 66 / 67 swallows dummy fetch pairs */
 
-/* seg: n_records rows of seg_dwords dwords (K words x S segments, pk = sh | idx << 5 | 0x60000 | q << 21 | n << 26 in the
- * first); fet: n_records rows of 4 dwords (format v4): 2 byte offsets (E << 8) of the first entries of the PAIRS whose loads are issued in this row
+/* seg: n_records rows of seg_dwords dwords (K words x S segments, pk = sh | idx << 5 | 0x60000 | q' << 21 | n << 26 in the
+ * first; format v4: the first segment names the register pair (idx - 1, idx) and is read straight into the word, q' is the
+ * funnel shift of the NEXT slot -- slane.hpp); fet: n_records rows of 4 dwords (format v4): 2 byte offsets (E << 8) of the first entries of the PAIRS whose loads are issued in this row
  * -- a pair = entries e and e + 1, two adjacent word columns of one source row, into an aligned pair of landing registers --,
  * 1 dword = 2 x u16 (EVEN ring register | 0x8000): where the two pairs that landed in this row's set of landing
  * registers (the loads of SL_AHEAD rows earlier) are committed before this row, as the kernel's v_mov_b64 does (an odd
@@ -61,15 +62,21 @@ int orc_slane_run_strip(const uint32_t *seg, int seg_dwords, const uint32_t *fet
             const int n = (int)((w[0] >> 26) & 31u);
             if (n < 1 || n > S || n > turn_slots) return -1; /* the kernel would stop before this word's last segment */
             for (int lane = 0; lane < lanes; lane++) {
-                uint32_t D = 0xdeadbeefu; /* whatever the register held: the first segment overwrites it */
+                uint32_t D = 0;
                 for (int j = 0; j < turn_slots; j++) { /* exactly the header's slots, pads included */
                     const uint32_t pk = w[j];
-                    const uint32_t idx = (pk >> 5) & 255u, sh = pk & 31u, qq = (pk >> 21) & 31u;
+                    const uint32_t idx = (pk >> 5) & 255u, sh = pk & 31u;
                     if (((pk >> 5) & 0xff00u) != 0x3000u || idx + 1 >= SL_RING) return -1; /* M0 image: index | SRC0_REL | SRC1_REL */
-                    const uint64_t pair = ((uint64_t)ring[idx + 1][lane] << 32) | ring[idx][lane];
-                    const uint32_t X = (uint32_t)(pair >> sh);
-                    if (j == 0) D = X << qq;
-                    else D = (uint32_t)((((uint64_t)X << 32) | D) >> qq);
+                    if (j == 0) { /* the first segment: the pair (index - 1, index) read straight into the word; register -1 is a
+                                     landing register -- whatever it holds must not matter */
+                        const uint32_t lo = idx ? ring[idx - 1][lane] : 0xdeadbeefu ^ (uint32_t)(q * 2654435761u + (uint32_t)lane);
+                        D = (uint32_t)((((uint64_t)ring[idx][lane] << 32) | lo) >> sh);
+                    } else { /* the funnel shift's amount rides in the slot before */
+                        const uint32_t qq = (w[j - 1] >> 21) & 31u;
+                        const uint64_t pair = ((uint64_t)ring[idx + 1][lane] << 32) | ring[idx][lane];
+                        const uint32_t X = (uint32_t)(pair >> sh);
+                        D = (uint32_t)((((uint64_t)X << 32) | D) >> qq);
+                    }
                 }
                 if (q >= pre_rows && q - pre_rows < rows) hrow[(int64_t)(q - pre_rows) * lanes + lane] += (uint32_t)__builtin_popcount(D);
                 else if (D) return -1; /* virtual rows carry no bits */

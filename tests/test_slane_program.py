@@ -116,7 +116,7 @@ def test_record_classes_follow_the_angle():
         M = orc.get_rotation_matrix_2d(cols / 2.0, rows / 2.0, ang, 1.0)
         _, rd, nrec, pre, most = strip_program(rows, cols, M, 3)
         assert rd == want, (ang, rd, most)
-        assert nrec == (rows + pre + 63) // 64 * 64
+        assert nrec == (rows + pre + 15) // 16 * 16  # whole turns (slane_exec_records)
 
 
 def test_steep_candidates_are_refused_not_mangled():

@@ -25,7 +25,7 @@ never carries (slane.hpp) -> row count (pairs of rows meet the
 workgroup's other strips in LDS; one global atomic per pair row and block of BLOCK rows) -> (odd rows) carry-save column counters.
 
 Register map (fixed; the statement clobbers s0-s13, s16-s101, v1-v127, so lane * 4 arrives in v0):
-  s[0:1] segment stream  s[2:3] fetch stream  s[4:7] bit-image descriptor  s8 rows left (a multiple of 64 at the start:
+  s[0:1] segment stream  s[2:3] fetch stream  s[4:7] bit-image descriptor  s8 rows left (whole turns; the record NUMBERS end on a multiple of 64:
   row phases are taken from -s8)  s9 pair rows the wave flushes (first in bits 4:0, number in bits 11:8) | LDS base of the scan group's accumulators (a multiple of 4096)
   s[10:11] second shifts of a segment pair / scratch  s[14:15] the task (input)
   segment sets A-D: s[16:31] s[32:47] s[48:63] s[64:79]   fetch records A-D (two pair offsets, commit word, turn header):
@@ -53,8 +53,9 @@ of round 4 -- profiles/r04_lanes_ablation.md -- was a violation of the second on
     respect to loads, which can only lengthen a counted wait, never satisfy it early;
   * M0: every word leaves M0 = 0 behind its indexed reads (s_mov m0, 0 in front of the funnel shifts), so every vector-ALU
     instruction outside word() and commit_and_fetch() runs unindexed; vector MEMORY instructions ignore the index mode;
-  * row phases (LDS slot, carry-save level, flush) are taken from -s8 modulo 64: the number of records is a multiple of 64,
-    not of 128.
+  * row phases (LDS slot, carry-save level, flush) are taken from -s8 modulo 64: the record numbers end on a multiple of 64
+    (not of 128); the first record a wave sweeps may have any number that is a multiple of the turn (the records before it --
+    virtual rows -- are not in the streams: all registers start at zero, as they would be behind rows that count nothing).
 Usage: python tools/gen_slane_asm.py   (writes the .inc; the build only reads it)"""
 import os
 
@@ -87,75 +88,47 @@ RSRC = 96                      # s[96:99]: the image's descriptor, its base move
 AHEAD = 4
 
 
-def word(out, k, sset, S, dreg, tag, E=None):
-    """segments of word k (pk dwords in s[sset + k * S ...], S slots laid out, E of them executed) -> VGPR dreg.  Scalar work
-    per segment: one s_lshr writes M0 (ring index + mode bits); the second shift amounts of TWO segments come out of one
-    s_lshr_b64 of their SGPR pair (low dword's bits 4:0 = q of the even segment, high dword's = q of the odd one; the junk
-    above bit 4 is ignored by v_alignbit / v_lshlrev)."""
-    E = E or S
-    Q32 = "q32" in ABLATE  # timing probe: one s_lshr_b32 per segment for the second shift instead of one s_lshr_b64 per pair
-    # a word of at most four segments could skip the second group (the generator's flag bit 31): paid off while strips ran 2 / 4 / 8
-    # slots (45.1 ms with, 45.9 without); with exact slot counts per strip it costs more than it saves (36.7 with, 36.5 without)
-    SKIP = "skip" in ABLATE
-    p = lambda j: "s%d" % (sset + k * S + j)
-    groups = [list(range(0, min(E, 4)))] + ([list(range(4, E))] if E > 4 else [])
-    for g, js in enumerate(groups):
-        for n, j in enumerate(js):
-            out.append("s_lshr_b32 m0, %s, 5" % p(j))        # ring index + SRC0_REL | SRC1_REL
-            tgt = dreg if (g == 0 and n == 0 and "nofirstshift" in ABLATE) else XR[n]
-            out.append("v_alignbit_b32 v%d, v%d, v%d, %s" % (tgt, RING + 1, RING, p(j)))
-        out.append("s_mov_b32 m0, 0")
-        for n, j in enumerate(js):
-            if Q32:
-                out.append("s_lshr_b32 s10, %s, 21" % p(j))
-                q = "s10"
-            else:
-                if n % 2 == 0:  # the pair (j, j + 1) sits in an even-aligned SGPR pair: sets and laid-out slot counts are even
-                    out.append("s_lshr_b64 s[10:11], s[%d:%d], 21" % (sset + k * S + j, sset + k * S + j + 1))
-                q = "s%d" % (10 + (n & 1))
-            if g == 0 and n == 0:
-                if "nofirstshift" in ABLATE:  # timing probe: what a first segment read straight into the word would save
-                    continue
-                out.append("v_lshlrev_b32 v%d, %s, v%d" % (dreg, q, XR[n]))
-            else:
-                out.append("v_alignbit_b32 v%d, v%d, v%d, %s" % (dreg, XR[n], dreg, q))
-        if g + 1 < len(groups) and SKIP:
-            out.append("s_bitcmp1_b32 %s, 31" % p(0))        # the generator's flag: at most four segments
-            out.append("s_cbranch_scc1 %s" % tag)
-    if len(groups) > 1 and SKIP:
-        out.append("%s:" % tag)
-
-
 def words2(out, sset, S, d0, d1, E, t):
-    """Both words of a row, group by group (a group = up to four segments of either word): the indexed reads of word 0 go to
-    the four window registers, those of word 1 to the row's four LANDING registers -- they were committed a moment ago and this
-    row's loads are issued only after the words (fetch()) --, so ONE `s_mov m0, 0` serves the funnel shifts of both words and
-    the two words' chains are independent instruction streams.  Word 1's second shifts come out of vcc."""
+    """Both words of a row (pk dwords in s[sset + k * S ...], S slots laid out, E of them executed), group by group.  Format v4:
+    slot 0 -- the word's first segment -- is read STRAIGHT into the word (the generator names the register pair and the shift
+    that put its bits at the top; what lies below is pushed out by the funnel shifts that follow), slots 1 .. 4 are the first
+    group of windows, slots 5 .. 7 the second.  The indexed reads of word 0 go to the four window registers, those of word 1 to
+    the row's four LANDING registers -- they were committed a moment ago and this row's loads are issued only after the words
+    (fetch()) --, so ONE `s_mov m0, 0` per group serves the funnel shifts of both words and the two words' chains are
+    independent instruction streams.  Scalar work per slot: one s_lshr writes M0 (ring index + mode bits); the funnel shift
+    of slot j rides in bits 25:21 of slot j - 1, and one s_lshr_b64 of the SGPR pair (2 p, 2 p + 1) serves slots 2 p + 1 and
+    2 p + 2 (low dword's bits 4:0, high dword's; the junk above bit 4 is ignored by v_alignbit): word 0's land in s[10:11],
+    word 1's in vcc."""
     E = E or S
     pk = lambda k, j: "s%d" % (sset + k * S + j)
     X = (XR, (t, t + 1, t + 2, t + 3))
     D = (d0, d1)
     Q = ("s10", "s11"), ("vcc_lo", "vcc_hi")
-    groups = [list(range(0, min(E, 4)))] + ([list(range(4, E))] if E > 4 else [])
+    NOM0 = "nom0" in ABLATE  # timing probe: what the M0 writes in front of the indexed reads cost (every window reads ring 0 / 1)
+    groups = [list(range(0, min(E, 5)))] + ([list(range(5, E))] if E > 5 else [])
     for g, js in enumerate(groups):
-        if "nom0" in ABLATE:  # timing probe: what the M0 writes in front of the indexed reads cost (every window reads ring 0 / 1)
+        if NOM0:
             out.append("s_mov_b32 m0, 0x3000")
         for k in range(2):
-            for n, j in enumerate(js):
-                if "nom0" not in ABLATE:
+            for j in js:
+                if not NOM0:
                     out.append("s_lshr_b32 m0, %s, 5" % pk(k, j))        # ring index + SRC0_REL | SRC1_REL
-                out.append("v_alignbit_b32 v%d, v%d, v%d, %s" % (X[k][n], RING + 1, RING, pk(k, j)))
-        out.append("s_mov_b32 m0, 0")
-        for n, j in enumerate(js):
-            for k in range(2):
-                if n % 2 == 0 and "noq" not in ABLATE:  # the pair (j, j + 1) sits in an even-aligned SGPR pair: sets and laid-out slot counts are even
-                    out.append("s_lshr_b64 %s, s[%d:%d], 21" % ("s[10:11]" if k == 0 else "vcc", sset + k * S + j, sset + k * S + j + 1))
-            for k in range(2):
-                q = Q[k][n & 1]
-                if g == 0 and n == 0:
-                    out.append("v_lshlrev_b32 v%d, %s, v%d" % (D[k], q, X[k][n]))
+                if j == 0:   # (index - 1, index) -> the word
+                    out.append("v_alignbit_b32 v%d, v%d, v%d, %s" % (D[k], RING, RING - 1, pk(k, j)))
                 else:
-                    out.append("v_alignbit_b32 v%d, v%d, v%d, %s" % (D[k], X[k][n], D[k], q))
+                    out.append("v_alignbit_b32 v%d, v%d, v%d, %s" % (X[k][(j - 1) & 3], RING + 1, RING, pk(k, j)))
+        funnels = [j for j in js if j > 0]
+        if not funnels:
+            continue  # (a word of one segment: M0 is reset by the next indexed write, or by the row's last word below)
+        out.append("s_mov_b32 m0, 0")
+        for j in funnels:
+            for k in range(2):
+                if j % 2 == 1 and "noq" not in ABLATE:  # the shifts of slots j, j + 1 sit in slots j - 1, j: an even-aligned SGPR pair
+                    out.append("s_lshr_b64 %s, s[%d:%d], 21" % ("s[10:11]" if k == 0 else "vcc", sset + k * S + j - 1, sset + k * S + j))
+            for k in range(2):
+                out.append("v_alignbit_b32 v%d, v%d, v%d, %s" % (D[k], X[k][(j - 1) & 3], D[k], Q[k][(j - 1) & 1]))
+    if E == 1:
+        out.append("s_mov_b32 m0, 0")  # every vector instruction outside the words runs unindexed
 
 
 def commit(out, x, tset):
@@ -371,13 +344,8 @@ def body(o, S, L):
             odd = r & 1
             commit(o, r % 4, r % 4)
             d = (ST[0], ST[1]) if not odd else DODD
-            if "words1" in ABLATE:  # (round 5's first form: one word after the other, the loads in front of them)
-                fetch(o, r % 4, r % 4)
-                word(o, 0, SEG[r % 4], S, d[0], "L%s_e%d_r%dw0" % (L, E, r), Ex)
-                word(o, 1, SEG[r % 4], S, d[1], "L%s_e%d_r%dw1" % (L, E, r), Ex)
-            else:
-                words2(o, SEG[r % 4], S, d[0], d[1], Ex, T0 + 4 * (r % 4))
-                fetch(o, r % 4, r % 4)
+            words2(o, SEG[r % 4], S, d[0], d[1], Ex, T0 + 4 * (r % 4))
+            fetch(o, r % 4, r % 4)
             row_count(o, d[0], d[1], odd == 1, r // 2)
             if odd:
                 carry_save(o, "L%s_e%d_cs%d" % (L, E, r), (r & 2) != 0, r // 4)
@@ -399,7 +367,7 @@ def kernel():
     VGPR -- a whole wave per SIMD.)"""
     o = []
     U = "%="  # unique label suffix per asm statement
-    o += ["s_load_dwordx4 s[0:3], %[desc], 0", "s_load_dwordx4 s[4:7], %[desc], 32", "s_load_dword s8, %[desc], 48",
+    o += ["s_load_dwordx4 s[0:3], %[desc], 0", "s_load_dwordx4 s[4:7], %[desc], 32", "s_load_dword s8, %[desc], 76",
           "s_load_dword s11, %[desc], 56", "s_load_dword s9, %[desc], 60", "s_load_dword s10, %[desc], 72"]
     for v in range(1, 128):
         o.append("v_mov_b32 v%d, 0" % v)
