@@ -80,7 +80,10 @@ constexpr int SL_QSHIFT = 21, SL_NSHIFT = 26;           // pk fields: second shi
 constexpr uint32_t SL_SHORT = 0x80000000u;              // first pk of a word: at most four segments (no longer read)
 constexpr int SL_GX = 4;                                // least zero guard, word columns on either side
 constexpr int SL_LANES = 64;
-constexpr int SL_BLOCK = 64;                            // rows between two meetings of a workgroup (row counts leave its LDS)
+#ifndef SL_BLOCK_ROWS
+#define SL_BLOCK_ROWS 64                                // (development builds try 16 / 32 with SLANE_BLOCK of tools/gen_slane_asm.py)
+#endif
+constexpr int SL_BLOCK = SL_BLOCK_ROWS;                 // rows between two meetings of a workgroup (row counts leave its LDS)
 constexpr int SL_DUMP = 13;                             // registers a wave dumps per word: planes p0..p12 (the parked carries of the
                                                         // carry-save tree are spent at the end: the records are a multiple of 64)
 constexpr int SL_MAX_RECORDS = 1 << SL_DUMP;            // a column count must fit the planes

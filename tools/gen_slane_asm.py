@@ -113,10 +113,11 @@ def words2(out, sset, S, d0, d1, E, t):
             for j in js:
                 if not NOM0:
                     out.append("s_lshr_b32 m0, %s, 5" % pk(k, j))        # ring index + SRC0_REL | SRC1_REL
+                shift = "5" if "constshift" in ABLATE else pk(k, j)  # (timing probe: what the SGPR operand of a vector instruction costs)
                 if j == 0:   # (index - 1, index) -> the word
-                    out.append("v_alignbit_b32 v%d, v%d, v%d, %s" % (D[k], RING, RING - 1, pk(k, j)))
+                    out.append("v_alignbit_b32 v%d, v%d, v%d, %s" % (D[k], RING, RING - 1, shift))
                 else:
-                    out.append("v_alignbit_b32 v%d, v%d, v%d, %s" % (X[k][(j - 1) & 3], RING + 1, RING, pk(k, j)))
+                    out.append("v_alignbit_b32 v%d, v%d, v%d, %s" % (X[k][(j - 1) & 3], RING + 1, RING, shift))
         funnels = [j for j in js if j > 0]
         if not funnels:
             continue  # (a word of one segment: M0 is reset by the next indexed write, or by the row's last word below)
@@ -126,7 +127,7 @@ def words2(out, sset, S, d0, d1, E, t):
                 if j % 2 == 1 and "noq" not in ABLATE:  # the shifts of slots j, j + 1 sit in slots j - 1, j: an even-aligned SGPR pair
                     out.append("s_lshr_b64 %s, s[%d:%d], 21" % ("s[10:11]" if k == 0 else "vcc", sset + k * S + j - 1, sset + k * S + j))
             for k in range(2):
-                out.append("v_alignbit_b32 v%d, v%d, v%d, %s" % (D[k], X[k][(j - 1) & 3], D[k], Q[k][(j - 1) & 1]))
+                out.append("v_alignbit_b32 v%d, v%d, v%d, %s" % (D[k], X[k][(j - 1) & 3], D[k], "7" if "constshift" in ABLATE else Q[k][(j - 1) & 1]))
     if E == 1:
         out.append("s_mov_b32 m0, 0")  # every vector instruction outside the words runs unindexed
 
