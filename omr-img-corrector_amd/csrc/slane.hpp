@@ -18,8 +18,10 @@
 //                its word columns from the row's own column base cb(s) on (slane_ring_register: a row of three columns keeps
 //                its middle column twice)
 //   words      : destination word w covers destination columns 32 w - off .. 32 w - off + 31 with off = (32 - cols % 32)
-//                % 32: the row's LAST column is the last bit of the last word, the columns that do not exist are
-//                the first bits of word 0
+//                % 32 (slane_grid_offset): the row's LAST column is the last bit of the last word, the columns that do not
+//                exist are the first bits of word 0 -- a white run, one segment.  When that would leave word 0 with 29 bits or
+//                more (a word that can need all 8 slots for itself at 10 degrees) the grid is moved 16 columns further: word 0
+//                and the last word are both short then, for one more word per row
 //   records    : one per destination row, plus SL_PRE virtual rows ahead of row 0 that only fill the ring and virtual
 //                rows at the end up to a whole turn (slane_exec_records; they are numbered so that the last is a multiple of 64).  Two streams per strip (format v3, round 5):
 //                  fetch stream, 4 dwords per row (format v4): 2 x (E << 8) = the byte offsets of the first entries of the two
@@ -88,10 +90,18 @@ constexpr int SL_DUMP = 13;                             // registers a wave dump
                                                         // carry-save tree are spent at the end: the records are a multiple of 64)
 constexpr int SL_MAX_RECORDS = 1 << SL_DUMP;            // a column count must fit the planes
 
+// columns that do not exist in front of destination column 0 (see "words" above)
+inline int slane_grid_offset(int cols)
+{
+    const int off = (32 - cols % 32) % 32;
+    return off >= 1 && off <= 3 ? off + 16 : off;
+}
+
 struct SlaneGeom {
     int rows = 0, cols = 0;  // image
     int off = 0;             // columns that do not exist at the start of destination word 0
-    int NW = 0;              // destination words per row (= source word columns)
+    int NW = 0;              // source word columns
+    int NWd = 0;             // destination words per row: (cols + off + 31) / 32
     int gx = SL_GX, gy = 0;  // zero guard around the bit image: word columns left / right, rows above / below.  A sample
                              // that falls outside the image (warpAffine: BORDER_CONSTANT white) reads the guard's zeros
                              // through the same run as its neighbours, so border words need no extra segments
@@ -100,7 +110,7 @@ struct SlaneGeom {
     int64_t entries = 0;     // 1 + rowsG * colsG (+ 1 spare in memory: the partner of a pair that starts at the last entry)
     void set(int r, int c, int guard_cols = SL_GX, int guard_rows = 0)
     {
-        rows = r, cols = c, NW = (c + 31) / 32, off = (32 - c % 32) % 32, NS = (NW + SL_K - 1) / SL_K;
+        rows = r, cols = c, NW = (c + 31) / 32, off = slane_grid_offset(c), NWd = (c + off + 31) / 32, NS = (NWd + SL_K - 1) / SL_K;
         gx = guard_cols < SL_GX ? SL_GX : guard_cols, gy = guard_rows < 0 ? 0 : guard_rows;
         colsG = NW + 2 * gx, rowsG = rows + 2 * gy;
         entries = 1 + (int64_t)rowsG * colsG;

@@ -37,7 +37,7 @@ __device__ __forceinline__ int sb_word_runs(const SlaneGeom &g, const int32_t *_
     for (int i = 0; i < 32; i++) {
         const int x = 32 * w - g.off + i;
         int sy = -1, base = 0;
-        if (w < g.NW && x >= 0 && x < g.cols) {
+        if (w < g.NWd && x >= 0 && x < g.cols) {
             const int sx = (X0 + ad[x]) >> 10, yy = (Y0 + bd[x]) >> 10;
             if (sx >= -32 * (g.gx - 1) && sx < g.cols + 32 * (g.gx - 1) && yy >= -g.gy && yy < g.rows + g.gy) sy = yy + g.gy, base = sx - i;
         }

@@ -87,7 +87,7 @@ inline int word_segments(const SlaneGeom &g, const int32_t *ad, const int32_t *b
     for (int i = 0; i < 32; i++) {
         const int x = 32 * w - g.off + i;
         int sy = -1, base = 0;
-        if (w < g.NW && x >= 0 && x < g.cols) {
+        if (w < g.NWd && x >= 0 && x < g.cols) {
             const int sx = (X0 + ad[x]) >> 10, yy = (Y0 + bd[x]) >> 10;
             // inside the image, or inside its zero guard (BORDER_CONSTANT white = the guard's zeros, read through the
             // same run); beyond the guard: a white run.  Source rows are kept as row + gy (never negative).

@@ -61,7 +61,10 @@ def run_lanes(scans, max_angle, step, lanes, want_proj=()):
 
 
 @pytest.mark.parametrize("rows,cols,max_angle,step,n", [(200, 300, 5, 0.5, 70), (97, 131, 9, 1.5, 64), (333, 64, 10, 1.0, 5),
-                                                        (120, 1000, 3, 0.25, 130), (5003, 150, 4, 1.0, 66)])
+                                                        (120, 1000, 3, 0.25, 130), (5003, 150, 4, 1.0, 66),
+                                                        # widths = 31 / 30 modulo 32 at +-10 degrees: the destination grid is
+                                                        # moved so that no partial word needs a ninth slot (slane_grid_offset)
+                                                        (260, 607, 10, 2.5, 66), (180, 958, 10, 5.0, 9)])
 def test_lanes_match_the_oracle(oracle, rows, cols, max_angle, step, n):
     scans = make_scans(rows, cols, n, rows + cols)
     N, A = oracle.candidate_count(max_angle, step)
@@ -281,7 +284,8 @@ def test_lanes_five_to_eight_scan_groups_every_scan(oracle, n):
 
 
 @pytest.mark.parametrize("rows,cols,max_angle,step", [(200, 300, 5, 0.5), (333, 64, 10, 1.0), (1754, 1240, 10, 0.25), (97, 131, 9, 1.5),
-                                                      (640, 1000, 7, 0.5), (3508, 2480, 10, 0.05), (7016, 300, 6, 1.0)])
+                                                      (640, 1000, 7, 0.5), (3508, 2480, 10, 0.05), (7016, 300, 6, 1.0),
+                                                      (700, 1343, 10, 1.0), (400, 94, 10, 2.0)])
 def test_device_built_programs_equal_the_host_generator(rows, cols, max_angle, step):
     """The plan's programs are generated on the device (slane_build.hip); the host generator (slane_plan.cpp, the one
     tests/test_slane_program.py runs through the CPU interpreter against the oracle) must produce the same buffer,

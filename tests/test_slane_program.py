@@ -31,6 +31,14 @@ def interleave(scans, gx, gy):
     return ent, NW, colsG
 
 
+def grid(cols):
+    """slane.hpp, slane_grid_offset / SlaneGeom::set: columns that do not exist in front of destination column 0, strips"""
+    off = (32 - cols % 32) % 32
+    if 1 <= off <= 3:
+        off += 16
+    return off, ((cols + off + 31) // 32 + 1) // 2
+
+
 def strip_program(rows, cols, M, strip):
     L = oics.lib()
     rd, nrec, pre, most, gx, gy = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
@@ -57,8 +65,7 @@ def sweep_by_programs(scans, Ms):
     OL.orc_slane_run_strip.restype = C.c_int
     lanes = len(scans)
     rows, cols = scans[0].shape
-    NW = (cols + 31) // 32
-    NS = (NW + 1) // 2
+    off, NS = grid(cols)
     A = len(Ms)
     ents = {}  # the interleaved bit image per guard size (the single-matrix entry point sizes the guard per matrix)
     vp = np.zeros((lanes, A, cols), np.uint32)
@@ -79,7 +86,7 @@ def sweep_by_programs(scans, Ms):
                                         ent.ctypes.data_as(u32p), ent.shape[0], lanes, hrow.ctypes.data_as(u32p),
                                         vcol.ctypes.data_as(u32p))
             assert rc == 0, "interpreter rejected the program of candidate %d strip %d" % (a, st)
-            off = (32 - cols % 32) % 32  # slane.hpp: destination word w covers columns 32 w - off ..
+            # (slane.hpp: destination word w covers columns 32 w - off ..)
             for b in range(64):
                 col = st * 64 - off + b
                 if 0 <= col < cols:
@@ -91,7 +98,10 @@ def sweep_by_programs(scans, Ms):
 
 
 @pytest.mark.parametrize("rows,cols,max_angle,step", [(120, 200, 10, 1.0), (97, 131, 5, 0.5), (64, 64, 9, 3.0),
-                                                      (300, 70, 10, 2.5), (33, 450, 8, 2.0)])
+                                                      (300, 70, 10, 2.5), (33, 450, 8, 2.0),
+                                                      # widths = 31 / 30 / 29 modulo 32 at the sweep's edge: word 0 would
+                                                      # hold 31 / 30 / 29 real bits and need a ninth slot for its white run
+                                                      (210, 95, 10, 5.0), (150, 222, 10, 5.0), (90, 349, 10, 10.0)])
 def test_programs_reproduce_the_oracle_sweep(rows, cols, max_angle, step):
     rng = np.random.Generator(np.random.PCG64(rows * 1000 + cols))
     scans = []
