@@ -184,7 +184,7 @@ int SlanePlan::build(const SweepTables &t, bool on_host)
         size_t at[2] = {0, 0};
         while (at[0] < side[0].size() || at[1] < side[1].size()) {
             int pick = at[0] >= side[0].size() ? 1 : at[1] >= side[1].size() ? 0 : (weight(side[0][at[0]]) >= weight(side[1][at[1]]) ? 0 : 1);
-            for (int k = 0; k < 32 && at[pick] < side[pick].size(); k++) merged.push_back(side[pick][at[pick]++]);
+            for (int k = 0; k < SL_CHUNK && at[pick] < side[pick].size(); k++) merged.push_back(side[pick][at[pick]++]);
         }
         order.swap(merged);
     }
@@ -192,8 +192,8 @@ int SlanePlan::build(const SweepTables &t, bool on_host)
     for (int a : order)
         for (int st = 0; st < NS; st++) tasks.push_back(a * NS + st);
     chunk_weight.clear(), chunk_size.clear();
-    for (size_t c0 = 0; c0 < order.size(); c0 += 32) {
-        const size_t n = std::min<size_t>(32, order.size() - c0);
+    for (size_t c0 = 0; c0 < order.size(); c0 += SL_CHUNK) {
+        const size_t n = std::min<size_t>(SL_CHUNK, order.size() - c0);
         double w = 0;
         // (a workgroup's time ~ 5 + executed slots per word, measured: 0.70 ms at 2 slots, 1.21 ms at 7 -- tools/kstamps_lanes.py)
         for (size_t i = 0; i < n; i++) w += 5.0 * NS + weight(order[c0 + i]);

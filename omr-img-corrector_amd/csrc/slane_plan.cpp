@@ -228,4 +228,46 @@ bool slane_strip_program(const SlaneGeom &g, const int32_t *ad, const int32_t *b
     return true;
 }
 
+// The units of a launch (unit u = chunk (u / ncq) of SL_CHUNK candidates in launch order x (strip group, scan-group group) u % ncq)
+// dealt to the 8 XCDs in slots of SL_SLOT workgroups (a quarter of a unit): heaviest first, each item to the XCD with the least
+// work so far.  A full chunk's unit is ONE item -- its four quarters stay on one XCD, that is the point of a unit --, the
+// quarters of the last, partial chunk are dealt one by one: they even out what the whole units left (8 000 workgroups of a
+// 512-scan A4 launch: 1 000 per XCD; whole and half units gave 992 / 1 008 and four XCDs idle for the last 0.4 ms).
+// chunk_weight[c] = the work of a workgroup of chunk c (any unit of measure), chunk_size[c] = its candidates.
+// Returns the table [8][per_xcd] of unit * 4 + quarter (-1 = none).
+std::vector<int32_t> slane_deal_units(const std::vector<double> &chunk_weight, const std::vector<int> &chunk_size, int ncq, int *per_xcd)
+{
+    static_assert(SL_CHUNK == 4 * SL_SLOT, "a unit is four slots");
+    struct Item {
+        int unit, q0, nq;
+        double w;
+    };
+    std::vector<Item> items;
+    const int nchunks = (int)chunk_weight.size();
+    for (int c = 0; c < nchunks; c++)
+        for (int cq = 0; cq < ncq; cq++) {
+            const int u = c * ncq + cq, n = chunk_size[(size_t)c];
+            if (n == SL_CHUNK) items.push_back({u, 0, 4, chunk_weight[(size_t)c] * n});
+            else
+                for (int q = 0; q * SL_SLOT < n; q++) items.push_back({u, q, 1, chunk_weight[(size_t)c] * std::min(SL_SLOT, n - q * SL_SLOT)});
+        }
+    std::stable_sort(items.begin(), items.end(), [](const Item &a, const Item &b) { return a.w > b.w; });
+    std::vector<std::vector<int32_t>> mine(8);
+    double load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (const Item &it : items) {
+        int best = 0;
+        for (int x = 1; x < 8; x++)
+            if (load[x] < load[best]) best = x;
+        for (int q = 0; q < it.nq; q++) mine[(size_t)best].push_back(it.unit * 4 + it.q0 + q);
+        load[best] += it.w;
+    }
+    size_t most = 0;
+    for (auto &m : mine) most = std::max(most, m.size());
+    std::vector<int32_t> tab(8 * most, -1);
+    for (int x = 0; x < 8; x++)
+        for (size_t k = 0; k < mine[(size_t)x].size(); k++) tab[(size_t)x * most + k] = mine[(size_t)x][k];
+    *per_xcd = (int)most;
+    return tab;
+}
+
 }  // namespace omr

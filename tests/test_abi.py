@@ -175,3 +175,65 @@ int main() {
     assert r.returncode == 0 and r.stdout.strip() == "ok", (r.returncode, r.stdout, r.stderr)
     # and the production synchronisation points call it
     assert src.count("guard_verdict(") >= 4 and "check_guards(ctx)" in src.split("int omr_batch_sync(omr_batch_ctx *ctx)")[1][:600]
+
+
+def test_units_are_dealt_to_the_xcds_evenly():
+    """slane_deal_units (csrc/slane_plan.cpp): the workgroups of a scan-lane launch reach an XCD only through the ids that XCD is
+    sent, so the host deals the launch's units to the 8 XCDs.  Compiled on its own (no GPU, no HIP): every (unit, quarter) of the
+    C2 launch -- 400 candidates in chunks of 32, 10 strip groups x 2 groups of scan groups -- appears exactly once, a full unit's
+    four quarters sit side by side on one XCD, and the XCDs' workloads differ by less than one quarter unit."""
+    import re
+    import shutil
+    import subprocess
+    import tempfile
+    src = open(os.path.join(PKG, "csrc", "slane_plan.cpp")).read()
+    m = re.search(r"std::vector<int32_t> slane_deal_units\(.*?\n\}\n", src, re.S)
+    assert m, "slane_deal_units not found in slane_plan.cpp"
+    if not shutil.which("g++"):
+        pytest.skip("g++ not available")
+    prog = """#include <stdint.h>
+#include <stdio.h>
+#include <algorithm>
+#include <map>
+#include <vector>
+constexpr int SL_CHUNK = 32, SL_SLOT = 8;
+%s
+int main() {
+    std::vector<double> w;
+    std::vector<int> n;
+    for (int c = 0; c < 13; c++) w.push_back(5.0 + 7.0 - 0.4 * c), n.push_back(c < 12 ? 32 : 16);
+    const int ncq = 20;
+    int per = 0;
+    const std::vector<int32_t> tab = slane_deal_units(w, n, ncq, &per);
+    if ((int)tab.size() != 8 * per) return 1;
+    std::map<int, int> seen;
+    double load[8] = {0}, lightest = 1e30;
+    int wgs[8] = {0};
+    for (int x = 0; x < 8; x++)
+        for (int k = 0; k < per; k++) {
+            const int e = tab[x * per + k];
+            if (e < 0) continue;
+            if (seen[e]++) return 2;                                   // a quarter dealt twice
+            const int u = e >> 2, q = e & 3, c = u / ncq;
+            if (c >= 13 || q * SL_SLOT >= n[c]) return 3;             // a quarter that holds no candidate
+            const int cand = std::min(SL_SLOT, n[c] - q * SL_SLOT);
+            load[x] += w[c] * cand, wgs[x] += cand;
+            lightest = std::min(lightest, w[c] * cand);
+            if (n[c] == 32 && q > 0 && (k == 0 || tab[x * per + k - 1] != e - 1)) return 4;  // a full unit stays together
+        }
+    int total = 0;
+    for (int x = 0; x < 8; x++) total += wgs[x];
+    if (total != 400 * ncq || (int)seen.size() != (12 * 4 + 2) * ncq) return 5;
+    const double lo = *std::min_element(load, load + 8), hi = *std::max_element(load, load + 8);
+    if (hi - lo > lightest * 1.0001) return 6;
+    for (int x = 0; x < 8; x++) if (wgs[x] != 1000) return 7;           // 8 000 workgroups: 1 000 per XCD
+    puts("ok");
+    return 0;
+}
+""" % m.group(0)
+    with tempfile.TemporaryDirectory() as td:
+        open(os.path.join(td, "u.cpp"), "w").write(prog)
+        subprocess.check_call(["g++", "-std=c++17", "-O1", "-o", os.path.join(td, "u"), os.path.join(td, "u.cpp")])
+        r = subprocess.run([os.path.join(td, "u")], capture_output=True, text=True)
+    assert r.returncode == 0 and r.stdout.strip() == "ok", (r.returncode, r.stdout, r.stderr)
+
