@@ -24,6 +24,16 @@ namespace omr {
 #define DW_TH (LINEAR ? DW_TH_LIN : DW_TH_NN)
 
 __device__ __forceinline__ int dw_mad24(int a, int b, int c) { return __mul24(a, b) + c; }  // v_mad_i32_i24
+// The same, spelled out: the compiler turns __mul24 of operands it has folded into other arithmetic back into a plain multiply
+// and then picks v_mul_lo_u32 -- a quarter-rate instruction (16 cycles per wave: four of the usual) -- for it; the vertical
+// blend of the bilinear tap was one (round 5, second half: the disassembly showed 12 such multiplies per 8 pixels, 29 % of the
+// loop's vector time).  |a|, |b| < 2^23 is the caller's business.
+__device__ __forceinline__ int dw_mad24_asm(int a, int b, int c)
+{
+    int r;
+    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
 __device__ __forceinline__ uint8_t dw_sat_u8(int v) { return (uint8_t)(v < 0 ? 0 : v > 255 ? 255 : v); }
 
 template <bool LINEAR>
@@ -100,7 +110,10 @@ __global__ __launch_bounds__(64) void deskew_tiles_kernel(const DeskewPass p, De
         // ... nor a scan of 2 GB or more: the staging loads address it by 32-bit byte offsets through a buffer descriptor
         const bool dwords = ((p.sstep | p.scan_stride | (int64_t)(uintptr_t)p.src | (int64_t)p.scols) & 3) == 0 &&
                             (int64_t)p.srows * p.sstep < (int64_t)0x7fffffff;
-        const bool staged = dwords && bwb > 0 && bh > 0 && (int64_t)bwb * bh <= DW_LDS && bx0 > -30000 && bx1 < 30000 &&
+        // ... nor a canvas of 2 GB or more, or with rows of 16 MB: the staged path's stores address the scan's canvas by 32-bit
+        // offsets made with a 24-bit multiply (a 64-bit address per store row cost two full-rate-quarter multiplies, see below)
+        const bool canvas32 = p.dstep < (1 << 24) && (int64_t)p.DR * p.dstep < (int64_t)0x7fffffff;
+        const bool staged = dwords && canvas32 && bwb > 0 && bh > 0 && (int64_t)bwb * bh <= DW_LDS && bx0 > -30000 && bx1 < 30000 &&
                             by0 > -30000 && by1 < 30000;
         // A tile whose box lies wholly outside the scan (the corners of a CONTAIN canvas: up to a fifth of it at 10 degrees)
         // is the border value: every tap of every sample is outside, NEAREST takes it as it is and the bilinear weights of
@@ -313,8 +326,8 @@ __global__ __launch_bounds__(256, DW_MIN_BLOCKS) void deskew_warp_kernel(const D
     // stores: 32-bit offsets from the scan's canvas (a canvas is far below 4 GB); a tile whose every thread stores whole
     // aligned dwords -- all but the canvas's last tile column, or an unaligned canvas -- has no per-lane store branches
     const uint32_t dstep32 = (uint32_t)p.dstep;
-    const bool aligned4 = ((p.dstep | p.out_stride | (int64_t)(uintptr_t)p.dst) & 3) == 0 && p.dstep < (1 << 24) &&
-                          (int64_t)p.DR * p.dstep < (int64_t)0x7fffffff;
+    // (a staged tile's canvas is below 2 GB with rows below 16 MB: deskew_tiles_kernel)
+    const bool aligned4 = ((p.dstep | p.out_stride | (int64_t)(uintptr_t)p.dst) & 3) == 0;
     const bool tile_whole = aligned4 && tx0 + DW_TW <= dcols;  // workgroup-uniform
     const bool whole = aligned4 && x0 + 4 <= dcols;
     const int rt0 = (int)(threadIdx.x >> 5);  // this thread's first row of the tile; rowtab is clamped to the tile's last row
@@ -341,7 +354,7 @@ __global__ __launch_bounds__(256, DW_MIN_BLOCKS) void deskew_warp_kernel(const D
                     const uint8_t *B = &box[idx];
                     const int b0 = B[0], b1 = B[1], b2 = B[bwb], b3 = B[bwb + 1];
                     const int top = dw_mad24(fx, b1 - b0, b0 << 5), bot = dw_mad24(fx, b3 - b2, b2 << 5);
-                    bts[j] = (uint32_t)(dw_mad24(fy, bot - top, (top << 5) + 512) >> 10);
+                    bts[j] = (uint32_t)(dw_mad24_asm(fy, bot - top, (top << 5) + 512) >> 10);
                 }
             }
             // four bytes, each < 256 in a register of its own -> one dword: three v_lshl_or
@@ -356,7 +369,9 @@ __global__ __launch_bounds__(256, DW_MIN_BLOCKS) void deskew_warp_kernel(const D
             } else if (whole) {
                 *(uint32_t *)(dst + off) = outs[kk];
             } else {
-                uint8_t *D = dst + (int64_t)min(yq + 8 * (k0 + kk), ty1) * p.dstep + x0;
+                // (the same 32-bit offset: a 64-bit row address here is computed for every row, taken or not -- the compiler
+                // hoists it above the branch -- with two quarter-rate multiplies)
+                uint8_t *D = dst + off;
                 for (int j = 0; j < 4 && x0 + j < dcols; j++) D[j] = (uint8_t)(outs[kk] >> (8 * j));
             }
         }
