@@ -213,6 +213,9 @@ if read("lds_dma_window.log"):
     with open(os.path.join(dst, tag + "_lds_dma.md"), "w") as f:
         f.write("# %s -- LDS-DMA probe behind DESIGN.md section 4.1 (tools/lds_dma_window.hip)\n\n" % tag + STAMP)
         f.write("```\n%s```\n" % read("lds_dma_window.log"))
+        if read("lds_u16_probe.log"):
+            f.write("\n`tools/lds_u16_probe.hip` (DESIGN.md section 4.3: the bilinear taps of the batch warp): 16-bit LDS reads at byte "
+                    "addresses -- do they work, what do they cost next to byte reads? -- and `v_dot4_u32_u8`:\n\n```\n%s```\n" % read("lds_u16_probe.log"))
 
 if read("mov64_probe.log") or read("pf_probe.log"):
     with open(os.path.join(dst, tag + "_slane_microbench.md"), "w") as f:

@@ -96,8 +96,8 @@ else
   echo "[profile] hough done"
   step core_protocol timeout -k 10 600 python3 tools/core_protocol.py
   # 6. micro-benchmarks behind DESIGN.md's statements
-  for t in lds_dma_window mov64_probe pf_probe; do
-    rm -f "$OUT/$t.log"; hipcc -O2 --offload-arch=gfx950 -Wno-inline-asm tools/$t.hip -o /tmp/$t > "$OUT/$t.build.log" 2>&1 && timeout -k 10 200 /tmp/$t > "$OUT/$t.log" 2>&1 || true
+  for t in lds_dma_window mov64_probe pf_probe lds_u16_probe; do
+    rm -f "$OUT/$t.log"; hipcc -O2 --offload-arch=gfx950 -Wno-inline-asm -Wno-unused-value tools/$t.hip -o /tmp/$t > "$OUT/$t.build.log" 2>&1 && timeout -k 10 200 /tmp/$t > "$OUT/$t.log" 2>&1 || true
   done
 fi
 echo "[profile] part $PART done"
