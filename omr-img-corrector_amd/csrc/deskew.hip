@@ -341,21 +341,34 @@ __global__ __launch_bounds__(256, DW_MIN_BLOCKS) void deskew_warp_kernel(const D
         for (int kk = 0; kk < DW_KU; kk++) {
             const int2_t rw = rowtab[rt0 + 8 * (k0 + kk)];
             uint32_t bts[4];
+            if constexpr (LINEAR) {
+                // ((v0 w0 + v1 w1 + v2 w2 + v3 w3 + 2^14) >> 15 with w = 32 (32 - fy)(32 - fx), ..) = two horizontal blends and
+                // a vertical one: the same integer, and <= 255 without a clamp.  Round 5, second half -- 18.5 -> 16.7 vector
+                // instructions per pixel: the two taps of a box row are packed into 16-bit halves (one v_lshl_or) and blended by
+                // ONE v_dot2_u32_u16 with the weights (64 - 2 fx, 2 fx) -- twice the reference's, so that with fy * 32 for the
+                // vertical weight the accumulator is the reference's << 6 and the output byte is its byte 2: no shift, v_perm
+                // packs the four pixels.  (ds_read_u8_d16 / _d16_hi would pack for free, but on this chip -- SRAM ECC -- a d16
+                // load zeroes the half it does not write: tried, wrong bytes; 16-bit LDS reads at byte addresses would halve the
+                // LDS instructions and cost 6 - 12 x their time: tools/lds_u16_probe.hip.)
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    typedef unsigned short v2u16 __attribute__((ext_vector_type(2)));
+                    const int Xf = rw.x + adv[j], Yf = rw.y + bdv[j];
+                    const uint8_t *Bx = &box[dw_mad24(Yf >> 10, bwb, Xf >> 10)];
+                    const uint32_t t = (uint32_t)Bx[0] | ((uint32_t)Bx[1] << 16), u = (uint32_t)Bx[bwb] | ((uint32_t)Bx[bwb + 1] << 16);
+                    const v2u16 w = __builtin_bit_cast(v2u16, __umul24((uint32_t)(Xf >> 5) & 31u, 131070u) + 64u);  // (64 - 2 fx) | 2 fx << 16
+                    const int top2 = (int)__builtin_amdgcn_udot2(__builtin_bit_cast(v2u16, t), w, 0u, false);
+                    const int bot2 = (int)__builtin_amdgcn_udot2(__builtin_bit_cast(v2u16, u), w, 0u, false);
+                    bts[j] = (uint32_t)dw_mad24_asm(Yf & 0x3e0, bot2 - top2, (top2 << 10) + 32768);  // the pixel is byte 2
+                }
+                outs[kk] = __builtin_amdgcn_perm(bts[1], bts[0], 0x0c0c0602u) | __builtin_amdgcn_perm(bts[3], bts[2], 0x06020c0cu);
+                continue;
+            }
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 const int Xf = rw.x + adv[j], Yf = rw.y + bdv[j];
                 const int idx = dw_mad24(Yf >> 10, bwb, Xf >> 10);
-                if (!LINEAR) {
-                    bts[j] = box[idx];
-                } else {
-                    // ((v0 w0 + v1 w1 + v2 w2 + v3 w3 + 2^14) >> 15 with w = 32 (32 - fy)(32 - fx), ..) as two horizontal
-                    // blends and a vertical one: the same integer, and <= 255 without a clamp
-                    const int fx = (Xf >> 5) & 31, fy = (Yf >> 5) & 31;
-                    const uint8_t *B = &box[idx];
-                    const int b0 = B[0], b1 = B[1], b2 = B[bwb], b3 = B[bwb + 1];
-                    const int top = dw_mad24(fx, b1 - b0, b0 << 5), bot = dw_mad24(fx, b3 - b2, b2 << 5);
-                    bts[j] = (uint32_t)(dw_mad24_asm(fy, bot - top, (top << 5) + 512) >> 10);
-                }
+                bts[j] = box[idx];
             }
             // four bytes, each < 256 in a register of its own -> one dword: three v_lshl_or
             outs[kk] = ((bts[1] << 8) | bts[0]) | (((bts[3] << 8) | bts[2]) << 16);
