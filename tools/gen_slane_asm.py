@@ -62,7 +62,9 @@ import os
 BLOCK = int(os.environ.get("SLANE_BLOCK", "64"))  # rows between two meetings of the workgroup (16, 32 or 64): its LDS row-count buffers hold BLOCK / 2 pair rows
 LB = {16: 4, 32: 5, 64: 6}[BLOCK]
 TURN = int(os.environ.get("SLANE_TURN", "16"))  # rows per turn of the loop (4, 8 or 16): the loop's own scalar work is paid once per turn
-ABLATE = os.environ.get("SLANE_ABLATE", "").split(",")  # timing probes only (results are wrong except noskip): norec, noatomic, nofetch, noskip
+# timing probes only -- their RESULTS ARE WRONG, only the time means something (profiles/r05_lanes_ablation.md): norec, hotrec,
+# nofetch, hotfetch, hotsgpr, nowait, nocommit, noatomic, nobarrier, nom0, noq, constshift, lessE, prio
+ABLATE = os.environ.get("SLANE_ABLATE", "").split(",")
 PREFETCH = int(os.environ.get("SLANE_PREFETCH", "1"))  # turns ahead the record streams are pulled into L2 by a vector load (0 = off)
 LOADBITS = os.environ.get("SLANE_LOADBITS", "")  # cache-policy bits of the source loads (measured: profiles/r05_lanes_ablation.md)
 if LOADBITS:

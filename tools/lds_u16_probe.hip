@@ -8,7 +8,7 @@
 #define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
 
 template <int MODE>
-__global__ __launch_bounds__(256) void probe(const uint8_t *src, uint32_t *out, int iters, int stride)
+__global__ __launch_bounds__(256) void probe(const uint8_t *src, uint32_t *out, int iters, int stride, uint32_t amask)
 {
     __shared__ __attribute__((aligned(16))) uint8_t box[16384];
     for (int i = threadIdx.x; i < 16384; i += 256) box[i] = src[i];
@@ -18,7 +18,7 @@ __global__ __launch_bounds__(256) void probe(const uint8_t *src, uint32_t *out, 
     const uint32_t base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t *)box;
     for (int it = 0; it < iters; it++) {
         uint32_t v = 0;
-        const uint32_t ad = base + a;
+        const uint32_t ad = base + (a & amask);  // amask = ~0: any byte address; ~1: even addresses only
         if (MODE == 0) {  // two byte reads per row, packed by hand
             uint32_t b0, b1, b2, b3;
             asm volatile("ds_read_u8 %0, %4\n\tds_read_u8 %1, %4 offset:1\n\tds_read_u8 %2, %4 offset:160\n\tds_read_u8 %3, %4 offset:161\n\ts_waitcnt lgkmcnt(0)"
@@ -49,16 +49,18 @@ int main()
     const int blocks = 2048, iters = 2000;
     CHECK(hipMalloc(&o, blocks * 256 * 4));
     uint32_t *ho = (uint32_t *)malloc(blocks * 256 * 4);
-    for (int stride = 1; stride <= 4; stride++) {
+    for (int pass = 0; pass < 5; pass++) {
+        const int stride = pass < 4 ? pass + 1 : 2;
+        const uint32_t amask = pass < 4 ? ~0u : ~1u;
         uint32_t ref[256];
         for (int mode = 0; mode < 3; mode++) {
             hipEvent_t e0, e1;
             hipEventCreate(&e0), hipEventCreate(&e1);
             for (int rep = 0; rep < 2; rep++) {
                 hipEventRecord(e0);
-                if (mode == 0) hipLaunchKernelGGL(probe<0>, dim3(blocks), dim3(256), 0, 0, d, o, iters, stride);
-                else if (mode == 1) hipLaunchKernelGGL(probe<1>, dim3(blocks), dim3(256), 0, 0, d, o, iters, stride);
-                else hipLaunchKernelGGL(probe<2>, dim3(blocks), dim3(256), 0, 0, d, o, iters, stride);
+                if (mode == 0) hipLaunchKernelGGL(probe<0>, dim3(blocks), dim3(256), 0, 0, d, o, iters, stride, amask);
+                else if (mode == 1) hipLaunchKernelGGL(probe<1>, dim3(blocks), dim3(256), 0, 0, d, o, iters, stride, amask);
+                else hipLaunchKernelGGL(probe<2>, dim3(blocks), dim3(256), 0, 0, d, o, iters, stride, amask);
                 hipEventRecord(e1);
                 CHECK(hipDeviceSynchronize());
             }
@@ -69,8 +71,8 @@ int main()
             if (mode == 0) memcpy(ref, ho, sizeof ref);
             else for (int i = 0; i < 256; i++) wrong += ho[i] != ref[i];
             const double per = ms * 1e-3 * 2.4e9 / ((double)iters * blocks * 4 / 1024.0);  // cycles per wave-iteration per SIMD
-            printf("lane stride %d bytes, %s: %.3f ms, %.1f cycles per wave and tap pair on a SIMD, wrong lanes %d\n", stride,
-                   mode == 0 ? "4 x ds_read_u8 + 3 pack ops" : mode == 1 ? "ds_read_u16_d16 + _d16_hi       " : "2 x ds_read_u16 + 1 pack op    ", ms, per, wrong);
+            printf("%slane stride %d bytes, %s: %.3f ms, %.1f cycles per wave and tap pair on a SIMD, wrong lanes %d\n", amask == ~1u ? "EVEN addresses only, " : "", stride,
+                   mode == 0 ? "4 x ds_read_u8 + 3 pack ops" : mode == 1 ? "ds_read_u16_d16 + _d16_hi (SRAM ECC: the other half is zeroed)" : "2 x ds_read_u16 + 1 pack op    ", ms, per, wrong);
         }
     }
     uint32_t ha[64], hb[64], *da, *db, *dd;
