@@ -239,9 +239,7 @@ int omr_batch_lanes_projections(omr_batch_ctx *ctx, int32_t set, int32_t scan, i
 /* A context for repeated host-memory batches of one shape and sweep: per device the sweep plan (the scan-lane sweep when
  * the candidates fit it and at least 64 scans per device are expected, else the run-merging path), a pinned ring of three
  * 16-scan slots and two device stages of one launch (64 scans) each.  n_devices <= 0 = every visible device,
- * n_devices > omr_device_count() is OMR_ERR_BADARG.  max_scans = the largest n a run may carry.  The context owns a pool
- * of copier / packer threads, one per hardware thread, 32 at most (environment: OMR_HOST_COPY_THREADS = 1 .. 256; measured:
- * 16 .. 96 threads give the same rate at A4 -- a batch of 512 scans is bound by filling and draining the pipeline). */
+ * n_devices > omr_device_count() is OMR_ERR_BADARG.  max_scans = the largest n a run may carry. */
 typedef struct omr_host_batch omr_host_batch;
 int omr_host_batch_create(int32_t rows, int32_t cols, uint16_t max_angle, double step, int32_t n_devices,
                           int32_t max_scans, omr_host_batch **out);

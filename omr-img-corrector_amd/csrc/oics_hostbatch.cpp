@@ -9,7 +9,6 @@
 //   --omr_batch_run_device (scan-lane sweep when the candidates fit it, else the run-merging path)--> results, one
 //   download at the end.  Scan i goes to device i % n_devices; the only "collective" is the host-side gather.
 //   The copier threads are a pool that lives as long as the context (round 4 started 16 threads per 16-scan chunk).
-#include <stdlib.h>
 #include <string.h>
 
 #include <emmintrin.h>
@@ -203,14 +202,8 @@ int omr_host_batch_create(int32_t rows, int32_t cols, uint16_t max_angle, double
     if (hb->A <= 0) return fail(OMR_ERR_BADARG, "empty candidate range");
     hb->rows = rows, hb->cols = cols, hb->step = step, hb->n_devices = n_devices;
     {
-        // the copier / packer threads: one per hardware thread, 32 at most (OMR_HOST_COPY_THREADS overrides: 1 .. 256)
         const unsigned hw = std::thread::hardware_concurrency();
-        unsigned nt = std::max(2u, std::min(hw ? hw : 8u, 32u));
-        if (const char *e = getenv("OMR_HOST_COPY_THREADS")) {
-            const int v = atoi(e);
-            if (v >= 1 && v <= 256) nt = (unsigned)v;
-        }
-        hb->pool.reset(new WorkerPool((int)nt));
+        hb->pool.reset(new WorkerPool((int)std::max(2u, std::min(hw ? hw : 8u, 32u))));
     }
     const int per_dev = (max_scans + n_devices - 1) / n_devices;
     const size_t img = (size_t)rows * cols;
