@@ -208,6 +208,15 @@ with open(os.path.join(dst, tag + "_deskew.md"), "w") as f:
                 % "\n".join(l for l in read("deskew64.log").splitlines() if "amdgpu.ids" not in l))
         stats_table("deskew64_stats", f, 8)
 
+# ---- where and when the workgroups of a scan-lane launch ran
+if read("kstamps_lanes.log"):
+    with open(os.path.join(dst, tag + "_lanes_stamps.md"), "w") as f:
+        f.write("# %s -- one scan-lane launch of 512 A4 scans, workgroup by workgroup (tools/kstamps_lanes.py, library built with -DSLANE_STAMP)\n\n" % tag + STAMP)
+        f.write("Start, end (constant 100 MHz clock) and XCC id of every workgroup: the units are dealt to the XCDs by `slane_deal_units` "
+                "(DESIGN.md section 4.6), so every XCD runs 1 000 of the 8 000 workgroups and all end within 0.1 ms of each other; what is "
+                "left between a CU's busy time and the launch's span is the tail of the last workgroups.\n\n```\n%s```\n"
+                % "\n".join(l for l in read("kstamps_lanes.log").splitlines() if "amdgpu.ids" not in l))
+
 # ---- micro-benchmark behind DESIGN.md's LDS-DMA statements
 if read("lds_dma_window.log"):
     with open(os.path.join(dst, tag + "_lds_dma.md"), "w") as f:

@@ -67,6 +67,11 @@ elif [ "$PART" = "a" ]; then
   step threads timeout -k 10 300 python3 tools/bench_threads.py
   step ksmall timeout -k 10 300 python3 tools/ksmall.py 4096 64
   step klanes600 timeout -k 10 300 python3 tools/klanes.py 128 64 2 7016 4960
+  # where and when the workgroups of one scan-lane launch ran (a library of its own with -DSLANE_STAMP, built here)
+  rm -f "$OUT/kstamps_lanes.log"
+  bash tools/build_variant.sh stamp -DSLANE_STAMP > "$OUT/kstamps_lanes.build.log" 2>&1 && \
+    OMR_AB_LIB=omr-img-corrector_amd/lib/variants/libomrdeskew_stamp.so timeout -k 10 300 python3 tools/ab_lib.py tools/kstamps_lanes.py > "$OUT/kstamps_lanes.log" 2>&1
+  echo "kstamps_lanes rc=$?" >> "$OUT/STATUS_$PART"
   step deskew64 timeout -k 10 300 python3 tools/bench_deskew.py 6 64
   prof deskew64_stats --stats -- python3 tools/bench_deskew.py 6 64
 else
