@@ -82,8 +82,11 @@ constexpr int SL_QSHIFT = 21, SL_NSHIFT = 26;           // pk fields: second shi
 constexpr uint32_t SL_SHORT = 0x80000000u;              // first pk of a word: at most four segments (no longer read)
 constexpr int SL_GX = 4;                                // least zero guard, word columns on either side
 constexpr int SL_LANES = 64;
-constexpr int SL_CHUNK = 32;                            // candidates of a unit of slane_kernel's launch order (one workgroup each, on one XCD)
-constexpr int SL_SLOT = 8;                              // workgroups per slot of an XCD's list of units (a quarter unit: slane_deal_units)
+#ifndef SL_CHUNK_CANDIDATES
+#define SL_CHUNK_CANDIDATES 32                          // (development builds try 16 / 64: profiles/r05_lanes_ablation.md)
+#endif
+constexpr int SL_CHUNK = SL_CHUNK_CANDIDATES;           // candidates of a unit of slane_kernel's launch order (one workgroup each, on one XCD)
+constexpr int SL_SLOT = SL_CHUNK / 4;                   // workgroups per slot of an XCD's list of units (a quarter unit: slane_deal_units)
 #ifndef SL_BLOCK_ROWS
 #define SL_BLOCK_ROWS 64                                // (development builds try 16 / 32 with SLANE_BLOCK of tools/gen_slane_asm.py)
 #endif
